@@ -1,0 +1,108 @@
+"""The numpy oracle (oracle/vame_oracle.py) against golden vectors produced by the imported reference."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, golden_weights, load_golden
+from oracle import vame_oracle as vo
+
+
+def spec_of(g):
+    T, F, Z, H, FS, fut, sp = [int(v) for v in g["spec"][:7]]
+    return vo.Spec(T=T, F=F, Z=Z, H=H, FS=FS, future=bool(fut), softplus=bool(sp))
+
+
+@pytest.mark.parametrize("name,kw,mse", [
+    ("step_tiny", 0.0, "sum"), ("step_tiny", 0.25, "sum"), ("step_tiny", 1.0, "sum"),
+    ("step_tiny_oddB", 1.0, "sum"), ("step_tiny_nofut", 1.0, "sum"), ("step_tiny_softplus", 1.0, "sum"),
+    ("step_tiny_mean", 1.0, "mean"), ("step_h64", 0.5, "sum"),
+])
+def test_step_forward_losses_grads(name, kw, mse):
+    g = load_golden(name)
+    spec = spec_of(g)
+    p = golden_weights(g)
+    cache = vo.FwdCache()
+    pred, fut, z, mu, lv = vo.model_forward(p, g["x"], g["eps"], spec, True, cache)
+    tag = f"kw{kw:g}/"
+    if tag + "losses" in g and "pred" in g and kw == max(float(k[2:-7]) for k in g if k.endswith("/losses")):
+        np.testing.assert_allclose(pred, g["pred"], atol=2e-5)
+        np.testing.assert_allclose(mu, g["mu"], atol=1e-5)
+        np.testing.assert_allclose(lv, g["logvar"], atol=1e-5)
+        np.testing.assert_allclose(z, g["z"], atol=1e-5)
+        if spec.future:
+            np.testing.assert_allclose(fut, g["fut"], atol=2e-5)
+    L = vo.total_loss(pred, fut, z, mu, lv, g["x"], g["xfut"], spec, kw, mse_red=mse, mse_pred=mse)
+    ref = g[tag + "losses"]
+    for i, k in enumerate(["rec", "fut", "kl", "kmeans", "total"]):
+        assert abs(L[k] - ref[i]) <= 1e-4 * max(1.0, abs(ref[i])), (k, L[k], ref[i])
+    # the reference's (B,B)-SVD form equals the (Z,Z)-Gram form
+    assert abs(vo.cluster_loss_svd(z, spec.Z, 0.1, z.shape[0]) - ref[3]) <= 1e-4 * max(1, abs(ref[3]))
+    grads = vo.model_backward(p, cache, spec, g["x"], g["xfut"], kw, mse_red=mse, mse_pred=mse)
+    for k, gv in grads.items():
+        r = g[tag + "g/" + k]
+        tol = 2e-4 * max(1.0, np.abs(r).max())
+        np.testing.assert_allclose(gv, r, atol=tol, err_msg=k)
+
+
+def test_eval_mode_forward():
+    g = load_golden("step_tiny")
+    spec = spec_of(g)
+    p = golden_weights(g)
+    pred, fut, z, mu, lv = vo.model_forward(p, g["x"], None, spec, training=False)
+    np.testing.assert_allclose(mu, g["eval_mu"], atol=1e-5)
+    np.testing.assert_allclose(pred, g["eval_pred"], atol=2e-5)
+    assert z is mu
+
+
+def test_adam_amsgrad_trajectory():
+    g = load_golden("step_tiny")
+    spec = spec_of(g)
+    p = golden_weights(g)
+    st = tuple({k: np.zeros_like(v) for k, v in p.items()} for _ in range(3))
+    for s in range(g["adam/eps"].shape[0]):
+        cache = vo.FwdCache()
+        out = vo.model_forward(p, g["x"], g["adam/eps"][s], spec, True, cache)
+        L = vo.total_loss(*out, g["x"], g["xfut"], spec, 1.0)
+        assert abs(L["total"] - g["adam/loss"][s]) <= 1e-4 * abs(g["adam/loss"][s])
+        grads = vo.model_backward(p, cache, spec, g["x"], g["xfut"], 1.0)
+        vo.adam_amsgrad_step(p, grads, st, 5e-4, s + 1)
+    for k, v in golden_weights(g, "adam/w/").items():
+        np.testing.assert_allclose(p[k], v, atol=2e-5, err_msg=k)
+
+
+def test_embedding_matches_reference_loop():
+    g = load_golden("embed_tiny")
+    spec = spec_of(g)
+    lat = vo.embed_series(golden_weights(g), g["data"], spec, batch=64)
+    assert lat.shape == g["latent"].shape == (g["data"].shape[1] - spec.T, spec.Z) and lat.dtype == np.float32
+    np.testing.assert_allclose(lat, g["latent"], atol=1e-5)
+
+
+def test_window_batcher():
+    g = load_golden("batcher")
+    Xn = vo.normalise_series(g["X"], float(g["mean"]), float(g["std"]))
+    win = vo.window_gather(Xn, g["starts"], int(g["T2"]))          # (B,2T,F)
+    np.testing.assert_array_equal(np.transpose(win, (0, 2, 1)), g["batch"])   # bit-exact f64
+    np.random.seed(11)
+    assert (np.random.randint(0, g["X"].shape[1] - int(g["T2"]), size=len(g["starts"])) == g["starts"]).all()
+
+
+@pytest.mark.parametrize("B", [1, 2, 6])
+def test_decoder_h0_view_mixing(B):
+    g = load_golden("h0view")
+    T, F, Z, H = [int(v) for v in g["spec"]]
+    p = golden_weights(g)
+    pred = vo.decoder_forward(p, g[f"B{B}/z"], T, "decoder", "rnn_rec")
+    np.testing.assert_allclose(pred, g[f"B{B}/pred"], atol=1e-5)
+
+
+def test_kl_annealing_table():
+    with open(os.path.join(GOLDEN, "kl_annealing.json")) as f:
+        t = json.load(f)
+    for fn, vals in t["table"].items():
+        for e, v in zip(t["epochs"], vals):
+            assert vo.kl_annealing(e, t["kl_start"], t["annealtime"], fn) == pytest.approx(v, abs=1e-12)
+    with pytest.raises(NotImplementedError):
+        vo.kl_annealing(5, 2, 4, "cosine")
