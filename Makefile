@@ -1,0 +1,17 @@
+# Builds the product library (gfx950) and the CPU emulation library used by the non-GPU tests.
+HIPCC ?= /opt/rocm/bin/hipcc
+HOSTCXX ?= /opt/rocm/lib/llvm/bin/clang++
+SRC := vame_amd/csrc/gru_seq.hip vame_amd/csrc/gemm.hip vame_amd/csrc/elementwise.hip
+HDR := vame_amd/csrc/vame_device.h vame_amd/csrc/vame_common.h include/vame_hip.h
+
+all: vame_amd/libvame_hip.so tests/emu/libvame_emu.so
+
+vame_amd/libvame_hip.so: $(SRC) $(HDR)
+	$(HIPCC) --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -o $@ $(SRC)
+
+tests/emu/libvame_emu.so: $(SRC) $(HDR) tests/emu/hip_emu.h tests/emu/hip_emu.cpp
+	$(HOSTCXX) -DVAME_EMU -O2 -std=c++17 -fPIC -shared -pthread -Itests/emu -Wno-unknown-attributes \
+	    -o $@ $(foreach f,$(SRC),-x c++ $(f)) -x c++ tests/emu/hip_emu.cpp
+
+clean:
+	rm -f vame_amd/libvame_hip.so tests/emu/libvame_emu.so

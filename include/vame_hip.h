@@ -1,0 +1,125 @@
+/* libvame_hip.so -- C ABI of the MI355X (gfx950) kernels behind VAME's RNN-VAE train + embed path.
+ *
+ * VAME has no FFI of its own: the reference reaches its numerics through PyTorch modules.  Each
+ * entry point below therefore names the reference code (file:line under /root/reference) whose
+ * arithmetic it replaces; INTEGRATION.md shows the ctypes stub a VAME maintainer would add.
+ *
+ * Conventions: all pointers are DEVICE pointers owned by the caller (the library never allocates,
+ * frees, keeps or synchronises); all tensors fp32 row-major; sizes/strides in ELEMENTS; `stream`
+ * is a hipStream_t passed as void*.  Every function returns 0 on success or a negative VAME_E_*
+ * code; vame_last_error() returns a thread-local description.  Re-entrant across streams/threads.
+ */
+#ifndef VAME_HIP_H
+#define VAME_HIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VAME_OK 0
+#define VAME_E_BADARG (-1)
+#define VAME_E_SHAPE (-2)
+#define VAME_E_HIP (-3)
+#define VAME_E_UNSUPPORTED (-4)
+
+int vame_version(void);
+const char* vame_last_error(void);
+
+/* Sliding-window batcher: out[b,l,f] = X[f*N + start_b + l]  (B,L,F).
+ * Replaces SEQUENCE_DATASET.__getitem__ + default collate + permute(0,2,1)
+ * (vame/model/dataloader.py:45-56, vame/model/rnn_vae.py:108-115) and the per-window slicing of
+ * embedd_latent_vectors (vame/analysis/pose_segmentation.py:89-90).
+ * starts == NULL means start_b = start0 + b (the stride-1 embedding sweep). */
+int vame_window_gather_f32(const float* X, int64_t N, int F, const int64_t* starts, int64_t start0,
+                           int B, int L, float* out, void* stream);
+
+/* Generic fp32 MFMA GEMM  C[M,N] (+)= opA(A) opB(B) (+ bias[N]).
+ *   a_kmajor = 0: A is (M,K) row-major, lda = row stride;  1: A is (K,M) row-major (A^T stored).
+ *   b_kmajor = 0: B is (N,K) row-major (a torch Linear weight); 1: B is (K,N) row-major.
+ *   Row i of an operand lives at (seg ? (i/seg)*seg_stride + (i%seg)*ld : i*ld): two-level
+ *   addressing for (batch,time) rows of padded sequences and (ld = 0) time-constant GRU inputs.
+ *   accumulate != 0: C += result.  splitk > 1 needs ws of splitk*M*N floats (reduced internally).
+ * Replaces the nn.Linear / nn.GRU input-projection and all weight-gradient contractions that
+ * torch autograd performs for vame/model/rnn_model.py:34-35,56-57,91-97,125-131. */
+int vame_gemm_f32(int M, int N, int K, const float* A, int64_t lda, int a_kmajor, int64_t a_seg,
+                  int64_t a_seg_stride, const float* B, int64_t ldb, int b_kmajor, int64_t b_seg,
+                  int64_t b_seg_stride, const float* bias, float* C, int64_t ldc, int accumulate,
+                  int splitk, float* ws, void* stream);
+
+/* Pack one GRU layer-direction's recurrent weights for the sequence kernels.
+ *   W_hh (3H,H), b_ih/b_hh (3H) -> wp_fwd (3H*H, MFMA B-fragment order for h W_hh^T),
+ *   wp_bwd (3H*H, fragment order for dgh W_hh), bias_gi (3H) = b_ih + [b_hr, b_hz, 0], b_hn (H). */
+int vame_gru_pack_f32(const float* W_hh, const float* b_ih, const float* b_hh, int H,
+                      float* wp_fwd, float* wp_bwd, float* bias_gi, float* b_hn, void* stream);
+
+/* GRU sequence forward for up to 8 independent (layer,direction) streams in one launch.
+ * desc = nstreams x VAME_GRU_FWD_FIELDS int64 (see vame_gru_fwd_field).  Cell = torch.nn.GRU
+ * (gate order r,z,n) as instantiated at vame/model/rnn_model.py:34-35 (encoder), :91-92 (decoder),
+ * :125-126 (future decoder); the input projection gi = x W_ih^T + bias_gi is supplied by the caller.
+ * Returns bytes of stash needed per stream via vame_gru_stash_floats(). */
+enum vame_gru_fwd_field {
+    GF_GI = 0, GF_GI_ROW, GF_GI_T,          /* gi (B,T,3H): ptr, row stride, time stride (0 = constant in time) */
+    GF_WP, GF_BHN,                          /* packed W_hh (vame_gru_pack_f32), b_hn (H) */
+    GF_H0, GF_H0_ROW,                       /* initial state rows (0 = zeros) */
+    GF_Y, GF_Y_ROW, GF_Y_T,                 /* output sequence h_t (0 = not written) */
+    GF_HN, GF_HN_ROW,                       /* final state (0 = not written) */
+    GF_STASH,                               /* r,u,n,gh_n stash for backward (0 = inference) */
+    GF_T, GF_REVERSE, GF_PAD,
+    VAME_GRU_FWD_FIELDS
+};
+int64_t vame_gru_stash_floats(int B, int T, int H);
+int vame_gru_seq_fwd_f32(const int64_t* desc, int nstreams, int B, int H, void* stream);
+
+/* GRU sequence backward (BPTT) for the same streams.  Writes dG (B,T,4H) = [da_r|da_z|dgi_n|dgh_n]
+ * for the weight-gradient GEMMs, per-tile bias-gradient partials, optional dh0 and sum_t dG. */
+enum vame_gru_bwd_field {
+    GB_STASH = 0, GB_Y, GB_Y_ROW, GB_Y_T,   /* forward stash and h sequence */
+    GB_H0, GB_H0_ROW,
+    GB_WPT,                                 /* packed W_hh (bwd order) */
+    GB_DY, GB_DY_ROW, GB_DY_T,              /* grad wrt output sequence (0 = none) */
+    GB_DHN, GB_DHN_ROW,                     /* grad wrt final state (0 = none) */
+    GB_DG,                                  /* out (B,T,4H) contiguous */
+    GB_DH0, GB_DH0_ROW,                     /* out grad wrt initial state (0 = none) */
+    GB_DBIAS,                               /* out (ntiles,4H) per-tile column sums of dG over rows and time */
+    GB_DGSUM,                               /* out (B,3H) sum over time of [da_r|da_z|dgi_n] (0 = none) */
+    GB_T, GB_REVERSE, GB_PAD,
+    VAME_GRU_BWD_FIELDS
+};
+int vame_gru_seq_bwd_f32(const int64_t* desc, int nstreams, int B, int H, void* stream);
+
+/* Lambda reparameterisation + KL partials (vame/model/rnn_model.py:63-76, vame/model/rnn_vae.py:53-60).
+ *   mu, lv_raw (B,Z) -> logvar (softplus optional), z = eps*exp(0.5*logvar)+mu (training) or mu;
+ *   kl_out[0] += sum(1 + logvar - mu^2 - exp(logvar))   (caller zeroes kl_out). */
+int vame_latent_fwd_f32(const float* mu, const float* lv_raw, const float* eps, int B, int Z, int softplus,
+                        int training, float* logvar, float* z, float* kl_out, void* stream);
+/* Backward of the above plus the KL term: dmu = dz + ckl*mu ; dlv = dz*eps*0.5*std + 0.5*ckl*(exp(lv)-1)
+ * (times sigmoid(lv_raw) under softplus), ckl = beta*kl_weight/(B*Z). */
+int vame_latent_bwd_f32(const float* dz, const float* mu, const float* logvar, const float* lv_raw,
+                        const float* eps, int B, int Z, int softplus, float ckl, float* dmu, float* dlv, void* stream);
+
+/* MSE (vame/model/rnn_vae.py:35-43): loss_out[0] += sum((pred-target)^2) ; dpred = gscale*(pred-target).
+ * target rows are (T,F) windows inside a (B, tgt_row) buffer starting at column offset 0. */
+int vame_mse_fwd_bwd_f32(const float* pred, const float* target, int64_t tgt_row, int B, int TF,
+                         float gscale, float* dpred, float* loss_out, void* stream);
+
+/* cluster_loss (vame/model/rnn_vae.py:45-50) from the (Z,Z) Gram G = z^T z (un-normalised, from vame_gemm_f32):
+ *   loss_out[0] = lmbda * sum_{i<k} sqrt(eig_i(G/bsize)),  Minv (Z,Z) = (lmbda/bsize) V_k S_k^-1 V_k^T
+ * so that d loss/dz = z Minv.  One workgroup, cyclic Jacobi in fp64. */
+int vame_nuclear_f32(const float* G, int Z, int kloss, int nrows, float lmbda, float bsize,
+                     float* loss_out, float* Minv, void* stream);
+
+/* out[c] (+)= sum_r in[r*ld + c] */
+int vame_colsum_f32(const float* in, int64_t R, int C, int64_t ld, float* out, int accumulate, void* stream);
+
+/* Fused Adam with AMSGrad over a flat parameter buffer (torch.optim.Adam(amsgrad=True), rnn_vae.py:332,143).
+ * gscale multiplies the gradient first (1/world_size after an all-reduce SUM). */
+int vame_adam_amsgrad_f32(float* p, const float* g, float* m, float* v, float* vmax, int64_t n, float lr,
+                          float beta1, float beta2, float eps, int step, float gscale, void* stream);
+
+/* y = a*x + y style helpers for the host orchestration */
+int vame_axpy_f32(const float* x, float a, float* y, int64_t n, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

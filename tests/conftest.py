@@ -26,3 +26,32 @@ def golden_weights(g, prefix="w/"):
 @pytest.fixture(scope="session")
 def golden():
     return load_golden
+
+
+def _reset_lib():
+    from vame_amd import _lib
+    _lib._lib = None
+    _lib._emulated = False
+
+
+@pytest.fixture(scope="module")
+def emu():
+    """Bind vame_amd to the host-emulated build of the kernel sources (tests/emu) for this module."""
+    import subprocess
+    from vame_amd import _lib
+    so = os.path.join(ROOT, "tests", "emu", "libvame_emu.so")
+    subprocess.run(["make", "-s", "tests/emu/libvame_emu.so"], cwd=ROOT, check=True)
+    _lib._load_for_tests(so)
+    yield _lib
+    _reset_lib()
+
+
+@pytest.fixture(scope="module")
+def hip():
+    """The real gfx950 library on a GPU box."""
+    import torch
+    from vame_amd import _lib
+    _reset_lib()
+    assert torch.cuda.is_available(), "gpu tests need a GPU"
+    _lib.lib()
+    yield _lib

@@ -1,0 +1,231 @@
+"""Shared kernel test bodies: run on `cpu` tensors through the emulator or on `cuda` through libvame_hip.so."""
+import numpy as np
+import torch
+
+from oracle import vame_oracle as vo
+from vame_amd import ops
+from vame_amd.ops import GB, GF, Operand
+
+
+def T_(a, dev):
+    return torch.from_numpy(np.array(a, copy=True, order="C")).to(dev)
+
+
+def N_(t):
+    return t.detach().cpu().numpy()
+
+
+def check_gemm_cases(dev, small=True):
+    rng = np.random.default_rng(0)
+    cases = [  # M, N, K, akm, bkm, splitk, bias, acc
+        (70, 40, 50, 0, 0, 1, True, False), (30, 24, 30, 0, 0, 1, True, True), (45, 130, 37, 0, 1, 1, False, False),
+        (33, 30, 200, 1, 1, 3, False, True), (96, 136, 64, 1, 1, 1, True, False), (130, 24, 19, 0, 0, 2, True, False),
+    ]
+    if not small:
+        cases += [(512, 768, 512, 0, 0, 1, True, False), (768, 256, 4096, 1, 1, 8, False, False), (1000, 512, 768, 0, 1, 1, False, True)]
+    for (M, Nn, K, akm, bkm, sk, hb, acc) in cases:
+        A = rng.standard_normal((K, M) if akm else (M, K)).astype(np.float32)
+        Bm = rng.standard_normal((K, Nn) if bkm else (Nn, K)).astype(np.float32)
+        bias = rng.standard_normal(Nn).astype(np.float32) if hb else None
+        C0 = rng.standard_normal((M, Nn + 3)).astype(np.float32)
+        At, Bt, Ct = T_(A, dev), T_(Bm, dev), T_(C0, dev)
+        ws = torch.zeros(sk * M * Nn, device=dev) if sk > 1 else None
+        ops.gemm(M, Nn, K, Operand(At, A.shape[1]), akm, Operand(Bt, Bm.shape[1]), bkm, Ct, Nn + 3, bias=T_(bias, dev) if hb else None,
+                 accumulate=acc, splitk=sk, ws=ws)
+        ref = (A.T if akm else A).astype(np.float64) @ (Bm if bkm else Bm.T).astype(np.float64)
+        if hb:
+            ref += bias
+        if acc:
+            ref += C0[:, :Nn]
+        out = N_(Ct)
+        np.testing.assert_allclose(out[:, :Nn], ref, atol=2e-4 * max(1, np.sqrt(K)), err_msg=str((M, Nn, K, akm, bkm, sk)))
+        np.testing.assert_array_equal(out[:, Nn:], C0[:, Nn:])
+    # two-level row addressing: rows (b,t) of a padded (B,T+2,W) sequence, and a time-constant operand
+    Bq, Tq, W, Nn = 6, 5, 20, 12
+    Y = rng.standard_normal((Bq, Tq + 2, W)).astype(np.float32)
+    Wt = rng.standard_normal((Nn, W)).astype(np.float32)
+    C = torch.zeros(Bq * Tq, Nn, device=dev)
+    Yt = T_(Y, dev)
+    ops.gemm(Bq * Tq, Nn, W, Operand(Yt, W, off=W, seg=Tq, seg_stride=(Tq + 2) * W), 0, Operand(T_(Wt, dev), W), 0, C, Nn)
+    np.testing.assert_allclose(N_(C), (Y[:, 1:Tq + 1].reshape(-1, W) @ Wt.T), atol=1e-4)
+    dG = rng.standard_normal((Bq * Tq, 16)).astype(np.float32)
+    z = rng.standard_normal((Bq, 10)).astype(np.float32)
+    C = torch.zeros(16, 10, device=dev)
+    ops.gemm(16, 10, Bq * Tq, Operand(T_(dG, dev), 16), 1, Operand(T_(z, dev), 0, seg=Tq, seg_stride=10), 1, C, 10)
+    np.testing.assert_allclose(N_(C), dG.T @ np.repeat(z, Tq, 0), atol=1e-4)
+
+
+def _gru_weights(rng, I, H):
+    k = 1 / np.sqrt(H)
+    return (rng.uniform(-k, k, (3 * H, I)).astype(np.float32), rng.uniform(-k, k, (3 * H, H)).astype(np.float32),
+            rng.uniform(-k, k, 3 * H).astype(np.float32), rng.uniform(-k, k, 3 * H).astype(np.float32))
+
+
+def _pack(dev, W_hh, b_ih, b_hh, H):
+    wpf = torch.zeros(3 * H * H, device=dev)
+    wpb = torch.zeros(3 * H * H, device=dev)
+    bgi = torch.zeros(3 * H, device=dev)
+    bhn = torch.zeros(H, device=dev)
+    ops.gru_pack(T_(W_hh, dev), T_(b_ih, dev), T_(b_hh, dev), H, wpf, wpb, bgi, bhn)
+    return wpf, wpb, bgi, bhn
+
+
+def run_gru_fwd(dev, H, B, T, seed=0):
+    """Two streams (forward + reverse dir, with h0) in one launch; returns everything needed for bwd."""
+    rng = np.random.default_rng(seed)
+    I = 7
+    x = rng.standard_normal((B, T, I)).astype(np.float32)
+    st = []
+    Y = torch.zeros(B, T + 2, 2 * H, device=dev)
+    hN = torch.zeros(B, 2 * H, device=dev)
+    rows = []
+    for d in range(2):
+        W_ih, W_hh, b_ih, b_hh = _gru_weights(rng, I, H)
+        h0 = rng.standard_normal((B, H)).astype(np.float32) * 0.5 if d == 1 else None
+        wpf, wpb, bgi, bhn = _pack(dev, W_hh, b_ih, b_hh, H)
+        gi = T_((x.reshape(B * T, I) @ W_ih.T + N_(bgi)).reshape(B, T, 3 * H), dev)
+        stash = torch.zeros(ops.gru_stash_floats(B, T, H), device=dev)
+        h0t = T_(h0, dev) if h0 is not None else None
+        rows.append({GF["GI"]: ops.addr(gi), GF["GI_ROW"]: T * 3 * H, GF["GI_T"]: 3 * H, GF["WP"]: ops.addr(wpf),
+                     GF["BHN"]: ops.addr(bhn), GF["H0"]: ops.addr(h0t), GF["H0_ROW"]: H,
+                     GF["Y"]: ops.addr(Y, 2 * H + d * H), GF["Y_ROW"]: (T + 2) * 2 * H, GF["Y_T"]: 2 * H,
+                     GF["HN"]: ops.addr(hN, d * H), GF["HN_ROW"]: 2 * H, GF["STASH"]: ops.addr(stash), GF["T"]: T,
+                     GF["REVERSE"]: d, GF["PAD"]: 1})
+        st.append(dict(W_ih=W_ih, W_hh=W_hh, b_ih=b_ih, b_hh=b_hh, h0=h0, wpb=wpb, stash=stash, keep=(gi, wpf, bhn, h0t)))
+    ops.gru_seq_fwd(rows, B, H)
+    return x, st, Y, hN
+
+
+def check_gru_fwd(dev, H, B, T):
+    x, st, Y, hN = run_gru_fwd(dev, H, B, T)
+    Yn, hNn = N_(Y), N_(hN)
+    for d, s in enumerate(st):
+        out, hn, _ = vo.gru_dir_forward(x, s["h0"], s["W_ih"], s["W_hh"], s["b_ih"], s["b_hh"], reverse=bool(d))
+        np.testing.assert_allclose(Yn[:, 1:T + 1, d * H:(d + 1) * H], out, atol=2e-5)
+        np.testing.assert_allclose(hNn[:, d * H:(d + 1) * H], hn, atol=2e-5)
+        pad = Yn[:, T + 1 if d else 0, d * H:(d + 1) * H]
+        np.testing.assert_allclose(pad, s["h0"] if s["h0"] is not None else 0 * pad, atol=0)
+
+
+def check_gru_bwd(dev, H, B, T):
+    x, st, Y, hN = run_gru_fwd(dev, H, B, T, seed=1)
+    rng = np.random.default_rng(5)
+    dY = rng.standard_normal((B, T, 2 * H)).astype(np.float32)
+    dhN = rng.standard_normal((B, 2 * H)).astype(np.float32)
+    dYt, dhNt = T_(dY, dev), T_(dhN, dev)
+    ntiles = (B + 31) // 32
+    rows, outs = [], []
+    for d, s in enumerate(st):
+        dG = torch.zeros(B, T, 4 * H, device=dev)
+        dh0 = torch.zeros(B, H, device=dev)
+        dbias = torch.zeros(ntiles, 4 * H, device=dev)
+        dgsum = torch.zeros(B, 3 * H, device=dev)
+        rows.append({GB["STASH"]: ops.addr(s["stash"]), GB["Y"]: ops.addr(Y, 2 * H + d * H), GB["Y_ROW"]: (T + 2) * 2 * H,
+                     GB["Y_T"]: 2 * H, GB["WPT"]: ops.addr(s["wpb"]), GB["DY"]: ops.addr(dYt, d * H), GB["DY_ROW"]: T * 2 * H,
+                     GB["DY_T"]: 2 * H, GB["DHN"]: ops.addr(dhNt, d * H), GB["DHN_ROW"]: 2 * H, GB["DG"]: ops.addr(dG),
+                     GB["DH0"]: ops.addr(dh0), GB["DH0_ROW"]: H, GB["DBIAS"]: ops.addr(dbias), GB["DGSUM"]: ops.addr(dgsum),
+                     GB["T"]: T, GB["REVERSE"]: d, GB["PAD"]: 1})
+        outs.append((dG, dh0, dbias, dgsum))
+    ops.gru_seq_bwd(rows, B, H)
+    for d, s in enumerate(st):
+        _, _, cache = vo.gru_dir_forward(x, s["h0"], s["W_ih"], s["W_hh"], s["b_ih"], s["b_hh"], reverse=bool(d))
+        dx, dh0, dWi, dWh, dbi, dbh = vo.gru_dir_backward(x, cache, np.ascontiguousarray(dY[:, :, d * H:(d + 1) * H]),
+                                                          dhN[:, d * H:(d + 1) * H], s["W_ih"], s["W_hh"])
+        dG, dh0k, dbias, dgsum = [N_(o) for o in outs[d]]
+        tol = 5e-5 * max(1.0, np.abs(dWh).max())
+        np.testing.assert_allclose(dh0k, dh0, atol=5e-5)
+        dgi = dG[:, :, :3 * H].reshape(B * T, 3 * H)
+        np.testing.assert_allclose(dgi.T @ x.reshape(B * T, -1), dWi, atol=tol)
+        np.testing.assert_allclose(dgi @ s["W_ih"], dx.reshape(B * T, -1), atol=5e-5)
+        dbs = dbias.sum(0)
+        np.testing.assert_allclose(dbs[:3 * H], dbi, atol=tol)
+        np.testing.assert_allclose(np.concatenate([dbs[:2 * H], dbs[3 * H:]]), dbh, atol=tol)
+        np.testing.assert_allclose(dgsum, dG[:, :, :3 * H].sum(1), atol=1e-5)
+        # dW_hh from dG and the padded h sequence (h_prev = previous slot in step order)
+        Yn = N_(Y)[:, :, d * H:(d + 1) * H]
+        hprev = Yn[:, 2:T + 2] if d else Yn[:, 0:T]
+        dgh = np.concatenate([dG[:, :, :2 * H], dG[:, :, 3 * H:]], 2).reshape(B * T, 3 * H)
+        np.testing.assert_allclose(dgh.T @ hprev.reshape(B * T, H), dWh, atol=tol)
+
+
+def check_gather(dev):
+    rng = np.random.default_rng(2)
+    F, Nn, L, B = 24, 300, 45, 9
+    X = rng.standard_normal((F, Nn)).astype(np.float32)
+    starts = rng.integers(0, Nn - L, B)
+    out = torch.zeros(B, L, F, device=dev)
+    ops.window_gather(T_(X, dev), Nn, F, T_(starts.astype(np.int64), dev), 0, B, L, out)
+    np.testing.assert_array_equal(N_(out), vo.window_gather(X, starts, L))
+    out2 = torch.zeros(7, 30, F, device=dev)
+    ops.window_gather(T_(X, dev), Nn, F, None, 100, 7, 30, out2)
+    np.testing.assert_array_equal(N_(out2), vo.window_gather(X, np.arange(100, 107), 30))
+
+
+def check_latent(dev):
+    rng = np.random.default_rng(3)
+    B, Z = 37, 30
+    mu, lvr, eps, dz = [rng.standard_normal((B, Z)).astype(np.float32) for _ in range(4)]
+    for sp in (0, 1):
+        for training in (1, 0):
+            lv, z, kl = torch.zeros(B, Z, device=dev), torch.zeros(B, Z, device=dev), torch.zeros(1, device=dev)
+            ops.latent_fwd(T_(mu, dev), T_(lvr, dev), T_(eps, dev), B, Z, sp, training, lv, z, kl)
+            lv_ref = vo.softplus(lvr) if sp else lvr
+            np.testing.assert_allclose(N_(lv), lv_ref, atol=1e-6)
+            z_ref = eps * np.exp(0.5 * lv_ref) + mu if training else mu
+            np.testing.assert_allclose(N_(z), z_ref, atol=1e-5)
+            np.testing.assert_allclose(-0.5 * N_(kl)[0] / (B * Z), vo.kl_loss(mu, lv_ref), rtol=1e-5)
+        dmu, dlv = torch.zeros(B, Z, device=dev), torch.zeros(B, Z, device=dev)
+        ckl = 0.7 / (B * Z)
+        ops.latent_bwd(T_(dz, dev), T_(mu, dev), T_(lv_ref, dev), T_(lvr, dev), T_(eps, dev), B, Z, sp, ckl, dmu, dlv)
+        np.testing.assert_allclose(N_(dmu), dz + ckl * mu, atol=1e-6)
+        ref = dz * eps * 0.5 * np.exp(0.5 * lv_ref) + 0.5 * ckl * (np.exp(lv_ref) - 1)
+        if sp:
+            ref = ref * vo.sigmoid(lvr)
+        np.testing.assert_allclose(N_(dlv), ref, atol=1e-5)
+
+
+def check_mse(dev):
+    rng = np.random.default_rng(4)
+    B, TF, row = 11, 30 * 24, 45 * 24
+    pred = rng.standard_normal((B, TF)).astype(np.float32)
+    win = rng.standard_normal((B, row)).astype(np.float32)
+    dp, loss = torch.zeros(B, TF, device=dev), torch.zeros(2, device=dev)
+    ops.mse_fwd_bwd(T_(pred, dev), T_(win, dev), 24, row, B, TF, 2.0, dp, loss, 1)
+    tgt = win[:, 24:24 + TF]
+    np.testing.assert_allclose(N_(loss)[1], ((pred - tgt) ** 2).sum(), rtol=1e-5)
+    np.testing.assert_allclose(N_(dp), 2 * (pred - tgt), atol=1e-6)
+
+
+def check_colsum(dev):
+    rng = np.random.default_rng(6)
+    a = rng.standard_normal((13, 300)).astype(np.float32)
+    out = torch.ones(260, device=dev)
+    ops.colsum(T_(a, dev), 5, 13, 260, 300, out, 0, accumulate=True)
+    np.testing.assert_allclose(N_(out), 1 + a[:, 5:265].sum(0), atol=1e-5)
+
+
+def check_adam(dev):
+    rng = np.random.default_rng(7)
+    n = 1000
+    p0 = rng.standard_normal(n).astype(np.float32)
+    pt = torch.nn.Parameter(torch.from_numpy(p0.copy()))
+    opt = torch.optim.Adam([pt], lr=5e-4, amsgrad=True)
+    p, m, v, vm = T_(p0, dev), torch.zeros(n, device=dev), torch.zeros(n, device=dev), torch.zeros(n, device=dev)
+    for step in range(1, 4):
+        g = rng.standard_normal(n).astype(np.float32) * (10.0 ** (step - 2))
+        pt.grad = torch.from_numpy(g.copy())
+        opt.step()
+        ops.adam_amsgrad(p, T_(2 * g, dev), m, v, vm, n, 5e-4, step, gscale=0.5)
+        np.testing.assert_allclose(N_(p), pt.detach().numpy(), atol=1e-6)
+
+
+def check_nuclear(dev, B, Z, k):
+    rng = np.random.default_rng(8)
+    z = (rng.standard_normal((B, Z)) * rng.uniform(0.2, 2.0, Z)).astype(np.float32)
+    G = (z.astype(np.float64).T @ z.astype(np.float64)).astype(np.float32)
+    loss, Minv = torch.zeros(1, device=dev), torch.zeros(Z, Z, device=dev)
+    ops.nuclear(T_(G, dev), Z, k, B, 0.1, B, loss, 0, Minv)
+    ref_loss, ref_dz = vo.cluster_loss_gram(z, k, 0.1, B)
+    assert abs(N_(loss)[0] - ref_loss) <= 1e-5 * max(1, abs(ref_loss))
+    assert abs(N_(loss)[0] - vo.cluster_loss_svd(z, k, 0.1, B)) <= 1e-4 * max(1, abs(ref_loss))
+    np.testing.assert_allclose(z @ N_(Minv), ref_dz, atol=2e-5 * max(1, np.abs(ref_dz).max()))

@@ -1,0 +1,42 @@
+"""Kernel-level checks of the HIP sources executed through the host emulator (tests/emu) vs the numpy oracle.
+
+These exercise the exact kernel code (index math, MFMA fragment layouts, LDS staging, masking) on
+the CPU; the same checks run on the real GPU in test_kernels_gpu.py.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import vame_oracle as vo
+from vame_amd import ops
+from kernel_cases import (check_adam, check_colsum, check_gather, check_gemm_cases, check_gru_bwd, check_gru_fwd,
+                          check_latent, check_mse, check_nuclear)
+
+DEV = "cpu"
+
+
+def test_gemm(emu):
+    check_gemm_cases(DEV, small=True)
+
+
+@pytest.mark.parametrize("H,B,T", [(32, 5, 4), (64, 40, 3)])
+def test_gru_fwd(emu, H, B, T):
+    check_gru_fwd(DEV, H, B, T)
+
+
+@pytest.mark.parametrize("H,B,T", [(32, 5, 4), (64, 40, 3)])
+def test_gru_bwd(emu, H, B, T):
+    check_gru_bwd(DEV, H, B, T)
+
+
+def test_elementwise(emu):
+    check_gather(DEV)
+    check_latent(DEV)
+    check_mse(DEV)
+    check_colsum(DEV)
+    check_adam(DEV)
+
+
+@pytest.mark.parametrize("B,Z,k", [(64, 30, 30), (8, 30, 30), (50, 7, 4)])
+def test_nuclear(emu, B, Z, k):
+    check_nuclear(DEV, B, Z, k)

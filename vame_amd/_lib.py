@@ -1,0 +1,81 @@
+"""ctypes binding of libvame_hip.so (the gfx950 kernels) -- fails loudly when the library is missing.
+
+There is no CPU fallback: every op in :mod:`vame_amd.ops` goes through this C ABI
+(``include/vame_hip.h``).  ``_load_for_tests`` exists so the CPU test-suite can point the very
+same bindings at the host emulation build of the kernel sources (tests/emu); nothing in the
+package calls it.
+"""
+import ctypes
+import os
+from ctypes import c_char_p, c_float, c_int, c_int64, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libvame_hip.so")
+_lib = None
+_emulated = False
+
+
+class VameHipError(RuntimeError):
+    pass
+
+
+_SIGS = {
+    "vame_version": (c_int, []),
+    "vame_last_error": (c_char_p, []),
+    "vame_window_gather_f32": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p]),
+    "vame_gemm_f32": (c_int, [c_int, c_int, c_int, c_void_p, c_int64, c_int, c_int64, c_int64, c_void_p, c_int64, c_int,
+                              c_int64, c_int64, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p]),
+    "vame_gru_pack_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "vame_gru_stash_floats": (c_int64, [c_int, c_int, c_int]),
+    "vame_gru_seq_fwd_f32": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p]),
+    "vame_gru_seq_bwd_f32": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p]),
+    "vame_latent_fwd_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,
+                                    c_void_p]),
+    "vame_latent_bwd_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_void_p,
+                                    c_void_p, c_void_p]),
+    "vame_mse_fwd_bwd_f32": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p]),
+    "vame_nuclear_f32": (c_int, [c_void_p, c_int, c_int, c_int, c_float, c_float, c_void_p, c_void_p, c_void_p]),
+    "vame_colsum_f32": (c_int, [c_void_p, c_int64, c_int, c_int64, c_void_p, c_int, c_void_p]),
+    "vame_adam_amsgrad_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, c_float,
+                                      c_float, c_int, c_float, c_void_p]),
+    "vame_axpy_f32": (c_int, [c_void_p, c_float, c_void_p, c_int64, c_void_p]),
+}
+EXPORTS = tuple(_SIGS)
+
+
+def _bind(path):
+    lib = ctypes.CDLL(path)
+    for name, (res, args) in _SIGS.items():
+        fn = getattr(lib, name)          # AttributeError here = the .so does not export the declared ABI
+        fn.restype = res
+        fn.argtypes = args
+    return lib
+
+
+def lib():
+    """The loaded library; raises if the HIP extension has not been built (no silent fallback)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise VameHipError(
+                f"{LIB_PATH} not found: the gfx950 HIP extension is not built. Run `python __graft_entry__.py` "
+                "(or `make`) first; vame_amd has no CPU fallback.")
+        _lib = _bind(LIB_PATH)
+    return _lib
+
+
+def _load_for_tests(path):
+    """Test-suite hook: bind the host-emulated build of the kernel sources (CPU tensors)."""
+    global _lib, _emulated
+    _lib = _bind(path)
+    _emulated = True
+
+
+def emulated():
+    return _emulated
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = lib().vame_last_error()
+        raise VameHipError(f"{what} failed (code {rc}): {msg.decode() if msg else ''}")

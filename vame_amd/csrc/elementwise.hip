@@ -1,0 +1,321 @@
+// Bandwidth-bound kernels of the path: sliding-window gather, reparameterisation + KL, MSE
+// fwd/bwd, column sums, fused Adam-AMSGrad, and the (Z,Z) nuclear-norm ("kmeans") loss.
+#include "vame_common.h"
+#include <math.h>
+
+static thread_local char g_err[512] = "";
+void vame_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+}
+extern "C" const char* vame_last_error(void) { return g_err; }
+extern "C" int vame_version(void) { return 100; }
+
+static inline int ew_blocks(int64_t n, int per_block = 256) {
+    int64_t b = cdiv64(n, per_block);
+    return (int)(b < 1 ? 1 : (b > 2048 ? 2048 : b));   // <= 256 CUs x 8 blocks, grid-stride the rest
+}
+
+__device__ __forceinline__ float block_sum_256(float v) {
+    __shared__ float part[4];
+    v = wave_sum(v);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) part[w] = v;
+    __syncthreads();
+    return part[0] + part[1] + part[2] + part[3];
+}
+
+// --------------------------------------------------------------------------------- window gather
+// out[b,l,f] = X[f*N + start_b + l].  One block per window: reads are contiguous along l for each
+// feature row (coalesced 4*L bytes), transposed through LDS, written as one contiguous L*F run.
+__global__ __launch_bounds__(256) void window_gather_kernel(const float* __restrict__ X, int64_t N, int F,
+                                                            const int64_t* __restrict__ starts, int64_t start0, int B,
+                                                            int L, float* __restrict__ out) {
+    VAME_DYN_SMEM(smem_raw);
+    float* tile = reinterpret_cast<float*>(smem_raw);   // [F][L+1]
+    const int LP = L + 1;
+    for (int b = blockIdx.x; b < B; b += gridDim.x) {
+        const int64_t s = starts ? starts[b] : start0 + b;
+        for (int i = threadIdx.x; i < F * L; i += blockDim.x) {
+            const int f = i / L, l = i % L;
+            tile[f * LP + l] = X[(int64_t)f * N + s + l];
+        }
+        __syncthreads();
+        float* o = out + (int64_t)b * L * F;
+        for (int i = threadIdx.x; i < F * L; i += blockDim.x) {
+            const int l = i / F, f = i % F;
+            o[i] = tile[f * LP + l];
+        }
+        __syncthreads();
+    }
+}
+
+extern "C" int vame_window_gather_f32(const float* X, int64_t N, int F, const int64_t* starts, int64_t start0, int B,
+                                      int L, float* out, void* stream) {
+    VAME_CHECK_ARG(X && out, VAME_E_BADARG, "window_gather: null pointer");
+    VAME_CHECK_ARG(B >= 0 && F >= 1 && L >= 1 && N >= L, VAME_E_SHAPE, "window_gather: bad shape B=%d F=%d L=%d N=%lld", B, F,
+                   L, (long long)N);
+    if (B == 0) return VAME_OK;
+    const size_t sh = (size_t)F * (L + 1) * sizeof(float);
+    VAME_CHECK_ARG(sh <= 64 * 1024, VAME_E_SHAPE, "window_gather: F*L too large for the LDS transpose");
+    hipLaunchKernelGGL(window_gather_kernel, dim3(B < 4096 ? B : 4096), dim3(256), sh, (hipStream_t)stream, X, N, F, starts,
+                       start0, B, L, out);
+    VAME_LAUNCH_CHECK("window_gather");
+    return VAME_OK;
+}
+
+// --------------------------------------------------------------------------------- latent fwd/bwd
+__device__ __forceinline__ float softplus_f(float x) { return x > 20.f ? x : log1pf(expf(x)); }
+
+__global__ __launch_bounds__(256) void latent_fwd_kernel(const float* __restrict__ mu, const float* __restrict__ lv_raw,
+                                                         const float* __restrict__ eps, int64_t n, int softplus,
+                                                         int training, float* __restrict__ logvar, float* __restrict__ z,
+                                                         float* __restrict__ kl_out) {
+    float part = 0.f;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float m = mu[i];
+        const float lv = softplus ? softplus_f(lv_raw[i]) : lv_raw[i];
+        const float ev = expf(lv);
+        logvar[i] = lv;
+        z[i] = training ? eps[i] * expf(0.5f * lv) + m : m;
+        part += 1.0f + lv - m * m - ev;
+    }
+    if (kl_out) {
+        part = block_sum_256(part);
+        if (threadIdx.x == 0) atomicAdd(kl_out, part);
+    }
+}
+
+extern "C" int vame_latent_fwd_f32(const float* mu, const float* lv_raw, const float* eps, int B, int Z, int softplus,
+                                   int training, float* logvar, float* z, float* kl_out, void* stream) {
+    VAME_CHECK_ARG(mu && lv_raw && logvar && z, VAME_E_BADARG, "latent_fwd: null pointer");
+    VAME_CHECK_ARG(!training || eps, VAME_E_BADARG, "latent_fwd: training mode needs eps");
+    VAME_CHECK_ARG(B >= 1 && Z >= 1, VAME_E_SHAPE, "latent_fwd: bad shape");
+    const int64_t n = (int64_t)B * Z;
+    hipLaunchKernelGGL(latent_fwd_kernel, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, mu, lv_raw, eps, n,
+                       softplus, training, logvar, z, kl_out);
+    VAME_LAUNCH_CHECK("latent_fwd");
+    return VAME_OK;
+}
+
+__global__ __launch_bounds__(256) void latent_bwd_kernel(const float* __restrict__ dz, const float* __restrict__ mu,
+                                                         const float* __restrict__ logvar, const float* __restrict__ lv_raw,
+                                                         const float* __restrict__ eps, int64_t n, int softplus, float ckl,
+                                                         float* __restrict__ dmu, float* __restrict__ dlv) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float d = dz[i], lv = logvar[i];
+        dmu[i] = d + ckl * mu[i];
+        float g = d * eps[i] * 0.5f * expf(0.5f * lv) + 0.5f * ckl * (expf(lv) - 1.0f);
+        if (softplus) g *= 1.0f / (1.0f + expf(-lv_raw[i]));
+        dlv[i] = g;
+    }
+}
+
+extern "C" int vame_latent_bwd_f32(const float* dz, const float* mu, const float* logvar, const float* lv_raw,
+                                   const float* eps, int B, int Z, int softplus, float ckl, float* dmu, float* dlv,
+                                   void* stream) {
+    VAME_CHECK_ARG(dz && mu && logvar && lv_raw && eps && dmu && dlv, VAME_E_BADARG, "latent_bwd: null pointer");
+    const int64_t n = (int64_t)B * Z;
+    hipLaunchKernelGGL(latent_bwd_kernel, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, dz, mu, logvar, lv_raw, eps,
+                       n, softplus, ckl, dmu, dlv);
+    VAME_LAUNCH_CHECK("latent_bwd");
+    return VAME_OK;
+}
+
+// --------------------------------------------------------------------------------- MSE fwd + bwd
+__global__ __launch_bounds__(256) void mse_kernel(const float* __restrict__ pred, const float* __restrict__ target,
+                                                  int64_t tgt_row, int B, int TF, float gscale, float* __restrict__ dpred,
+                                                  float* __restrict__ loss_out) {
+    const int64_t n = (int64_t)B * TF;
+    float part = 0.f;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t b = i / TF, j = i % TF;
+        const float d = pred[i] - target[b * tgt_row + j];
+        part += d * d;
+        if (dpred) dpred[i] = gscale * d;
+    }
+    part = block_sum_256(part);
+    if (threadIdx.x == 0 && loss_out) atomicAdd(loss_out, part);
+}
+
+extern "C" int vame_mse_fwd_bwd_f32(const float* pred, const float* target, int64_t tgt_row, int B, int TF, float gscale,
+                                    float* dpred, float* loss_out, void* stream) {
+    VAME_CHECK_ARG(pred && target, VAME_E_BADARG, "mse: null pointer");
+    VAME_CHECK_ARG(B >= 1 && TF >= 1 && tgt_row >= TF, VAME_E_SHAPE, "mse: bad shape");
+    hipLaunchKernelGGL(mse_kernel, dim3(ew_blocks((int64_t)B * TF, 1024)), dim3(256), 0, (hipStream_t)stream, pred, target,
+                       tgt_row, B, TF, gscale, dpred, loss_out);
+    VAME_LAUNCH_CHECK("mse");
+    return VAME_OK;
+}
+
+// --------------------------------------------------------------------------------- column sums
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ in, int64_t R, int C, int64_t ld,
+                                                     float* __restrict__ out, int accumulate) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float s = 0.f;
+    for (int64_t r = 0; r < R; ++r) s += in[r * ld + c];
+    out[c] = accumulate ? out[c] + s : s;
+}
+
+extern "C" int vame_colsum_f32(const float* in, int64_t R, int C, int64_t ld, float* out, int accumulate, void* stream) {
+    VAME_CHECK_ARG(in && out && R >= 1 && C >= 1, VAME_E_BADARG, "colsum: bad argument");
+    hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)cdiv64(C, 256)), dim3(256), 0, (hipStream_t)stream, in, R, C, ld, out,
+                       accumulate);
+    VAME_LAUNCH_CHECK("colsum");
+    return VAME_OK;
+}
+
+// --------------------------------------------------------------------------------- Adam (AMSGrad)
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                   float* __restrict__ v, float* __restrict__ vmax, int64_t n, float step_size,
+                                                   float beta1, float beta2, float eps, float inv_sqrt_bc2, float gscale) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float gi = g[i] * gscale;
+        const float mi = beta1 * m[i] + (1.0f - beta1) * gi;
+        const float vi = beta2 * v[i] + (1.0f - beta2) * gi * gi;
+        const float vm = fmaxf(vmax[i], vi);
+        m[i] = mi; v[i] = vi; vmax[i] = vm;
+        const float denom = sqrtf(vm) * inv_sqrt_bc2 + eps;
+        p[i] -= step_size * (mi / denom);
+    }
+}
+
+extern "C" int vame_adam_amsgrad_f32(float* p, const float* g, float* m, float* v, float* vmax, int64_t n, float lr,
+                                     float beta1, float beta2, float eps, int step, float gscale, void* stream) {
+    VAME_CHECK_ARG(p && g && m && v && vmax && n >= 1 && step >= 1, VAME_E_BADARG, "adam: bad argument");
+    const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
+    hipLaunchKernelGGL(adam_kernel, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, vmax, n,
+                       (float)(lr / bc1), beta1, beta2, eps, (float)(1.0 / sqrt(bc2)), gscale);
+    VAME_LAUNCH_CHECK("adam");
+    return VAME_OK;
+}
+
+__global__ __launch_bounds__(256) void axpy_kernel(const float* __restrict__ x, float a, float* __restrict__ y, int64_t n) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        y[i] += a * x[i];
+}
+extern "C" int vame_axpy_f32(const float* x, float a, float* y, int64_t n, void* stream) {
+    VAME_CHECK_ARG(x && y && n >= 1, VAME_E_BADARG, "axpy: bad argument");
+    hipLaunchKernelGGL(axpy_kernel, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, x, a, y, n);
+    VAME_LAUNCH_CHECK("axpy");
+    return VAME_OK;
+}
+
+// --------------------------------------------------------------------------------- nuclear norm
+// Symmetric eigen-decomposition of G/bsize (Z<=64) by parallel-ordered cyclic Jacobi in fp64: a
+// round-robin schedule gives Z/2 disjoint rotations per round, applied as a column pass and a row
+// pass.  One 256-thread workgroup; latency ~0.1 ms, run beside the decoder kernels.
+#define NUC_MAXZ 64
+__global__ __launch_bounds__(256) void nuclear_kernel(const float* __restrict__ G, int Z, int kloss, int nrows, float lmbda,
+                                                      float bsize, float* __restrict__ loss_out, float* __restrict__ Minv) {
+    __shared__ double A[NUC_MAXZ * NUC_MAXZ];
+    __shared__ double V[NUC_MAXZ * NUC_MAXZ];
+    __shared__ double cs[NUC_MAXZ];        // c at [k], s at [k + 32]
+    __shared__ int pq[NUC_MAXZ];           // p at [k], q at [k + 32]
+    __shared__ double wsel[NUC_MAXZ];
+    const int tid = threadIdx.x, n = Z + (Z & 1), np = n / 2;
+    for (int i = tid; i < n * n; i += 256) {
+        const int r = i / n, c = i % n;
+        A[i] = (r < Z && c < Z) ? 0.5 * ((double)G[r * Z + c] + (double)G[c * Z + r]) / (double)bsize : 0.0;
+        V[i] = (r == c) ? 1.0 : 0.0;
+    }
+    __syncthreads();
+    for (int sweep = 0; sweep < 30; ++sweep) {
+        double off = 0.0, dg = 0.0;
+        for (int i = tid; i < n * n; i += 256) {
+            const int r = i / n, c = i % n;
+            const double a = A[i];
+            if (r == c) dg += a * a; else off += a * a;
+        }
+        __shared__ double ro[256], rd[256];   // block reduce (fp64) through LDS
+        ro[tid] = off; rd[tid] = dg;
+        __syncthreads();
+        for (int s = 128; s >= 1; s >>= 1) {
+            if (tid < s) { ro[tid] += ro[tid + s]; rd[tid] += rd[tid + s]; }
+            __syncthreads();
+        }
+        const bool done = ro[0] <= 1e-26 * rd[0] || rd[0] == 0.0;
+        __syncthreads();
+        if (done) break;
+        for (int round = 0; round < n - 1; ++round) {
+            if (tid < np) {
+                int p, q;
+                if (tid == 0) { p = n - 1; q = round; }
+                else { p = (round + tid) % (n - 1); q = (round - tid + (n - 1)) % (n - 1); }
+                if (p > q) { const int t = p; p = q; q = t; }
+                const double app = A[p * n + p], aqq = A[q * n + q], apq = A[p * n + q];
+                double c = 1.0, s = 0.0;
+                if (fabs(apq) > 1e-300) {
+                    const double tau = (aqq - app) / (2.0 * apq);
+                    const double t = (tau >= 0 ? 1.0 : -1.0) / (fabs(tau) + sqrt(1.0 + tau * tau));
+                    c = 1.0 / sqrt(1.0 + t * t);
+                    s = t * c;
+                }
+                cs[tid] = c; cs[tid + 32] = s; pq[tid] = p; pq[tid + 32] = q;
+            }
+            __syncthreads();
+            for (int i = tid; i < np * n; i += 256) {       // columns: A <- A J ; V <- V J
+                const int k = i / n, r = i % n;
+                const double c = cs[k], s = cs[k + 32];
+                const int p = pq[k], q = pq[k + 32];
+                const double ap = A[r * n + p], aq = A[r * n + q];
+                A[r * n + p] = c * ap - s * aq; A[r * n + q] = s * ap + c * aq;
+                const double vp = V[r * n + p], vq = V[r * n + q];
+                V[r * n + p] = c * vp - s * vq; V[r * n + q] = s * vp + c * vq;
+            }
+            __syncthreads();
+            for (int i = tid; i < np * n; i += 256) {       // rows: A <- J^T A
+                const int k = i / n, col = i % n;
+                const double c = cs[k], s = cs[k + 32];
+                const int p = pq[k], q = pq[k + 32];
+                const double ap = A[p * n + col], aq = A[q * n + col];
+                A[p * n + col] = c * ap - s * aq; A[q * n + col] = s * ap + c * aq;
+            }
+            __syncthreads();
+        }
+    }
+    // select the top k_eff eigenvalues: the (B,B) Gram of the reference has min(B,Z) non-zero ones
+    int keff = kloss < Z ? kloss : Z;
+    if (nrows < keff) keff = nrows;
+    if (tid < Z) {
+        const double w = A[tid * n + tid];
+        int rank = 0;
+        for (int j = 0; j < Z; ++j) {
+            const double wj = A[j * n + j];
+            rank += (wj > w) || (wj == w && j < tid);
+        }
+        wsel[tid] = (rank < keff && w > 0.0) ? sqrt(w) : 0.0;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        double s = 0.0;
+        for (int j = 0; j < Z; ++j) s += wsel[j];
+        loss_out[0] = (float)(lmbda * s);
+    }
+    if (Minv) {
+        for (int i = tid; i < Z * Z; i += 256) {
+            const int a = i / Z, b = i % Z;
+            double s = 0.0;
+            for (int j = 0; j < Z; ++j) {
+                const double sv = wsel[j];
+                if (sv > 0.0) s += V[a * n + j] * V[b * n + j] / sv;
+            }
+            Minv[i] = (float)((double)lmbda / (double)bsize * s);
+        }
+    }
+}
+
+extern "C" int vame_nuclear_f32(const float* G, int Z, int kloss, int nrows, float lmbda, float bsize, float* loss_out,
+                                float* Minv, void* stream) {
+    VAME_CHECK_ARG(G && loss_out, VAME_E_BADARG, "nuclear: null pointer");
+    VAME_CHECK_ARG(Z >= 1 && Z <= NUC_MAXZ && kloss >= 1 && nrows >= 1 && bsize > 0, VAME_E_SHAPE, "nuclear: Z=%d must be in 1..%d",
+                   Z, NUC_MAXZ);
+    hipLaunchKernelGGL(nuclear_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, G, Z, kloss, nrows, lmbda, bsize, loss_out,
+                       Minv);
+    VAME_LAUNCH_CHECK("nuclear");
+    return VAME_OK;
+}

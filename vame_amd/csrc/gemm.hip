@@ -1,0 +1,207 @@
+// Generic fp32 GEMM on the gfx950 f32-input matrix cores (v_mfma_f32_32x32x2_f32: exact fp32,
+// k-ordered fmaf chain, 157 TF peak).  Used for every non-recurrent contraction of the path:
+// GRU input projections, Linear layers, data gradients and the large-K weight gradients
+// (split-K over batch x time).  Operand tiles are staged k-major in LDS so that the MFMA A/B
+// fragments (lane = row/col, lane>>5 = k) are conflict-free ds_read_b32's; global loads are
+// 16-byte and register-prefetched one k-tile ahead.
+#include "vame_common.h"
+
+struct GemmOperand {
+    const float* p;
+    int64_t ld, seg, seg_stride;   // row i -> (seg ? (i/seg)*seg_stride + (i%seg)*ld : i*ld)
+    int vec;                       // 16-byte loads legal
+};
+struct GemmParams {
+    GemmOperand A, B;
+    const float* bias;
+    float* C; int64_t ldc;
+    float* ws;
+    int M, N, K, kper, splitk, accumulate;
+};
+
+__device__ __forceinline__ int64_t op_row(const GemmOperand& o, int64_t i) {
+    return o.seg ? (i / o.seg) * o.seg_stride + (i % o.seg) * o.ld : i * o.ld;
+}
+
+// Fetch this thread's share of a (BK x BX) operand tile into registers.
+//   KM  (stored K x X, X contiguous): item = (k, x-quad)   -> float4 along X
+//   !KM (stored X x K, K contiguous): item = (x, k-quad)   -> float4 along K
+template <int BK, int BX, int NT, bool KM>
+struct TileIO {
+    static constexpr int ITEMS = BK * BX / 4;
+    static constexpr int PER = (ITEMS + NT - 1) / NT;
+    float4 v[PER];
+    __device__ __forceinline__ void fetch(const GemmOperand& o, int x0, int X, int k0, int ke, int tid) {
+#pragma unroll
+        for (int it = 0; it < PER; ++it) {
+            const int idx = tid + it * NT;
+            float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (ITEMS % NT == 0 || idx < ITEMS) {
+                if (KM) {
+                    const int k = idx / (BX / 4), xq = idx % (BX / 4);
+                    const int gk = k0 + k, gx = x0 + 4 * xq;
+                    if (gk < ke && gx < X) {
+                        const float* src = o.p + op_row(o, gk) + gx;
+                        if (o.vec && gx + 3 < X) r = *reinterpret_cast<const float4*>(src);
+                        else { r.x = src[0]; if (gx + 1 < X) r.y = src[1]; if (gx + 2 < X) r.z = src[2]; if (gx + 3 < X) r.w = src[3]; }
+                    }
+                } else {
+                    const int x = idx / (BK / 4), kq = idx % (BK / 4);
+                    const int gx = x0 + x, gk = k0 + 4 * kq;
+                    if (gx < X && gk < ke) {
+                        const float* src = o.p + op_row(o, gx) + gk;
+                        if (o.vec && gk + 3 < ke) r = *reinterpret_cast<const float4*>(src);
+                        else { r.x = src[0]; if (gk + 1 < ke) r.y = src[1]; if (gk + 2 < ke) r.z = src[2]; if (gk + 3 < ke) r.w = src[3]; }
+                    }
+                }
+            }
+            v[it] = r;
+        }
+    }
+    __device__ __forceinline__ void store(float* lds, int LD, int tid) const {
+#pragma unroll
+        for (int it = 0; it < PER; ++it) {
+            const int idx = tid + it * NT;
+            if (ITEMS % NT == 0 || idx < ITEMS) {
+                if (KM) {
+                    const int k = idx / (BX / 4), xq = idx % (BX / 4);
+                    *reinterpret_cast<float4*>(&lds[k * LD + 4 * xq]) = v[it];
+                } else {
+                    const int x = idx / (BK / 4), kq = idx % (BK / 4);
+                    lds[(4 * kq + 0) * LD + x] = v[it].x;
+                    lds[(4 * kq + 1) * LD + x] = v[it].y;
+                    lds[(4 * kq + 2) * LD + x] = v[it].z;
+                    lds[(4 * kq + 3) * LD + x] = v[it].w;
+                }
+            }
+        }
+    }
+};
+
+template <int BM, int BN, int WM, int WN, bool AKM, bool BKM>
+__global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmParams p) {
+    constexpr int BK = 16, NT = WM * WN * 64, TM = BM / WM / 32, TN = BN / WN / 32, LDA = BM + 4, LDB = BN + 4;
+    __shared__ __attribute__((aligned(16))) float As[BK * LDA];
+    __shared__ __attribute__((aligned(16))) float Bs[BK * LDB];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, li = lane & 31, hh = lane >> 5;
+    const int wm = wv / WN, wn = wv % WN;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN, z = blockIdx.z;
+    const int kb = z * p.kper, ke = (kb + p.kper < p.K) ? kb + p.kper : p.K;
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    TileIO<BK, BM, NT, AKM> ta;
+    TileIO<BK, BN, NT, BKM> tb;
+    if (kb < ke) { ta.fetch(p.A, m0, p.M, kb, ke, tid); tb.fetch(p.B, n0, p.N, kb, ke, tid); }
+    for (int k0 = kb; k0 < ke; k0 += BK) {
+        ta.store(As, LDA, tid);
+        tb.store(Bs, LDB, tid);
+        __syncthreads();
+        if (k0 + BK < ke) { ta.fetch(p.A, m0, p.M, k0 + BK, ke, tid); tb.fetch(p.B, n0, p.N, k0 + BK, ke, tid); }
+        const float* ap = &As[hh * LDA + wm * (BM / WM) + li];
+        const float* bp = &Bs[hh * LDB + wn * (BN / WN) + li];
+#pragma unroll
+        for (int kk = 0; kk < BK / 2; ++kk) {
+            float a[TM], b[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) a[i] = ap[2 * kk * LDA + i * 32];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) b[j] = bp[2 * kk * LDB + j * 32];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j] = MFMA_32x32x2(a[i], b[j], acc[i][j]);
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int col = n0 + wn * (BN / WN) + j * 32 + li;
+            if (col >= p.N) continue;
+            const float bv = (p.bias && p.splitk == 1) ? p.bias[col] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wm * (BM / WM) + i * 32 + frag_row(r, lane);
+                if (row >= p.M) continue;
+                float v = acc[i][j][r];
+                if (p.splitk > 1) {
+                    p.ws[((int64_t)z * p.M + row) * p.N + col] = v;
+                } else {
+                    float* c = p.C + (int64_t)row * p.ldc + col;
+                    v += bv;
+                    if (p.accumulate) v += *c;
+                    *c = v;
+                }
+            }
+        }
+}
+
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ ws, int splitk, int M, int N,
+                                                            const float* __restrict__ bias, float* __restrict__ C,
+                                                            int64_t ldc, int accumulate) {
+    const int64_t n = (int64_t)M * N;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        float v = 0.f;
+        for (int z = 0; z < splitk; ++z) v += ws[(int64_t)z * n + i];
+        const int row = (int)(i / N), col = (int)(i % N);
+        if (bias) v += bias[col];
+        float* c = C + (int64_t)row * ldc + col;
+        if (accumulate) v += *c;
+        *c = v;
+    }
+}
+
+template <int BM, int BN, int WM, int WN>
+static int launch_gemm(const GemmParams& p, int akm, int bkm, hipStream_t st) {
+    dim3 grid((unsigned)cdiv64(p.N, BN), (unsigned)cdiv64(p.M, BM), (unsigned)p.splitk), block(WM * WN * 64);
+    if (!akm && !bkm) hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, false, false>), grid, block, 0, st, p);
+    else if (!akm && bkm) hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, false, true>), grid, block, 0, st, p);
+    else if (akm && bkm) hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, true, true>), grid, block, 0, st, p);
+    else return VAME_E_UNSUPPORTED;
+    return VAME_OK;
+}
+
+static int operand_vec(const float* p, int64_t ld, int64_t seg, int64_t seg_stride) {
+    return ((uintptr_t)p % 16 == 0) && (ld % 4 == 0) && (seg == 0 || seg_stride % 4 == 0);
+}
+
+extern "C" int vame_gemm_f32(int M, int N, int K, const float* A, int64_t lda, int a_kmajor, int64_t a_seg,
+                             int64_t a_seg_stride, const float* B, int64_t ldb, int b_kmajor, int64_t b_seg,
+                             int64_t b_seg_stride, const float* bias, float* C, int64_t ldc, int accumulate, int splitk,
+                             float* ws, void* stream) {
+    VAME_CHECK_ARG(M >= 1 && N >= 1 && K >= 1, VAME_E_SHAPE, "gemm: empty problem M=%d N=%d K=%d", M, N, K);
+    VAME_CHECK_ARG(A && B && C, VAME_E_BADARG, "gemm: null operand");
+    VAME_CHECK_ARG(!(a_kmajor && !b_kmajor), VAME_E_UNSUPPORTED, "gemm: A k-major with B n-major is not provided");
+    VAME_CHECK_ARG(splitk >= 1 && (splitk == 1 || ws), VAME_E_BADARG, "gemm: splitk=%d needs a workspace", splitk);
+    GemmParams p;
+    p.A = {A, lda, a_seg, a_seg_stride, operand_vec(A, lda, a_seg, a_seg_stride)};
+    p.B = {B, ldb, b_seg, b_seg_stride, operand_vec(B, ldb, b_seg, b_seg_stride)};
+    p.bias = bias; p.C = C; p.ldc = ldc; p.ws = ws;
+    p.M = M; p.N = N; p.K = K; p.accumulate = accumulate;
+    int kper = (int)(cdiv64(cdiv64(K, splitk), 16) * 16);
+    p.kper = kper;
+    p.splitk = (int)cdiv64(K, kper);
+    hipStream_t st = (hipStream_t)stream;
+    int rc;
+    if (N > 64) rc = launch_gemm<128, 128, 2, 2>(p, a_kmajor, b_kmajor, st);
+    else if (N > 32) rc = launch_gemm<128, 64, 4, 1>(p, a_kmajor, b_kmajor, st);
+    else rc = launch_gemm<128, 32, 4, 1>(p, a_kmajor, b_kmajor, st);
+    VAME_CHECK_ARG(rc == VAME_OK, rc, "gemm: unsupported layout");
+    VAME_LAUNCH_CHECK("gemm");
+    if (p.splitk > 1) {
+        const int64_t n = (int64_t)M * N;
+        const int blocks = (int)(cdiv64(n, 256) < 2048 ? cdiv64(n, 256) : 2048);
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, (const float*)ws, p.splitk, M, N, bias, C,
+                           ldc, accumulate);
+        VAME_LAUNCH_CHECK("gemm splitk reduce");
+    }
+    return VAME_OK;
+}

@@ -1,0 +1,43 @@
+// Common device-side definitions for the gfx950 kernels of the VAME RNN-VAE hot path.
+// Written for MI355X (CDNA4, wave64) only.  VAME_EMU selects the host emulator used by the CPU
+// test-suite (tests/emu); the shipped library is always built with hipcc for gfx950.
+#pragma once
+#ifdef VAME_EMU
+#include "hip_emu.h"
+typedef f32x16_emu f32x16;
+typedef f32x4_emu f32x4;
+#define MFMA_32x32x2(a, b, c) emu_mfma_32x32x2((a), (b), (c))
+#define MFMA_16x16x4(a, b, c) emu_mfma_16x16x4((a), (b), (c))
+#define VAME_DYN_SMEM(name) char* name = emu::dyn_smem()
+#define SETPRIO(n)
+#define VAME_EXPF(x) expf(x)
+#define VAME_RCP(x) (1.0f / (x))
+#else
+#include <hip/hip_runtime.h>
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+// f32-in/f32-acc matrix FMA: exact f32 (k-ordered fmaf chain) at the 157 TF rate on gfx950
+#define MFMA_32x32x2(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
+#define MFMA_16x16x4(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+#define VAME_DYN_SMEM(name) extern __shared__ __attribute__((aligned(16))) char name[]
+#define SETPRIO(n) __builtin_amdgcn_s_setprio(n)
+#define VAME_EXPF(x) __expf(x)
+#define VAME_RCP(x) __frcp_rn(x)
+#endif
+#include <stdint.h>
+
+#define VAME_WAVE 64
+
+// ---- 32x32 MFMA accumulator fragment (C/D) layout on gfx950:
+//   lane l holds column (l & 31); register r holds row  (r&3) + 8*(r>>2) + 4*(l>>5)
+__device__ __forceinline__ int frag_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
+
+__device__ __forceinline__ float fast_sigmoid(float x) { return VAME_RCP(1.0f + VAME_EXPF(-x)); }
+// tanh(x) = 1 - 2/(exp(2x)+1): absolute error ~1e-7, saturates correctly for |x| large
+__device__ __forceinline__ float fast_tanh(float x) { return 1.0f - 2.0f * VAME_RCP(VAME_EXPF(2.0f * x) + 1.0f); }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
+    return v;
+}

@@ -1,0 +1,124 @@
+"""Thin tensor-level wrappers over the C ABI (include/vame_hip.h).  PyTorch is plumbing here:
+device memory, the current HIP stream and nothing else."""
+import torch
+
+from . import _lib
+
+GF = dict(GI=0, GI_ROW=1, GI_T=2, WP=3, BHN=4, H0=5, H0_ROW=6, Y=7, Y_ROW=8, Y_T=9, HN=10, HN_ROW=11, STASH=12, T=13,
+          REVERSE=14, PAD=15, N=16)
+GB = dict(STASH=0, Y=1, Y_ROW=2, Y_T=3, H0=4, H0_ROW=5, WPT=6, DY=7, DY_ROW=8, DY_T=9, DHN=10, DHN_ROW=11, DG=12, DH0=13,
+          DH0_ROW=14, DBIAS=15, DGSUM=16, T=17, REVERSE=18, PAD=19, N=20)
+
+
+def _stream():
+    if _lib.emulated():
+        return None
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _ptr(t, off=0):
+    if t is None:
+        return None
+    if not _lib.emulated() and not t.is_cuda:
+        raise _lib.VameHipError("vame_amd ops need CUDA(HIP) tensors; there is no CPU path")
+    assert t.dtype in (torch.float32, torch.int64), t.dtype
+    return t.data_ptr() + off * t.element_size()
+
+
+def addr(t, off=0):
+    """Integer device address of element `off` of tensor t (0 for None) for descriptor tables."""
+    return 0 if t is None else _ptr(t, off)
+
+
+class Operand:
+    """A GEMM operand: base tensor (+ element offset), leading dim and optional 2-level row addressing."""
+    __slots__ = ("t", "off", "ld", "seg", "seg_stride")
+
+    def __init__(self, t, ld, off=0, seg=0, seg_stride=0):
+        self.t, self.off, self.ld, self.seg, self.seg_stride = t, off, ld, seg, seg_stride
+
+
+def gemm(M, N, K, A, a_kmajor, B, b_kmajor, C, ldc, c_off=0, bias=None, accumulate=False, splitk=1, ws=None):
+    L = _lib.lib()
+    if splitk > 1:
+        assert ws is not None and ws.numel() >= splitk * M * N, "split-K workspace too small"
+    rc = L.vame_gemm_f32(M, N, K, _ptr(A.t, A.off), A.ld, int(a_kmajor), A.seg, A.seg_stride, _ptr(B.t, B.off), B.ld,
+                         int(b_kmajor), B.seg, B.seg_stride, _ptr(bias), _ptr(C, c_off), ldc, int(accumulate), splitk,
+                         _ptr(ws), _stream())
+    _lib.check(rc, "vame_gemm_f32")
+
+
+def window_gather(X, N, F, starts, start0, B, L, out):
+    rc = _lib.lib().vame_window_gather_f32(_ptr(X), N, F, _ptr(starts), start0, B, L, _ptr(out), _stream())
+    _lib.check(rc, "vame_window_gather_f32")
+
+
+def gru_pack(W_hh, b_ih, b_hh, H, wp_fwd, wp_bwd, bias_gi, b_hn):
+    rc = _lib.lib().vame_gru_pack_f32(_ptr(W_hh), _ptr(b_ih), _ptr(b_hh), H, _ptr(wp_fwd), _ptr(wp_bwd), _ptr(bias_gi),
+                                      _ptr(b_hn), _stream())
+    _lib.check(rc, "vame_gru_pack_f32")
+
+
+def gru_stash_floats(B, T, H):
+    return int(_lib.lib().vame_gru_stash_floats(B, T, H))
+
+
+def _desc_tensor(rows, nfields):
+    d = torch.zeros(len(rows), nfields, dtype=torch.int64)
+    for i, r in enumerate(rows):
+        for k, v in r.items():
+            d[i, k] = int(v)
+    return d
+
+
+def gru_seq_fwd(streams, B, H):
+    """streams: list of dicts keyed by GF[...] indices."""
+    d = _desc_tensor(streams, GF["N"])
+    rc = _lib.lib().vame_gru_seq_fwd_f32(d.data_ptr(), len(streams), B, H, _stream())
+    _lib.check(rc, "vame_gru_seq_fwd_f32")
+
+
+def gru_seq_bwd(streams, B, H):
+    d = _desc_tensor(streams, GB["N"])
+    rc = _lib.lib().vame_gru_seq_bwd_f32(d.data_ptr(), len(streams), B, H, _stream())
+    _lib.check(rc, "vame_gru_seq_bwd_f32")
+
+
+def latent_fwd(mu, lv_raw, eps, B, Z, softplus, training, logvar, z, kl_out):
+    rc = _lib.lib().vame_latent_fwd_f32(_ptr(mu), _ptr(lv_raw), _ptr(eps), B, Z, int(softplus), int(training), _ptr(logvar),
+                                        _ptr(z), _ptr(kl_out), _stream())
+    _lib.check(rc, "vame_latent_fwd_f32")
+
+
+def latent_bwd(dz, mu, logvar, lv_raw, eps, B, Z, softplus, ckl, dmu, dlv):
+    rc = _lib.lib().vame_latent_bwd_f32(_ptr(dz), _ptr(mu), _ptr(logvar), _ptr(lv_raw), _ptr(eps), B, Z, int(softplus),
+                                        float(ckl), _ptr(dmu), _ptr(dlv), _stream())
+    _lib.check(rc, "vame_latent_bwd_f32")
+
+
+def mse_fwd_bwd(pred, target, tgt_off, tgt_row, B, TF, gscale, dpred, loss_out, loss_off=0):
+    rc = _lib.lib().vame_mse_fwd_bwd_f32(_ptr(pred), _ptr(target, tgt_off), tgt_row, B, TF, float(gscale), _ptr(dpred),
+                                         _ptr(loss_out, loss_off), _stream())
+    _lib.check(rc, "vame_mse_fwd_bwd_f32")
+
+
+def nuclear(G, Z, kloss, nrows, lmbda, bsize, loss_out, loss_off, Minv):
+    rc = _lib.lib().vame_nuclear_f32(_ptr(G), Z, kloss, nrows, float(lmbda), float(bsize), _ptr(loss_out, loss_off),
+                                     _ptr(Minv), _stream())
+    _lib.check(rc, "vame_nuclear_f32")
+
+
+def colsum(inp, in_off, R, C, ld, out, out_off=0, accumulate=False):
+    rc = _lib.lib().vame_colsum_f32(_ptr(inp, in_off), R, C, ld, _ptr(out, out_off), int(accumulate), _stream())
+    _lib.check(rc, "vame_colsum_f32")
+
+
+def adam_amsgrad(p, g, m, v, vmax, n, lr, step, gscale=1.0, beta1=0.9, beta2=0.999, eps=1e-8):
+    rc = _lib.lib().vame_adam_amsgrad_f32(_ptr(p), _ptr(g), _ptr(m), _ptr(v), _ptr(vmax), n, lr, beta1, beta2, eps, step,
+                                          gscale, _stream())
+    _lib.check(rc, "vame_adam_amsgrad_f32")
+
+
+def axpy(x, a, y, n, x_off=0, y_off=0):
+    rc = _lib.lib().vame_axpy_f32(_ptr(x, x_off), float(a), _ptr(y, y_off), n, _stream())
+    _lib.check(rc, "vame_axpy_f32")
