@@ -1,0 +1,212 @@
+#!/usr/bin/env python3
+"""Benchmark of the VAME RNN-VAE training hot path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+A "step" is one pass of the hot path over one batch of synthetic temporal windows: window gather
+(sliding-window batcher) -> RNN-VAE forward -> MSE + future-MSE + KL + nuclear-norm loss -> BPTT
+-> one RCCL all-reduce of the flat gradient bucket (N > 1) -> fused Adam-AMSGrad.  Workload =
+BASELINE.json config 2: T=30, F=24, H=256, Z=30, FS=15, batch 4096 windows per GPU, fp32.
+The series is already resident in HBM when the timed region starts.
+
+Prints ONE JSON line (rank 0): metric/value/unit + roofline (dominant kernel, measured with HIP
+events on the launch stream) + cpu_baseline (reference-equivalent torch-CPU model, oracle/torch_ref.py).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+T, F, Z, H, FS = 30, 24, 30, 256, 15
+B_LOCAL = 4096
+N_SERIES = 1_000_000
+MFLOP_PER_WINDOW_TRAIN = 400.343          # matmul flops, 2/MAC, bwd = 2x fwd, decoder input projection once
+PEAK_F32_MFMA_TFLOPS = 157.3              # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+PEAK_HBM_GBS = 8000.0
+
+
+def synth_series(n, seed=0):
+    rng = np.random.default_rng(seed)
+    i = np.arange(n, dtype=np.float64)
+    X = np.sin(2 * np.pi * i[None, :] * (np.arange(F, dtype=np.float64)[:, None] + 1) / 997.0) + 0.5 * rng.standard_normal((F, n))
+    return ((X - X.mean()) / X.std()).astype(np.float32)
+
+
+class KernelTimer:
+    """HIP-event timing of each C-ABI launch group on the stream it is launched on (torch's current stream)."""
+
+    def __init__(self):
+        self.records = []
+
+    def wrap(self, ops_mod, name, flops_fn):
+        inner = getattr(ops_mod, name)
+
+        def timed(*a, **k):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            r = inner(*a, **k)
+            e1.record()
+            self.records.append((name, flops_fn(*a, **k), e0, e1))
+            return r
+        setattr(ops_mod, name, timed)
+        return inner
+
+    def summary(self):
+        torch.cuda.synchronize()
+        agg = {}
+        for name, (key, flops), e0, e1 in self.records:
+            d = agg.setdefault(key, dict(api=name, launches=0, ms=0.0, flops=0.0))
+            d["launches"] += 1
+            d["ms"] += e0.elapsed_time(e1)
+            d["flops"] += flops
+        return agg
+
+
+def profile_kernels(model, loader, steps=3):
+    """Per-kernel-class time + algorithmic flops over `steps` train steps (separate from the timed region)."""
+    from vame_amd import ops
+    kt = KernelTimer()
+
+    def gru_flops(tag):
+        def f(streams, B, Hh):
+            key_t = ops.GF["T"] if tag == "fwd" else ops.GB["T"]
+            fl = sum(2.0 * 3 * Hh * Hh * B * int(s[key_t]) for s in streams)
+            return (f"gru_seq_{tag}_kernel<{Hh}> x{len(streams)} streams", fl)
+        return f
+
+    def gemm_flops(M, N, K, A, akm, Bm, bkm, *a, **k):
+        kind = "NT" if (not akm and not bkm) else ("NN" if not akm else "TN")
+        return (f"gemm_kernel {kind} M={M} N={N} K={K}", 2.0 * M * N * K)
+    saved = {n: kt.wrap(ops, n, fn) for n, fn in (("gru_seq_fwd", gru_flops("fwd")), ("gru_seq_bwd", gru_flops("bwd")),
+                                                  ("gemm", gemm_flops))}
+    try:
+        for _ in range(steps):
+            win = loader.gather(loader.draw_starts())
+            model.loss_step(win, 1.0, beta=1.0, kloss=Z, klmbda=0.1, bsize=B_LOCAL)
+        agg = kt.summary()
+    finally:
+        for n, fn in saved.items():
+            setattr(ops, n, fn)
+    for d in agg.values():
+        d["launches"] /= steps
+        d["ms"] /= steps
+        d["flops"] /= steps
+    return agg
+
+
+def main():
+    global B_LOCAL
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--batch", type=int, default=B_LOCAL)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback for the measured path)")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+
+    from vame_amd.model.dataloader import DeviceWindowLoader
+    from vame_amd.model.rnn_model import RNN_VAE
+    from vame_amd.model.rnn_vae import FusedAdamAMSGrad, allreduce_gradients
+
+    B_LOCAL = args.batch
+    torch.manual_seed(19)
+    model = RNN_VAE(2 * T, Z, F, 1, FS, H, H, H, H, 0, 0, 0, False).to(dev).train()
+    opt = FusedAdamAMSGrad(model, lr=5e-4)
+
+    class _DS:   # synthetic stand-in for SEQUENCE_DATASET: already z-scored (F,N) series
+        data_points, temporal_window = N_SERIES, 2 * T
+        X = np.empty((F, 1))
+
+        @staticmethod
+        def normalised_f32():
+            return synth_series(N_SERIES)
+    loader = DeviceWindowLoader(_DS, B_LOCAL, T + FS, dev, rank=0, world=1)
+    np.random.seed(1000 + rank)
+
+    def step():
+        win = loader.gather(loader.draw_starts())
+        terms = model.loss_step(win, 1.0, beta=1.0, kloss=Z, klmbda=0.1, bsize=B_LOCAL)
+        gs = allreduce_gradients(model)
+        opt.step(gscale=gs)
+        return terms
+
+    for _ in range(args.warmup):
+        terms = step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        terms = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    last = [float(v) for v in terms.cpu()]
+    assert all(np.isfinite(last)), f"non-finite loss terms {last}"
+
+    if rank == 0:
+        value = B_LOCAL * world * args.steps / dt
+        agg = profile_kernels(model, loader)
+        total_ms = sum(d["ms"] for d in agg.values())
+        dom_key = max(agg, key=lambda k: agg[k]["ms"])
+        dom = agg[dom_key]
+        per_launch_ms = dom["ms"] / dom["launches"]
+        achieved = dom["flops"] / dom["launches"] / (per_launch_ms * 1e-3) / 1e12
+        classes = {}
+        for k, d in agg.items():
+            c = k.split(" ")[0] + (" " + k.split(" ")[1] if k.startswith("gemm") else "")
+            e = classes.setdefault(c, dict(ms=0.0, flops=0.0))
+            e["ms"] += d["ms"]
+            e["flops"] += d["flops"]
+        roof = dict(bound="mfma", kernel=dom_key, achieved=round(achieved, 3), peak=PEAK_F32_MFMA_TFLOPS, unit="TFLOP/s",
+                    frac=round(achieved / PEAK_F32_MFMA_TFLOPS, 4), traffic=None,
+                    launch_ms=round(per_launch_ms, 4), launches_per_step=dom["launches"],
+                    step_frac=round(value / world * MFLOP_PER_WINDOW_TRAIN * 1e6 / (PEAK_F32_MFMA_TFLOPS * 1e12), 4),
+                    by_class={c: dict(ms_per_step=round(e["ms"], 3), tflops=round(e["flops"] / (e["ms"] * 1e-3) / 1e12, 2))
+                              for c, e in classes.items()},
+                    timed_kernel_ms_per_step=round(total_ms, 3))
+        out = dict(metric="temporal windows/sec (train) T=30,F=24,h=256", value=round(value, 1), unit="windows/s", n_gpus=world,
+                   steps=args.steps, warmup=args.warmup, ms_per_step=round(dt / args.steps * 1e3, 3), higher_is_better=True,
+                   scaling="weak", vs_baseline=None, dtype="f32", data="synthetic",
+                   config=dict(workload="BASELINE.json configs[1]: T=30,F=24,zdims=30,hidden=256,FS=15, batch=4096/GPU fp32 train step "
+                                        "(gather+fwd+loss+bwd+allreduce+Adam-amsgrad)", global_batch=B_LOCAL * world,
+                               parallelism=f"dp{world}", last_loss_terms=last),
+                   roofline=roof)
+        if not args.no_cpu_baseline and world == 1:
+            from oracle.torch_ref import time_train_steps
+            out["cpu_baseline"] = time_train_steps(B=256, steps=12, warmup=2)
+            out["cpu_baseline"]["value"] = round(out["cpu_baseline"]["value"], 1)
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -103,9 +103,11 @@ int vame_mse_fwd_bwd_f32(const float* pred, const float* target, int64_t tgt_row
                          float gscale, float* dpred, float* loss_out, void* stream);
 
 /* cluster_loss (vame/model/rnn_vae.py:45-50) from the (Z,Z) Gram G = z^T z (un-normalised, from vame_gemm_f32):
- *   loss_out[0] = lmbda * sum_{i<k} sqrt(eig_i(G/bsize)),  Minv (Z,Z) = (lmbda/bsize) V_k S_k^-1 V_k^T
- * so that d loss/dz = z Minv.  One workgroup, cyclic Jacobi in fp64. */
-int vame_nuclear_f32(const float* G, int Z, int kloss, int nrows, float lmbda, float bsize,
+ *   loss_out[0] = lmbda * sum_{i<k} sqrt(eig_i(G/bsize)),  Minv (Z,Z) = gscale*(lmbda/bsize) V_k S_k^-1 V_k^T
+ * so that gscale * d loss/dz = z Minv (gscale = the KL-annealing weight).  k is clipped to
+ * min(kloss, Z, nrows) like sv_2[:kloss] of the reference's (B,B) SVD.  One workgroup, parallel
+ * cyclic Jacobi in fp64. */
+int vame_nuclear_f32(const float* G, int Z, int kloss, int nrows, float lmbda, float bsize, float gscale,
                      float* loss_out, float* Minv, void* stream);
 
 /* out[c] (+)= sum_r in[r*ld + c] */

@@ -1,0 +1,35 @@
+"""The kernel checks of test_kernels_emu.py on the real MI355X through libvame_hip.so (C ABI)."""
+import pytest
+
+from kernel_cases import (check_adam, check_colsum, check_gather, check_gemm_cases, check_gru_bwd, check_gru_fwd,
+                          check_latent, check_mse, check_nuclear)
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def test_gemm(hip):
+    check_gemm_cases(DEV, small=False)
+
+
+@pytest.mark.parametrize("H,B,T", [(32, 5, 4), (64, 40, 3), (128, 70, 5), (256, 100, 30), (256, 4096, 4)])
+def test_gru_fwd(hip, H, B, T):
+    check_gru_fwd(DEV, H, B, T)
+
+
+@pytest.mark.parametrize("H,B,T", [(32, 5, 4), (64, 40, 3), (128, 70, 5), (256, 100, 30)])
+def test_gru_bwd(hip, H, B, T):
+    check_gru_bwd(DEV, H, B, T)
+
+
+def test_elementwise(hip):
+    check_gather(DEV)
+    check_latent(DEV)
+    check_mse(DEV)
+    check_colsum(DEV)
+    check_adam(DEV)
+
+
+@pytest.mark.parametrize("B,Z,k", [(64, 30, 30), (8, 30, 30), (50, 7, 4), (4096, 30, 30)])
+def test_nuclear(hip, B, Z, k):
+    check_nuclear(DEV, B, Z, k)

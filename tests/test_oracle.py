@@ -106,3 +106,23 @@ def test_kl_annealing_table():
             assert vo.kl_annealing(e, t["kl_start"], t["annealtime"], fn) == pytest.approx(v, abs=1e-12)
     with pytest.raises(NotImplementedError):
         vo.kl_annealing(5, 2, 4, "cosine")
+
+
+def test_torch_cpu_baseline_model_matches_reference():
+    """oracle/torch_ref.py (the CPU baseline timed by bench.py) reproduces the reference's losses and grads."""
+    import torch
+    from oracle.torch_ref import TorchRef, reference_loss
+    g = load_golden("step_tiny")
+    spec = spec_of(g)
+    m = TorchRef(spec.T, spec.F, spec.Z, spec.H, spec.FS, spec.future, spec.softplus)
+    m.load_reference_state(golden_weights(g))
+    m.train()
+    x, xf, eps = [torch.from_numpy(g[k]) for k in ("x", "xfut", "eps")]
+    loss, terms = reference_loss(m(x, eps), x, xf, 1.0)
+    loss.backward()
+    ref = g["kw1/losses"]
+    for v, r in zip(list(terms) + [loss], ref):
+        assert abs(v.item() - r) <= 1e-5 * max(1, abs(r))
+    for k, gr in m.reference_named_grads().items():
+        r = g["kw1/g/" + k]
+        np.testing.assert_allclose(gr.numpy(), r, atol=1e-5 * max(1, np.abs(r).max()), err_msg=k)

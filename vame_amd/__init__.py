@@ -1,0 +1,9 @@
+"""vame_amd -- MI355X-native implementation of VAME's RNN-VAE training + latent-embedding path.
+
+`import vame_amd as vame` gives the two workflow calls of the reference that sit on this path
+(vame/__init__.py:16,18):  vame.train_model(config)  and  vame.pose_segmentation(config).
+"""
+from .analysis.pose_segmentation import pose_segmentation  # noqa: F401
+from .model.rnn_vae import train_model  # noqa: F401
+
+__version__ = "0.1.0"

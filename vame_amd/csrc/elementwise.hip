@@ -211,7 +211,8 @@ extern "C" int vame_axpy_f32(const float* x, float a, float* y, int64_t n, void*
 // pass.  One 256-thread workgroup; latency ~0.1 ms, run beside the decoder kernels.
 #define NUC_MAXZ 64
 __global__ __launch_bounds__(256) void nuclear_kernel(const float* __restrict__ G, int Z, int kloss, int nrows, float lmbda,
-                                                      float bsize, float* __restrict__ loss_out, float* __restrict__ Minv) {
+                                                      float bsize, float gscale, float* __restrict__ loss_out,
+                                                      float* __restrict__ Minv) {
     __shared__ double A[NUC_MAXZ * NUC_MAXZ];
     __shared__ double V[NUC_MAXZ * NUC_MAXZ];
     __shared__ double cs[NUC_MAXZ];        // c at [k], s at [k + 32]
@@ -304,18 +305,18 @@ __global__ __launch_bounds__(256) void nuclear_kernel(const float* __restrict__ 
                 const double sv = wsel[j];
                 if (sv > 0.0) s += V[a * n + j] * V[b * n + j] / sv;
             }
-            Minv[i] = (float)((double)lmbda / (double)bsize * s);
+            Minv[i] = (float)((double)gscale * (double)lmbda / (double)bsize * s);
         }
     }
 }
 
-extern "C" int vame_nuclear_f32(const float* G, int Z, int kloss, int nrows, float lmbda, float bsize, float* loss_out,
-                                float* Minv, void* stream) {
+extern "C" int vame_nuclear_f32(const float* G, int Z, int kloss, int nrows, float lmbda, float bsize, float gscale,
+                                float* loss_out, float* Minv, void* stream) {
     VAME_CHECK_ARG(G && loss_out, VAME_E_BADARG, "nuclear: null pointer");
     VAME_CHECK_ARG(Z >= 1 && Z <= NUC_MAXZ && kloss >= 1 && nrows >= 1 && bsize > 0, VAME_E_SHAPE, "nuclear: Z=%d must be in 1..%d",
                    Z, NUC_MAXZ);
-    hipLaunchKernelGGL(nuclear_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, G, Z, kloss, nrows, lmbda, bsize, loss_out,
-                       Minv);
+    hipLaunchKernelGGL(nuclear_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, G, Z, kloss, nrows, lmbda, bsize, gscale,
+                       loss_out, Minv);
     VAME_LAUNCH_CHECK("nuclear");
     return VAME_OK;
 }

@@ -1,0 +1,378 @@
+"""Host orchestration of the RNN-VAE forward / backward on MI355X.
+
+The reference delegates this to torch autograd over nn.GRU / nn.Linear
+(vame/model/rnn_model.py:162-179 forward, vame/model/rnn_vae.py:124-143 loss + backward).  Here
+it is an explicit schedule of the C-ABI kernels (include/vame_hip.h) on the current HIP stream:
+
+  forward   input-projection GEMMs -> GRU sequence kernels (2 or 4 (layer,dir) streams per
+            launch) -> Lambda GEMMs + reparameterisation -> decoder GEMMs/GRUs -> output GEMMs
+  loss      MSE(sum) x2 + KL(mean) + nuclear norm from the (Z,Z) Gram
+  backward  the same graph reversed; weight gradients are split-K GEMMs over (batch x time)
+            written straight into the flat gradient bucket that RCCL all-reduces.
+
+All buffers are fp32 and live in a per-batch-size workspace (no allocation inside a step).
+Sequences are stored as (B, T+2, 2H): slot 0 / T+1 hold the initial state of the forward /
+reverse direction so h_{t-1} is a plain strided view for the BPTT kernels and the dW_hh GEMMs.
+"""
+from dataclasses import dataclass
+
+import torch
+
+from . import ops
+from .ops import GB, GF, Operand
+
+LOSS_REC, LOSS_FUT, LOSS_KLSUM, LOSS_KMEANS = 0, 1, 2, 3
+
+
+@dataclass(frozen=True)
+class Spec:
+    T: int
+    F: int
+    Z: int
+    H: int
+    FS: int
+    future: bool
+    softplus: bool
+
+
+class ParamTable:
+    """Name -> (offset, shape) layout of the flat fp32 parameter / gradient buffers."""
+
+    def __init__(self, named_shapes):
+        self.offsets, self.shapes, n = {}, {}, 0
+        for name, shape in named_shapes:
+            numel = 1
+            for s in shape:
+                numel *= s
+            self.offsets[name], self.shapes[name] = n, tuple(shape)
+            n += (numel + 3) // 4 * 4            # keep every tensor 16-byte aligned inside the bucket
+        self.numel = n
+
+    def off(self, name):
+        return self.offsets[name]
+
+
+class GruDir:
+    """Packed per-(layer,direction) weights refreshed after every optimizer step."""
+
+    def __init__(self, prefix, sfx, H, I, dev):
+        self.w_ih, self.w_hh = f"{prefix}.weight_ih{sfx}", f"{prefix}.weight_hh{sfx}"
+        self.b_ih, self.b_hh = f"{prefix}.bias_ih{sfx}", f"{prefix}.bias_hh{sfx}"
+        self.H, self.I = H, I
+        self.wp_fwd = torch.empty(3 * H * H, device=dev)
+        self.wp_bwd = torch.empty(3 * H * H, device=dev)
+        self.bias_gi = torch.empty(3 * H, device=dev)
+        self.b_hn = torch.empty(H, device=dev)
+
+
+class Workspace:
+    def __init__(self):
+        self.t = {}
+
+    def get(self, name, numel, dev, dtype=torch.float32, zero=False):
+        t = self.t.get(name)
+        if t is None or t.numel() < numel or t.device != dev:
+            t = (torch.zeros if zero else torch.empty)(int(numel), device=dev, dtype=dtype)
+            self.t[name] = t
+        return t
+
+
+class VAEEngine:
+    def __init__(self, spec: Spec, table: ParamTable, flat_p: torch.Tensor, flat_g: torch.Tensor):
+        self.spec, self.table, self.p, self.g = spec, table, flat_p, flat_g
+        self.dev = flat_p.device
+        H, F, Z = spec.H, spec.F, spec.Z
+        if H % 32 or H > 256:
+            raise ValueError(f"hidden size {H}: the gfx950 GRU kernels support multiples of 32 up to 256")
+        e = "encoder.encoder_rnn"
+        self.enc = [[GruDir(e, "_l0", H, F, self.dev), GruDir(e, "_l0_reverse", H, F, self.dev)],
+                    [GruDir(e, "_l1", H, 2 * H, self.dev), GruDir(e, "_l1_reverse", H, 2 * H, self.dev)]]
+        self.dec = [GruDir("decoder.rnn_rec", "_l0", H, Z, self.dev), GruDir("decoder.rnn_rec", "_l0_reverse", H, Z, self.dev)]
+        self.fut = ([GruDir("decoder_future.rnn_pred", "_l0", H, Z, self.dev),
+                     GruDir("decoder_future.rnn_pred", "_l0_reverse", H, Z, self.dev)] if spec.future else [])
+        self.ws = Workspace()
+        self.packed_version = -1
+        self.version = 0          # bumped by the owner whenever flat_p changes
+        self._B = None
+
+    # ------------------------------------------------------------------ helpers
+    def _all_dirs(self):
+        return self.enc[0] + self.enc[1] + self.dec + self.fut
+
+    def repack(self):
+        if self.packed_version == self.version:
+            return
+        t = self.table
+        for d in self._all_dirs():
+            ops.gru_pack(self._pv(d.w_hh), self._pv(d.b_ih), self._pv(d.b_hh), d.H, d.wp_fwd, d.wp_bwd, d.bias_gi, d.b_hn)
+        self.packed_version = self.version
+
+    def _pv(self, name):
+        o = self.table.off(name)
+        n = 1
+        for s in self.table.shapes[name]:
+            n *= s
+        return self.p[o:o + n]
+
+    def P(self, name, ld):
+        return Operand(self.p, ld, off=self.table.off(name))
+
+    def buf(self, name, *shape, zero=False):
+        n = 1
+        for s in shape:
+            n *= s
+        return self.ws.get(name, n, self.dev, zero=zero)
+
+    def _splitk(self, M, N, K):
+        tiles = ((M + 127) // 128) * ((N + 127) // 128 if N > 64 else 1)
+        sk = max(1, min(512 // max(tiles, 1), K // 256))
+        return sk
+
+    def _gemm_wgrad(self, M, N, K, A, B, gname, row_off=0):
+        """flat_g[gname][row_off:row_off+M, :N] = A^T B with split-K over K = batch x time."""
+        sk = self._splitk(M, N, K)
+        ws = self.ws.get("splitk", max(sk * M * N, 1), self.dev) if sk > 1 else None
+        ops.gemm(M, N, K, A, 1, B, 1, self.g, N, c_off=self.table.off(gname) + row_off * N, splitk=sk, ws=ws)
+
+    # ------------------------------------------------------------------ forward
+    def _gru_fwd_stream(self, d: GruDir, gi, gi_row, gi_t, h0, h0_off, Y, y_cols, y_T, dirn, hn, hn_off, hn_row, stash, T,
+                        write_y=True):
+        H = self.spec.H
+        return {GF["GI"]: ops.addr(gi), GF["GI_ROW"]: gi_row, GF["GI_T"]: gi_t, GF["WP"]: ops.addr(d.wp_fwd),
+                GF["BHN"]: ops.addr(d.b_hn), GF["H0"]: ops.addr(h0, h0_off) if h0 is not None else 0, GF["H0_ROW"]: H,
+                GF["Y"]: ops.addr(Y, y_cols + dirn * H) if (write_y and Y is not None) else 0,
+                GF["Y_ROW"]: (y_T + 2) * 2 * H, GF["Y_T"]: 2 * H,
+                GF["HN"]: ops.addr(hn, hn_off) if hn is not None else 0, GF["HN_ROW"]: hn_row,
+                GF["STASH"]: ops.addr(stash) if stash is not None else 0, GF["T"]: T, GF["REVERSE"]: dirn, GF["PAD"]: 1}
+
+    def encode(self, win, win_row, B, training):
+        """win: (B, >=T, F) windows with row stride win_row (elements).  Returns hn (B,4H)."""
+        s, H, T, F = self.spec, self.spec.H, self.spec.T, self.spec.F
+        self.repack()
+        x_op = Operand(win, F, seg=T, seg_stride=win_row)
+        Y0 = self.buf("Y0", B, T + 2, 2 * H)
+        hn = self.buf("hn", B, 4 * H)
+        rows = []
+        for dirn, d in enumerate(self.enc[0]):
+            gi = self.buf(f"gi_e0_{dirn}", B, T, 3 * H)
+            ops.gemm(B * T, 3 * H, F, x_op, 0, self.P(d.w_ih, F), 0, gi, 3 * H, bias=d.bias_gi)
+            st = self.buf(f"st_e0_{dirn}", ops.gru_stash_floats(B, T, H)) if training else None
+            rows.append(self._gru_fwd_stream(d, gi, T * 3 * H, 3 * H, None, 0, Y0, 2 * H, T, dirn, hn, dirn * H, 4 * H, st, T))
+        ops.gru_seq_fwd(rows, B, H)
+        y_op = Operand(Y0, 2 * H, off=2 * H, seg=T, seg_stride=(T + 2) * 2 * H)
+        Y1 = self.buf("Y1", B, T + 2, 2 * H) if training else None
+        rows = []
+        for dirn, d in enumerate(self.enc[1]):
+            gi = self.buf(f"gi_e1_{dirn}", B, T, 3 * H)
+            ops.gemm(B * T, 3 * H, 2 * H, y_op, 0, self.P(d.w_ih, 2 * H), 0, gi, 3 * H, bias=d.bias_gi)
+            st = self.buf(f"st_e1_{dirn}", ops.gru_stash_floats(B, T, H)) if training else None
+            rows.append(self._gru_fwd_stream(d, gi, T * 3 * H, 3 * H, None, 0, Y1, 2 * H, T, dirn, hn, (2 + dirn) * H, 4 * H, st, T,
+                                             write_y=training))
+        ops.gru_seq_fwd(rows, B, H)
+        return hn
+
+    def latent(self, hn, B, eps, training, want_kl=True):
+        s, H, Z = self.spec, self.spec.H, self.spec.Z
+        mu, lvr = self.buf("mu", B, Z), self.buf("lv_raw", B, Z)
+        logvar, z = self.buf("logvar", B, Z), self.buf("z", B, Z)
+        hn_op = Operand(hn, 4 * H)
+        ops.gemm(B, Z, 4 * H, hn_op, 0, self.P("lmbda.hidden_to_mean.weight", 4 * H), 0, mu, Z,
+                 bias=self._pv("lmbda.hidden_to_mean.bias"))
+        ops.gemm(B, Z, 4 * H, hn_op, 0, self.P("lmbda.hidden_to_logvar.weight", 4 * H), 0, lvr, Z,
+                 bias=self._pv("lmbda.hidden_to_logvar.bias"))
+        losses = self.buf("losses", 8)
+        losses.zero_()
+        ops.latent_fwd(mu, lvr, eps, B, Z, s.softplus, training, logvar, z, losses[LOSS_KLSUM:] if want_kl else None)
+        return z, mu, logvar
+
+    def _decode_one(self, tag, name, dirs, steps, z, B, training, rows):
+        H, Z = self.spec.H, self.spec.Z
+        hid = self.buf(f"hid_{tag}", B, 2 * H)
+        ops.gemm(B, 2 * H, Z, Operand(z, Z), 0, self.P(f"{name}.latent_to_hidden.weight", Z), 0, hid, 2 * H,
+                 bias=self._pv(f"{name}.latent_to_hidden.bias"))
+        Y = self.buf(f"Y_{tag}", B, steps + 2, 2 * H)
+        for dirn, d in enumerate(dirs):
+            gi = self.buf(f"gi_{tag}_{dirn}", B, 3 * H)
+            ops.gemm(B, 3 * H, Z, Operand(z, Z), 0, self.P(d.w_ih, Z), 0, gi, 3 * H, bias=d.bias_gi)
+            st = self.buf(f"st_{tag}_{dirn}", ops.gru_stash_floats(B, steps, H)) if training else None
+            # hidden.view(2,B,H) (rnn_model.py:104,137): direction d, row b lives at flat offset (d*B+b)*H
+            rows.append(self._gru_fwd_stream(d, gi, 3 * H, 0, hid, dirn * B * H, Y, 2 * H, steps, dirn, None, 0, 0, st, steps))
+        return Y
+
+    def decode(self, z, B, training):
+        s, H, F, T, FS = self.spec, self.spec.H, self.spec.F, self.spec.T, self.spec.FS
+        self.repack()
+        rows = []
+        Yd = self._decode_one("dec", "decoder", self.dec, T, z, B, training, rows)
+        Yf = self._decode_one("fut", "decoder_future", self.fut, FS, z, B, training, rows) if s.future else None
+        ops.gru_seq_fwd(rows, B, H)
+        pred = self.buf("pred", B, T, F)
+        ops.gemm(B * T, F, 2 * H, Operand(Yd, 2 * H, off=2 * H, seg=T, seg_stride=(T + 2) * 2 * H), 0,
+                 self.P("decoder.hidden_to_output.weight", 2 * H), 0, pred, F, bias=self._pv("decoder.hidden_to_output.bias"))
+        fut = None
+        if s.future:
+            fut = self.buf("futp", B, FS, F)
+            ops.gemm(B * FS, F, 2 * H, Operand(Yf, 2 * H, off=2 * H, seg=FS, seg_stride=(FS + 2) * 2 * H), 0,
+                     self.P("decoder_future.hidden_to_output.weight", 2 * H), 0, fut, F,
+                     bias=self._pv("decoder_future.hidden_to_output.bias"))
+        return pred, fut
+
+    def forward(self, win, win_row, B, eps, training):
+        """Full RNN_VAE.forward (rnn_model.py:162-179).  Returns workspace views pred, fut, z, mu, logvar."""
+        s = self.spec
+        hn = self.encode(win, win_row, B, training)
+        z, mu, logvar = self.latent(hn, B, eps, training)
+        pred, fut = self.decode(z, B, training)
+        self._B = B
+        self._win, self._win_row, self._eps = win, win_row, eps
+        sh = lambda t, *shape: t[:_numel(shape)].view(*shape)
+        return (sh(pred, B, s.T, s.F), sh(fut, B, s.FS, s.F) if fut is not None else None, sh(z, B, s.Z), sh(mu, B, s.Z),
+                sh(logvar, B, s.Z))
+
+    # ------------------------------------------------------------------ loss (fused fwd + grad seeds)
+    def loss(self, B, tgt, tgt_row, fut_tgt_off, kl_weight, kloss, klmbda, bsize, mse_red="sum", mse_pred="sum", with_future=True):
+        """rnn_vae.py:124-129.  Fills losses[REC,FUT,KLSUM,KMEANS] and the gradient seeds dpred/dfut/Minv."""
+        s, T, F, FS, Z = self.spec, self.spec.T, self.spec.F, self.spec.FS, self.spec.Z
+        losses = self.buf("losses", 8)
+        dpred = self.buf("dpred", B, T, F)
+        sc = 2.0 if mse_red == "sum" else 2.0 / (B * T * F)
+        ops.mse_fwd_bwd(self.buf("pred", B, T, F), tgt, 0, tgt_row, B, T * F, sc, dpred, losses, LOSS_REC)
+        if s.future and with_future:
+            dfut = self.buf("dfut", B, FS, F)
+            sc = 2.0 if mse_pred == "sum" else 2.0 / (B * FS * F)
+            ops.mse_fwd_bwd(self.buf("futp", B, FS, F), tgt, fut_tgt_off, tgt_row, B, FS * F, sc, dfut, losses, LOSS_FUT)
+        z = self.buf("z", B, Z)
+        G = self.buf("gram", Z, Z)
+        sk = max(1, min(64, B // 256))
+        ws = self.ws.get("splitk", sk * Z * Z, self.dev) if sk > 1 else None
+        ops.gemm(Z, Z, B, Operand(z, Z), 1, Operand(z, Z), 1, G, Z, splitk=sk, ws=ws)
+        ops.nuclear(G, Z, kloss, B, klmbda, bsize, losses, LOSS_KMEANS, self.buf("Minv", Z, Z), gscale=kl_weight)
+        return losses
+
+    # ------------------------------------------------------------------ backward
+    def _gru_bwd_stream(self, d, stash, Y, y_T, dirn, dY, dy_T, dhn, dhn_off, dhn_row, dG, dh0, dh0_off, dbias, dgsum, T):
+        H = self.spec.H
+        return {GB["STASH"]: ops.addr(stash), GB["Y"]: ops.addr(Y, 2 * H + dirn * H), GB["Y_ROW"]: (y_T + 2) * 2 * H,
+                GB["Y_T"]: 2 * H, GB["WPT"]: ops.addr(d.wp_bwd),
+                GB["DY"]: ops.addr(dY, dirn * H) if dY is not None else 0, GB["DY_ROW"]: dy_T * 2 * H, GB["DY_T"]: 2 * H,
+                GB["DHN"]: ops.addr(dhn, dhn_off) if dhn is not None else 0, GB["DHN_ROW"]: dhn_row, GB["DG"]: ops.addr(dG),
+                GB["DH0"]: ops.addr(dh0, dh0_off) if dh0 is not None else 0, GB["DH0_ROW"]: H, GB["DBIAS"]: ops.addr(dbias),
+                GB["DGSUM"]: ops.addr(dgsum) if dgsum is not None else 0, GB["T"]: T, GB["REVERSE"]: dirn, GB["PAD"]: 1}
+
+    def _gru_param_grads(self, d: GruDir, dG, dbias, ntiles, B, T, Yseq, dirn, x_op, x_K, const_in=None):
+        """dW_ih, dW_hh, db_ih, db_hh of one (layer,direction) from its dG (B,T,4H) stash."""
+        H, g, t = self.spec.H, self.g, self.table
+        K = B * T
+        dG_i = Operand(dG, 4 * H)                               # [da_r | da_z | dgi_n] = cols 0..3H
+        if const_in is None:
+            self._gemm_wgrad(3 * H, x_K, K, dG_i, x_op, d.w_ih)
+        else:                                                   # time-constant input: sum_t dG first (in-kernel)
+            dgsum, z = const_in
+            self._gemm_wgrad(3 * H, x_K, B, Operand(dgsum, 3 * H), Operand(z, x_K), d.w_ih)
+        # h_{t-1} rows: padded slot t (forward dir) / t+2 (reverse dir) of the (B,T+2,2H) sequence
+        hp = Operand(Yseq, 2 * H, off=(2 * 2 * H if dirn else 0) + dirn * H, seg=T, seg_stride=(T + 2) * 2 * H)
+        self._gemm_wgrad(2 * H, H, K, dG_i, hp, d.w_hh, row_off=0)
+        self._gemm_wgrad(H, H, K, Operand(dG, 4 * H, off=3 * H), hp, d.w_hh, row_off=2 * H)
+        ob_i, ob_h = t.off(d.b_ih), t.off(d.b_hh)
+        ops.colsum(dbias, 0, ntiles, 3 * H, 4 * H, g, ob_i)
+        ops.colsum(dbias, 0, ntiles, 2 * H, 4 * H, g, ob_h)
+        ops.colsum(dbias, 3 * H, ntiles, H, 4 * H, g, ob_h + 2 * H)
+
+    def _decoder_backward(self, tag, name, dirs, steps, dpred, B, dz, first):
+        H, F, Z, t = self.spec.H, self.spec.F, self.spec.Z, self.table
+        ntiles = (B + 31) // 32
+        Y = self.buf(f"Y_{tag}", B, steps + 2, 2 * H)
+        Yrows = Operand(Y, 2 * H, off=2 * H, seg=steps, seg_stride=(steps + 2) * 2 * H)
+        dY = self.buf(f"dY_{tag}", B, steps, 2 * H)
+        wo = f"{name}.hidden_to_output.weight"
+        ops.gemm(B * steps, 2 * H, F, Operand(dpred, F), 0, self.P(wo, 2 * H), 1, dY, 2 * H)
+        self._gemm_wgrad(F, 2 * H, B * steps, Operand(dpred, F), Yrows, wo)
+        ops.colsum(dpred, 0, B * steps, F, F, self.g, t.off(f"{name}.hidden_to_output.bias"))
+        dhid = self.buf(f"dhid_{tag}", B, 2 * H)
+        rows, per = [], []
+        for dirn, d in enumerate(dirs):
+            dG = self.buf(f"dG_{tag}_{dirn}", B, steps, 4 * H)
+            dbias = self.buf(f"db_{tag}_{dirn}", ntiles, 4 * H)
+            dgsum = self.buf(f"dgs_{tag}_{dirn}", B, 3 * H)
+            st = self.buf(f"st_{tag}_{dirn}", ops.gru_stash_floats(B, steps, H))
+            rows.append(self._gru_bwd_stream(d, st, Y, steps, dirn, dY, steps, None, 0, 0, dG, dhid, dirn * B * H, dbias, dgsum, steps))
+            per.append((d, dG, dbias, dgsum))
+        return rows, per, Y, dhid
+
+    def backward(self, B, kl_weight, beta, dz_ext=None, dmu_ext=None, dlv_ext=None, use_minv=True):
+        """Backward of the whole model given the seeds left by loss() (or external ones).  Fills flat_g."""
+        s, H, F, Z, T, FS, t = self.spec, self.spec.H, self.spec.F, self.spec.Z, self.spec.T, self.spec.FS, self.table
+        ntiles = (B + 31) // 32
+        z = self.buf("z", B, Z)
+        dz = self.buf("dz", B, Z)
+        # ---- decoders (one BPTT launch for all 2 or 4 streams)
+        rows_d, per_d, Yd, dhid_d = self._decoder_backward("dec", "decoder", self.dec, T, self.buf("dpred", B, T, F), B, dz, True)
+        rows, groups = list(rows_d), [("decoder", per_d, Yd, dhid_d, T)]
+        if s.future:
+            rows_f, per_f, Yf, dhid_f = self._decoder_backward("fut", "decoder_future", self.fut, FS, self.buf("dfut", B, FS, F), B, dz, False)
+            rows += rows_f
+            groups.append(("decoder_future", per_f, Yf, dhid_f, FS))
+        ops.gru_seq_bwd(rows, B, H)
+        first = True
+        for name, per, Y, dhid, steps in groups:
+            for dirn, (d, dG, dbias, dgsum) in enumerate(per):
+                self._gru_param_grads(d, dG, dbias, ntiles, B, steps, Y, dirn, None, Z, const_in=(dgsum, z))
+                ops.gemm(B, Z, 3 * H, Operand(dgsum, 3 * H), 0, self.P(d.w_ih, Z), 1, dz, Z, accumulate=not first)
+                first = False
+            wl = f"{name}.latent_to_hidden.weight"
+            self._gemm_wgrad(2 * H, Z, B, Operand(dhid, 2 * H), Operand(z, Z), wl)
+            ops.colsum(dhid, 0, B, 2 * H, 2 * H, self.g, t.off(f"{name}.latent_to_hidden.bias"))
+            ops.gemm(B, Z, 2 * H, Operand(dhid, 2 * H), 0, self.P(wl, Z), 1, dz, Z, accumulate=True)
+        if use_minv and kl_weight != 0:
+            ops.gemm(B, Z, Z, Operand(z, Z), 0, Operand(self.buf("Minv", Z, Z), Z), 1, dz, Z, accumulate=True)
+        if dz_ext is not None:
+            ops.axpy(dz_ext, 1.0, dz, B * Z)
+        # ---- reparameterisation + KL
+        dmu, dlv = self.buf("dmu", B, Z), self.buf("dlv", B, Z)
+        ckl = beta * kl_weight / (B * Z)
+        ops.latent_bwd(dz, self.buf("mu", B, Z), self.buf("logvar", B, Z), self.buf("lv_raw", B, Z), self._eps, B, Z,
+                       s.softplus, ckl, dmu, dlv)
+        if dmu_ext is not None:
+            ops.axpy(dmu_ext, 1.0, dmu, B * Z)
+        if dlv_ext is not None:
+            ops.axpy(dlv_ext, 1.0, dlv, B * Z)
+        hn = self.buf("hn", B, 4 * H)
+        dhn = self.buf("dhn", B, 4 * H)
+        for nm, dv, first in (("lmbda.hidden_to_mean", dmu, True), ("lmbda.hidden_to_logvar", dlv, False)):
+            self._gemm_wgrad(Z, 4 * H, B, Operand(dv, Z), Operand(hn, 4 * H), nm + ".weight")
+            ops.colsum(dv, 0, B, Z, Z, self.g, t.off(nm + ".bias"))
+            ops.gemm(B, 4 * H, Z, Operand(dv, Z), 0, self.P(nm + ".weight", 4 * H), 1, dhn, 4 * H, accumulate=not first)
+        # ---- encoder layer 1
+        Y0, Y1 = self.buf("Y0", B, T + 2, 2 * H), self.buf("Y1", B, T + 2, 2 * H)
+        rows, per = [], []
+        for dirn, d in enumerate(self.enc[1]):
+            dG = self.buf(f"dG_e1_{dirn}", B, T, 4 * H)
+            dbias = self.buf(f"db_e1_{dirn}", ntiles, 4 * H)
+            st = self.buf(f"st_e1_{dirn}", ops.gru_stash_floats(B, T, H))
+            rows.append(self._gru_bwd_stream(d, st, Y1, T, dirn, None, T, dhn, (2 + dirn) * H, 4 * H, dG, None, 0, dbias, None, T))
+            per.append((d, dG, dbias))
+        ops.gru_seq_bwd(rows, B, H)
+        dY0 = self.buf("dY0", B, T, 2 * H)
+        y0rows = Operand(Y0, 2 * H, off=2 * H, seg=T, seg_stride=(T + 2) * 2 * H)
+        for dirn, (d, dG, dbias) in enumerate(per):
+            ops.gemm(B * T, 2 * H, 3 * H, Operand(dG, 4 * H), 0, self.P(d.w_ih, 2 * H), 1, dY0, 2 * H, accumulate=dirn > 0)
+            self._gru_param_grads(d, dG, dbias, ntiles, B, T, Y1, dirn, y0rows, 2 * H)
+        # ---- encoder layer 0
+        rows, per = [], []
+        for dirn, d in enumerate(self.enc[0]):
+            dG = self.buf(f"dG_e0_{dirn}", B, T, 4 * H)
+            dbias = self.buf(f"db_e0_{dirn}", ntiles, 4 * H)
+            st = self.buf(f"st_e0_{dirn}", ops.gru_stash_floats(B, T, H))
+            rows.append(self._gru_bwd_stream(d, st, Y0, T, dirn, dY0, T, dhn, dirn * H, 4 * H, dG, None, 0, dbias, None, T))
+            per.append((d, dG, dbias))
+        ops.gru_seq_bwd(rows, B, H)
+        xrows = Operand(self._win, F, seg=T, seg_stride=self._win_row)
+        for dirn, (d, dG, dbias) in enumerate(per):
+            self._gru_param_grads(d, dG, dbias, ntiles, B, T, Y0, dirn, xrows, F)
+
+
+def _numel(shape):
+    n = 1
+    for s in shape:
+        n *= s
+    return n

@@ -1,0 +1,82 @@
+"""Sliding-window batcher.
+
+Reference: vame/model/dataloader.py:18-56 (`SEQUENCE_DATASET`) + torch DataLoader collate.
+`SEQUENCE_DATASET` keeps the reference's constructor, `__len__` and `__getitem__` semantics
+(random start, index ignored, float64 (F, 2T) item) for API users.  Training uses
+`DeviceWindowLoader`: the z-scored series is resident in HBM as fp32 and a HIP gather kernel
+cuts B windows per step (out[b,t,f] = Xn[f, start_b+t]) -- bit-identical to the reference's
+per-window (x-mean)/std in float64 followed by the cast to float32 at rnn_vae.py:111-115.
+"""
+import os
+
+import numpy as np
+import torch
+from torch.utils.data.dataset import Dataset
+
+from .. import ops
+
+
+class SEQUENCE_DATASET(Dataset):
+    def __init__(self, path_to_file, data, train, temporal_window):
+        self.temporal_window = temporal_window
+        self.X = np.load(path_to_file + data)
+        if self.X.shape[0] > self.X.shape[1]:
+            self.X = self.X.T
+        self.data_points = len(self.X[0, :])
+        if train and not os.path.exists(os.path.join(path_to_file, 'seq_mean.npy')):
+            print("Compute mean and std for temporal dataset.")
+            self.mean = np.mean(self.X)
+            self.std = np.std(self.X)
+            np.save(path_to_file + 'seq_mean.npy', self.mean)
+            np.save(path_to_file + 'seq_std.npy', self.std)
+        else:
+            self.mean = np.load(path_to_file + 'seq_mean.npy')
+            self.std = np.load(path_to_file + 'seq_std.npy')
+        print('Initialize %s data. Datapoints %d' % ('train' if train else 'test', self.data_points))
+
+    def __len__(self):
+        return self.data_points
+
+    def __getitem__(self, index):
+        start = np.random.choice(self.data_points - self.temporal_window)
+        sequence = self.X[:, start:start + self.temporal_window]
+        return torch.from_numpy((sequence - self.mean) / self.std)
+
+    def normalised_f32(self):
+        """(F,N) float32 of the whole z-scored series (normalised in float64 first, like __getitem__)."""
+        return ((self.X - self.mean) / self.std).astype(np.float32)
+
+
+class DeviceWindowLoader:
+    """Iterable over floor(N / batch_size) batches of (B, L, F) fp32 device windows, L = window length kept.
+
+    Window starts come from the global numpy RNG, `np.random.randint(0, N - 2T, size=B)`, which is
+    stream-equivalent to the B scalar `np.random.choice(N - 2T)` calls the reference's DataLoader
+    makes per batch (dataloader.py:49; tests/golden/batcher.npz).  With several ranks each rank
+    draws its own disjoint slice of the same stream.
+    """
+
+    def __init__(self, dataset: SEQUENCE_DATASET, batch_size, keep, device, rank=0, world=1):
+        self.ds, self.B, self.L, self.dev = dataset, int(batch_size), int(keep), device
+        self.N, self.F = dataset.data_points, dataset.X.shape[0]
+        self.T2 = dataset.temporal_window
+        self.rank, self.world = rank, world
+        self.Xn = torch.from_numpy(dataset.normalised_f32()).to(device).contiguous()
+        self.n_batches = self.N // (self.B * world)
+
+    def __len__(self):
+        return self.n_batches
+
+    def draw_starts(self):
+        s = np.random.randint(0, self.N - self.T2, size=self.B * self.world)
+        return s[self.rank * self.B:(self.rank + 1) * self.B]
+
+    def gather(self, starts):
+        st = torch.from_numpy(np.ascontiguousarray(starts, dtype=np.int64)).to(self.dev, non_blocking=True)
+        out = torch.empty(self.B, self.L, self.F, device=self.dev)
+        ops.window_gather(self.Xn, self.N, self.F, st, 0, self.B, self.L, out)
+        return out
+
+    def __iter__(self):
+        for _ in range(self.n_batches):
+            yield self.gather(self.draw_starts())

@@ -1,0 +1,299 @@
+"""RNN-VAE model classes with the reference's names, constructor signatures and state_dict layout,
+whose forward passes run on the MI355X HIP kernels (vame_amd.engine) instead of torch.nn.GRU.
+
+Drop-in surface kept (reference: vame/model/rnn_model.py):
+  Encoder :23-45, Lambda :48-76, Decoder :79-109, Decoder_Future :112-144, RNN_VAE :147-179
+  * the same sub-module / parameter names, so `state_dict()` keys, shapes and default
+    initialisation under `torch.manual_seed` are identical and .pkl checkpoints interchange;
+  * `model.encoder(x)`, `model.lmbda(h)`, `model.decoder(ins, z)` stay callable on their own
+    (pose_segmentation.py:92-95, generative_functions.py:39).
+The torch.nn.GRU / nn.Linear objects are parameter containers only; they are never executed.
+"""
+import torch
+from torch import nn
+
+from .. import _lib, ops
+from ..engine import ParamTable, Spec, VAEEngine
+
+
+class _EngineOwner:
+    """Mixin giving sub-modules access to the RNN_VAE that owns the flat buffers + engine."""
+    _owner = None
+
+    def _eng(self):
+        if self._owner is None:
+            raise RuntimeError(f"{type(self).__name__} must be used as part of an RNN_VAE (it runs on the shared HIP engine)")
+        return self._owner[0]._ensure_engine()
+
+
+class Encoder(nn.Module, _EngineOwner):
+    def __init__(self, NUM_FEATURES, hidden_size_layer_1, hidden_size_layer_2, dropout_encoder):
+        super().__init__()
+        self.input_size, self.hidden_size, self.hidden_size_2 = NUM_FEATURES, hidden_size_layer_1, hidden_size_layer_2
+        self.n_layers, self.dropout, self.bidirectional = 2, dropout_encoder, True
+        self.encoder_rnn = nn.GRU(input_size=NUM_FEATURES, hidden_size=hidden_size_layer_1, num_layers=2, bias=True,
+                                  batch_first=True, dropout=dropout_encoder, bidirectional=True)
+        self.hidden_factor = 4
+
+    def forward(self, inputs):
+        """(B,T,F) -> (B,4H) = [l0 fwd | l0 bwd | l1 fwd | l1 bwd] final states (rnn_model.py:40-45)."""
+        eng = self._eng()
+        x = _as_f32(inputs, eng.dev)
+        B, T, F = x.shape
+        _check(T == eng.spec.T and F == eng.spec.F, f"encoder input {tuple(x.shape)} != (B,{eng.spec.T},{eng.spec.F})")
+        with torch.no_grad():
+            hn = eng.encode(x, T * F, B, training=False)
+            return hn[:B * 4 * eng.spec.H].view(B, 4 * eng.spec.H).clone()
+
+
+class Lambda(nn.Module, _EngineOwner):
+    def __init__(self, ZDIMS, hidden_size_layer_1, hidden_size_layer_2, softplus):
+        super().__init__()
+        self.hid_dim, self.latent_length, self.softplus = hidden_size_layer_1 * 4, ZDIMS, softplus
+        self.hidden_to_mean = nn.Linear(self.hid_dim, ZDIMS)
+        self.hidden_to_logvar = nn.Linear(self.hid_dim, ZDIMS)
+        if softplus == True:  # noqa: E712  (config values may be 0/1)
+            print("Using a softplus activation to ensures that the variance is parameterized as non-negative and "
+                  "activated by a smooth function")
+            self.softplus_fn = nn.Softplus()
+
+    def forward(self, hidden, eps=None):
+        """(B,4H) -> (z, mean, logvar); eval mode returns (mean, mean, logvar) (rnn_model.py:63-76)."""
+        eng = self._eng()
+        h = _as_f32(hidden, eng.dev)
+        B, Z = h.shape[0], eng.spec.Z
+        with torch.no_grad():
+            if self.training and eps is None:
+                eps = torch.randn(B, Z, device=eng.dev)
+            z, mu, lv = eng.latent(h, B, eps, self.training, want_kl=False)
+            self.mean, self.logvar = mu[:B * Z].view(B, Z).clone(), lv[:B * Z].view(B, Z).clone()
+            zz = z[:B * Z].view(B, Z).clone() if self.training else self.mean
+        return zz, self.mean, self.logvar
+
+
+class _DecoderBase(nn.Module, _EngineOwner):
+    def _run(self, inputs, z, which):
+        eng = self._eng()
+        zt = _as_f32(z, eng.dev)
+        B = zt.shape[0]
+        # `inputs` is z tiled over time by construction (rnn_model.py:169-170); the kernels read z once.
+        with torch.no_grad():
+            pred, fut = eng.decode(zt, B, training=False)
+            s = eng.spec
+            if which == "dec":
+                return pred[:B * s.T * s.F].view(B, s.T, s.F).clone()
+            return fut[:B * s.FS * s.F].view(B, s.FS, s.F).clone()
+
+
+class Decoder(_DecoderBase):
+    def __init__(self, TEMPORAL_WINDOW, ZDIMS, NUM_FEATURES, hidden_size_rec, dropout_rec):
+        super().__init__()
+        self.num_features, self.sequence_length, self.hidden_size = NUM_FEATURES, TEMPORAL_WINDOW, hidden_size_rec
+        self.latent_length, self.n_layers, self.dropout, self.bidirectional = ZDIMS, 1, dropout_rec, True
+        self.rnn_rec = nn.GRU(ZDIMS, hidden_size=hidden_size_rec, num_layers=1, bias=True, batch_first=True,
+                              dropout=dropout_rec, bidirectional=True)
+        self.hidden_factor = 2
+        self.latent_to_hidden = nn.Linear(ZDIMS, hidden_size_rec * 2)
+        self.hidden_to_output = nn.Linear(hidden_size_rec * 2, NUM_FEATURES)
+
+    def forward(self, inputs, z):
+        return self._run(inputs, z, "dec")
+
+
+class Decoder_Future(_DecoderBase):
+    def __init__(self, TEMPORAL_WINDOW, ZDIMS, NUM_FEATURES, FUTURE_STEPS, hidden_size_pred, dropout_pred):
+        super().__init__()
+        self.num_features, self.future_steps, self.sequence_length = NUM_FEATURES, FUTURE_STEPS, TEMPORAL_WINDOW
+        self.hidden_size, self.latent_length, self.n_layers = hidden_size_pred, ZDIMS, 1
+        self.dropout, self.bidirectional = dropout_pred, True
+        self.rnn_pred = nn.GRU(ZDIMS, hidden_size=hidden_size_pred, num_layers=1, bias=True, batch_first=True,
+                               dropout=dropout_pred, bidirectional=True)
+        self.hidden_factor = 2
+        self.latent_to_hidden = nn.Linear(ZDIMS, hidden_size_pred * 2)
+        self.hidden_to_output = nn.Linear(hidden_size_pred * 2, NUM_FEATURES)
+
+    def forward(self, inputs, z):
+        return self._run(inputs, z, "fut")
+
+
+def _as_f32(t, dev):
+    if not torch.is_tensor(t):
+        t = torch.as_tensor(t)
+    return t.detach().to(device=dev, dtype=torch.float32).contiguous()
+
+
+def _check(cond, msg):
+    if not cond:
+        raise ValueError(msg)
+
+
+class _VAEFunction(torch.autograd.Function):
+    """Autograd bridge for `model(x)` in training mode: HIP forward, HIP backward into the flat bucket."""
+
+    @staticmethod
+    def forward(ctx, model, x, eps, *params):
+        eng = model._ensure_engine()
+        B = x.shape[0]
+        outs = eng.forward(x, x.shape[1] * x.shape[2], B, eps, training=True)
+        ctx.model, ctx.B, ctx.x = model, B, x
+        return tuple(o.clone() if o is not None else None for o in outs)
+
+    @staticmethod
+    def backward(ctx, dpred, dfut, dz, dmu, dlv):
+        model, B = ctx.model, ctx.B
+        eng = model._ensure_engine()
+        s = eng.spec
+
+        def seed(name, g, n):
+            buf = eng.buf(name, n)
+            if g is None:
+                buf[:n].zero_()
+            else:
+                buf[:n].copy_(g.contiguous().view(-1))
+        seed("dpred", dpred, B * s.T * s.F)
+        if s.future:
+            seed("dfut", dfut, B * s.FS * s.F)
+        c = lambda g: None if g is None else g.contiguous()
+        eng.g = model._flat_gtmp
+        try:
+            eng.backward(B, 0.0, 0.0, dz_ext=c(dz), dmu_ext=c(dmu), dlv_ext=c(dlv), use_minv=False)
+        finally:
+            eng.g = model._flat_g
+        model._accumulate_tmp_grads()
+        return (None, None, None) + (None,) * len(model._param_list)
+
+
+class RNN_VAE(nn.Module):
+    def __init__(self, TEMPORAL_WINDOW, ZDIMS, NUM_FEATURES, FUTURE_DECODER, FUTURE_STEPS, hidden_size_layer_1,
+                 hidden_size_layer_2, hidden_size_rec, hidden_size_pred, dropout_encoder, dropout_rec, dropout_pred, softplus):
+        super().__init__()
+        _check(hidden_size_layer_1 == hidden_size_rec and (not FUTURE_DECODER or hidden_size_pred == hidden_size_layer_1),
+               "vame_amd: the gfx950 kernels need one hidden size for encoder, decoder and future decoder")
+        _check(not (dropout_encoder or dropout_rec or dropout_pred), "vame_amd: dropout > 0 is not supported by the HIP GRU kernels")
+        self.FUTURE_DECODER = FUTURE_DECODER
+        self.seq_len = int(TEMPORAL_WINDOW / 2)
+        self.encoder = Encoder(NUM_FEATURES, hidden_size_layer_1, hidden_size_layer_2, dropout_encoder)
+        self.lmbda = Lambda(ZDIMS, hidden_size_layer_1, hidden_size_layer_2, softplus)
+        self.decoder = Decoder(self.seq_len, ZDIMS, NUM_FEATURES, hidden_size_rec, dropout_rec)
+        if FUTURE_DECODER:
+            self.decoder_future = Decoder_Future(self.seq_len, ZDIMS, NUM_FEATURES, FUTURE_STEPS, hidden_size_pred, dropout_pred)
+        self.spec = Spec(T=self.seq_len, F=NUM_FEATURES, Z=ZDIMS, H=hidden_size_layer_1, FS=FUTURE_STEPS if FUTURE_DECODER else 0,
+                         future=bool(FUTURE_DECODER), softplus=bool(softplus))
+        for m in (self.encoder, self.lmbda, self.decoder, getattr(self, "decoder_future", None)):
+            if m is not None:
+                object.__setattr__(m, "_owner", (self,))       # tuple: not registered as a sub-module
+        self._flat_p = self._flat_g = self._flat_gtmp = None
+        self._engine = None
+        self._register_state_dict_hook(_clone_state_dict)
+
+    # ---------------------------------------------------------------- flat parameter bucket
+    def _ensure_engine(self):
+        plist = list(self.named_parameters())
+        dev = plist[0][1].device
+        if dev.type != "cuda" and not _lib.emulated():
+            raise _lib.VameHipError("vame_amd.RNN_VAE runs only on an MI355X: move the model with .cuda() (no CPU fallback)")
+        ok = self._flat_p is not None and self._flat_p.device == dev
+        if ok:
+            base, esz, tab = self._flat_p.data_ptr(), 4, self._table
+            ok = all(p.data_ptr() == base + esz * tab.off(n) for n, p in plist)
+        if not ok:
+            self._table = ParamTable([(n, p.shape) for n, p in plist])
+            flat_p = torch.zeros(self._table.numel, device=dev)
+            flat_g = torch.zeros(self._table.numel, device=dev)
+            for n, p in plist:
+                o, k = self._table.off(n), p.numel()
+                flat_p[o:o + k].copy_(p.data.detach().reshape(-1).to(torch.float32))
+                p.data = flat_p[o:o + k].view(p.shape)
+                p.grad = flat_g[o:o + k].view(p.shape)
+            self._flat_p, self._flat_g = flat_p, flat_g
+            self._flat_gtmp = torch.zeros_like(flat_g)
+            self._param_list = [p for _, p in plist]
+            self._engine = VAEEngine(self.spec, self._table, flat_p, flat_g)
+        self._engine.version += 1          # weights may have changed since the last call: repack (a few tiny kernels)
+        return self._engine
+
+    def _accumulate_tmp_grads(self):
+        for n, p in self.named_parameters():
+            o, k = self._table.off(n), p.numel()
+            gview = self._flat_g[o:o + k].view(p.shape)
+            tview = self._flat_gtmp[o:o + k].view(p.shape)
+            if p.grad is None:
+                gview.copy_(tview)
+                p.grad = gview
+            else:
+                p.grad.add_(tview)
+
+    def flat_parameters(self):
+        """(flat_p, flat_g): the contiguous fp32 parameter / gradient buckets (RCCL all-reduce + fused Adam)."""
+        self._ensure_engine()
+        return self._flat_p, self._flat_g
+
+    # ---------------------------------------------------------------- forward
+    def forward(self, seq, eps=None):
+        """rnn_model.py:162-179.  Returns (prediction, future, z, mu, logvar) or, without the
+        future decoder, (prediction, z, mu, logvar).  `eps` optionally injects the N(0,1) draw of
+        the reparameterisation (parity tests); by default it is drawn on the device."""
+        eng = self._ensure_engine()
+        s = self.spec
+        x = seq.to(device=eng.dev, dtype=torch.float32).contiguous()
+        _check(x.dim() == 3 and x.shape[1] == s.T and x.shape[2] == s.F, f"input {tuple(x.shape)} != (B,{s.T},{s.F})")
+        B = x.shape[0]
+        if self.training:
+            if eps is None:
+                eps = torch.randn(B, s.Z, device=eng.dev)
+            eps = eps.to(device=eng.dev, dtype=torch.float32).contiguous()
+        if self.training and torch.is_grad_enabled():
+            pred, fut, z, mu, lv = _VAEFunction.apply(self, x, eps, *self._param_list)
+        else:
+            with torch.no_grad():
+                outs = eng.forward(x, s.T * s.F, B, eps, training=self.training)
+                pred, fut, z, mu, lv = [o.clone() if o is not None else None for o in outs]
+            if not self.training:
+                z = mu
+        self.lmbda.mean, self.lmbda.logvar = mu, lv
+        if self.FUTURE_DECODER:
+            return pred, fut, z, mu, lv
+        return pred, z, mu, lv
+
+    # ---------------------------------------------------------------- fused training / evaluation step
+    def loss_step(self, win, kl_weight, *, beta, kloss, klmbda, bsize, mse_red="sum", mse_pred="sum", eps=None, backward=True):
+        """One fused forward + loss (+ backward) over a batch of windows, entirely on device.
+
+        win: (B, L, F) fp32 device tensor, L >= T (+FS): steps [0,T) are the encoder input and
+        reconstruction target, steps [T, T+FS) the future target (rnn_vae.py:111-112).
+        Gradients land in the flat bucket (p.grad views).  Returns a device tensor
+        [rec, fut, kl, kmeans] in the reference's units (no host sync)."""
+        eng = self._ensure_engine()
+        s = self.spec
+        B, L, F = win.shape
+        training = self.training
+        _check(F == s.F and L >= s.T + (s.FS if (training and s.future) else 0), f"window batch {tuple(win.shape)} too short")
+        if training and eps is None:
+            eps = torch.randn(B, s.Z, device=eng.dev)
+        with torch.no_grad():
+            eng.forward(win, L * F, B, eps, training)
+            # test(): no future term (rnn_vae.py:183-198)
+            losses = eng.loss(B, win, L * F, s.T * F, kl_weight, kloss, klmbda, bsize, mse_red, mse_pred,
+                              with_future=training and s.future)
+            if backward and training:
+                eng.backward(B, kl_weight, beta)
+            out = losses[:4].clone()
+            out[2] = out[2] * (-0.5 / (B * s.Z))
+            if mse_red != "sum":
+                out[0] = out[0] / (B * s.T * F)
+            if s.future and mse_pred != "sum":
+                out[1] = out[1] / (B * s.FS * F)
+        return out
+
+    def load_state_dict(self, state_dict, *a, **k):
+        r = super().load_state_dict(state_dict, *a, **k)
+        if self._engine is not None:
+            self._engine.version += 1
+        return r
+
+
+def _clone_state_dict(module, state_dict, prefix, local_metadata):
+    # parameters are views into one flat bucket; hand out independent tensors like the reference's state_dict
+    for k in list(state_dict.keys()):
+        state_dict[k] = state_dict[k].clone()
+    return state_dict

@@ -1,0 +1,356 @@
+"""Training driver of the RNN-VAE on MI355X -- drop-in for vame/model/rnn_vae.py.
+
+Kept from the reference (file:line there): the loss functions :35-60, `kl_annealing` :63-81,
+`gaussian` :84-91, the epoch loops `train` :94-164 / `test` :167-210 (including their quirks: epoch
+means divide by the last batch index, the scheduler steps on the last batch's loss), and the
+`train_model(config)` driver :213-413 (Adam-AMSGrad, ReduceLROnPlateau, best-model / snapshot rules,
+the eight loss arrays).  What changed is how a step executes: windows are gathered on the device,
+forward + loss + backward run as fused HIP kernels (RNN_VAE.loss_step), gradients are all-reduced
+with one RCCL call over the flat bucket when several ranks run, and Adam is one fused kernel.
+Loss scalars stay on the device; the host syncs once per epoch instead of four times per step.
+"""
+import os
+from pathlib import Path
+
+import numpy as np
+import torch
+import torch.distributed as dist
+from torch import nn
+from torch.optim.lr_scheduler import ReduceLROnPlateau, StepLR
+
+from .. import _lib, ops
+from ..util.auxiliary import read_config
+from .dataloader import SEQUENCE_DATASET, DeviceWindowLoader
+from .rnn_model import RNN_VAE  # noqa: F401  (evaluate.py:20 imports RNN_VAE from here)
+
+
+# ------------------------------------------------------------------------------------ losses (API)
+def reconstruction_loss(x, x_tilde, reduction):
+    return nn.functional.mse_loss(x_tilde, x, reduction=reduction)
+
+
+def future_reconstruction_loss(x, x_tilde, reduction):
+    return nn.functional.mse_loss(x_tilde, x, reduction=reduction)
+
+
+class _NuclearNorm(torch.autograd.Function):
+    """lmbda * sum_k sqrt(eig_k(latent^T latent / batch_size)) on the (Z,Z) Gram -- equal to the
+    reference's (B,B) SVD form (rnn_vae.py:45-50) at O(B Z^2) instead of O(B^3)."""
+
+    @staticmethod
+    def forward(ctx, latent, kloss, lmbda, batch_size):
+        lat = latent.detach().to(torch.float32).contiguous()
+        B, Z = lat.shape
+        dev = lat.device
+        G, Minv, loss = torch.empty(Z, Z, device=dev), torch.empty(Z, Z, device=dev), torch.zeros(1, device=dev)
+        sk = max(1, min(64, B // 256))
+        ws = torch.empty(sk * Z * Z, device=dev) if sk > 1 else None
+        ops.gemm(Z, Z, B, ops.Operand(lat, Z), 1, ops.Operand(lat, Z), 1, G, Z, splitk=sk, ws=ws)
+        ops.nuclear(G, Z, int(kloss), B, float(lmbda), float(batch_size), loss, 0, Minv)
+        ctx.save_for_backward(lat, Minv)
+        return loss[0].clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        lat, Minv = ctx.saved_tensors
+        B, Z = lat.shape
+        d = torch.empty(B, Z, device=lat.device)
+        ops.gemm(B, Z, Z, ops.Operand(lat, Z), 0, ops.Operand(Minv, Z), 1, d, Z)
+        return d * g, None, None, None
+
+
+def cluster_loss(H, kloss, lmbda, batch_size):
+    """H = latent.T (Z,B) as in the reference's call sites (rnn_vae.py:126,137,190,197)."""
+    return _NuclearNorm.apply(H.T, kloss, lmbda, batch_size)
+
+
+def kullback_leibler_loss(mu, logvar):
+    return -0.5 * torch.mean(1 + logvar - mu.pow(2) - logvar.exp())
+
+
+def kl_annealing(epoch, kl_start, annealtime, function):
+    if epoch > kl_start:
+        if function == 'linear':
+            new_weight = min(1, (epoch - kl_start) / (annealtime))
+        elif function == 'sigmoid':
+            new_weight = float(1 / (1 + np.exp(-0.9 * (epoch - annealtime))))
+        else:
+            raise NotImplementedError('currently only "linear" and "sigmoid" are implemented')
+        return new_weight
+    return 0
+
+
+def gaussian(ins, is_training, seq_len, std_n=0.8):
+    """Optional input noise (cfg['noise'], off by default): ins + N(0,1) * 0.8 * std over time."""
+    if is_training:
+        emp_std = ins.std(1, keepdim=True) * std_n
+        return ins + torch.randn_like(ins) * emp_std
+    return ins
+
+
+# ------------------------------------------------------------------------------------ optimizer
+class FusedAdamAMSGrad(torch.optim.Optimizer):
+    """torch.optim.Adam(amsgrad=True) semantics (rnn_vae.py:332) as ONE kernel over the model's flat
+    parameter bucket; exposes param_groups so torch LR schedulers drive it unchanged."""
+
+    def __init__(self, model, lr):
+        super().__init__(list(model.parameters()), dict(lr=lr, betas=(0.9, 0.999), eps=1e-8))
+        self.model = model
+        self.flat_p, self.flat_g = model.flat_parameters()
+        self.m = torch.zeros_like(self.flat_p)
+        self.v = torch.zeros_like(self.flat_p)
+        self.vmax = torch.zeros_like(self.flat_p)
+        self.t = 0
+
+    @torch.no_grad()
+    def step(self, closure=None, gscale=1.0):
+        flat_p, flat_g = self.model.flat_parameters()
+        if flat_p is not self.flat_p:
+            raise RuntimeError("the model was moved after the optimizer was built")
+        self.t += 1
+        g = self.param_groups[0]
+        ops.adam_amsgrad(flat_p, flat_g, self.m, self.v, self.vmax, flat_p.numel(), g["lr"], self.t, gscale=gscale,
+                         beta1=g["betas"][0], beta2=g["betas"][1], eps=g["eps"])
+
+    def zero_grad(self, set_to_none=False):
+        pass  # every backward overwrites the whole bucket
+
+
+def _world():
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size()
+    return 0, 1
+
+
+def allreduce_gradients(model):
+    """One RCCL all-reduce (SUM) of the flat fp32 gradient bucket over xGMI; the 1/world factor is folded
+    into the Adam kernel.  2,618,476 floats = 10.5 MB at the default model size."""
+    _, world = _world()
+    if world > 1:
+        dist.all_reduce(model.flat_parameters()[1], op=dist.ReduceOp.SUM)
+    return 1.0 / world
+
+
+# ------------------------------------------------------------------------------------ epoch loops
+def _to_windows(item, keep, dev):
+    """Accept either device windows (B,L,F) from DeviceWindowLoader or the reference loader's (B,F,2T) items."""
+    if item.dim() == 3 and item.is_floating_point() and item.dtype == torch.float32 and item.device.type == dev.type:
+        return item
+    return item.permute(0, 2, 1)[:, :keep, :].to(dtype=torch.float32).to(dev).contiguous()
+
+
+def train(train_loader, epoch, model, optimizer, anneal_function, BETA, kl_start, annealtime, seq_len, future_decoder,
+          future_steps, scheduler, mse_red, mse_pred, kloss, klmbda, bsize, noise):
+    model.train()
+    dev = model.flat_parameters()[0].device
+    seq_len_half = int(seq_len / 2)
+    keep = seq_len_half + (future_steps if future_decoder else 0)
+    kl_weight = kl_annealing(epoch, kl_start, annealtime, anneal_function)
+    acc = torch.zeros(5, device=dev, dtype=torch.float64)     # total, rec, fut, kl, kmeans (summed over batches)
+    last = None
+    idx = -1
+    for idx, data_item in enumerate(train_loader):
+        win = _to_windows(data_item, keep, dev)
+        if noise == True:  # noqa: E712
+            enc_in = gaussian(win[:, :seq_len_half, :], True, seq_len_half)
+            raise NotImplementedError("vame_amd: cfg['noise']=True needs separate encoder input and target buffers")
+        terms = model.loss_step(win, kl_weight, beta=BETA, kloss=kloss, klmbda=klmbda, bsize=bsize, mse_red=mse_red,
+                                mse_pred=mse_pred)
+        gscale = allreduce_gradients(model)
+        optimizer.step(gscale=gscale) if isinstance(optimizer, FusedAdamAMSGrad) else optimizer.step()
+        total = terms[0] + terms[1] + BETA * kl_weight * terms[2] + kl_weight * terms[3]
+        acc += torch.stack([total, terms[0], terms[1], terms[2], terms[3]]).to(torch.float64)
+        last = total
+    if idx < 1:
+        raise ValueError("train(): need at least 2 batches per epoch (the reference divides by the last batch index, "
+                         "rnn_vae.py:158,164); lower batch_size or provide more data")
+    scheduler.step(last.item())
+    train_loss, mse_loss, fut_loss, kullback_loss, kmeans_losses = [float(v) for v in acc.cpu()]
+    if future_decoder:
+        print('Train loss: {:.3f}, MSE-Loss: {:.3f}, MSE-Future-Loss {:.3f}, KL-Loss: {:.3f}, Kmeans-Loss: {:.3f}, weight: {:.2f}'.format(
+            train_loss / idx, mse_loss / idx, fut_loss / idx, BETA * kl_weight * kullback_loss / idx, kl_weight * kmeans_losses / idx, kl_weight))
+    else:
+        print('Train loss: {:.3f}, MSE-Loss: {:.3f}, KL-Loss: {:.3f}, Kmeans-Loss: {:.3f}, weight: {:.2f}'.format(
+            train_loss / idx, mse_loss / idx, BETA * kl_weight * kullback_loss / idx, kl_weight * kmeans_losses / idx, kl_weight))
+    return kl_weight, train_loss / idx, kl_weight * kmeans_losses / idx, kullback_loss / idx, mse_loss / idx, fut_loss / idx
+
+
+def test(test_loader, epoch, model, optimizer, BETA, kl_weight, seq_len, mse_red, kloss, klmbda, future_decoder, bsize):
+    model.eval()
+    dev = model.flat_parameters()[0].device
+    seq_len_half = int(seq_len / 2)
+    acc = torch.zeros(4, device=dev, dtype=torch.float64)
+    idx = -1
+    with torch.no_grad():
+        for idx, data_item in enumerate(test_loader):
+            win = _to_windows(data_item, seq_len_half, dev)
+            terms = model.loss_step(win, kl_weight, beta=BETA, kloss=kloss, klmbda=klmbda, bsize=bsize, mse_red=mse_red,
+                                    backward=False)
+            total = terms[0] + BETA * kl_weight * terms[2] + kl_weight * terms[3]
+            acc += torch.stack([total, terms[0], terms[2], terms[3]]).to(torch.float64)
+    if idx < 1:
+        raise ValueError("test(): need at least 2 test batches of batch_size/4 (rnn_vae.py:207-210 divides by the last index)")
+    test_loss, mse_loss, kullback_loss, kmeans_losses = [float(v) for v in acc.cpu()]
+    print('Test loss: {:.3f}, MSE-Loss: {:.3f}, KL-Loss: {:.3f}, Kmeans-Loss: {:.3f}'.format(
+        test_loss / idx, mse_loss / idx, BETA * kl_weight * kullback_loss / idx, kl_weight * kmeans_losses / idx))
+    return mse_loss / idx, test_loss / idx, kl_weight * kmeans_losses
+
+
+# ------------------------------------------------------------------------------------ driver
+def _maybe_init_distributed():
+    """One process per GPU under torchrun (RANK/WORLD_SIZE/LOCAL_RANK in the env): RCCL over xGMI."""
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1 and not dist.is_initialized():
+        local = int(os.environ.get("LOCAL_RANK", "0"))
+        if torch.cuda.is_available():
+            torch.cuda.set_device(local)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group("gloo")
+    return _world()
+
+
+def train_model(config):
+    config_file = Path(config).resolve()
+    cfg = read_config(config_file)
+    legacy = cfg['legacy']
+    model_name = cfg['model_name']
+    pretrained_weights = cfg['pretrained_weights']
+    pretrained_model = cfg['pretrained_model']
+    fixed = cfg['egocentric_data']
+    if legacy:
+        raise NotImplementedError("vame_amd: RNN_VAE_LEGACY is outside the MI355X hot path (SURVEY.md row 1b)")
+    rank, world = _maybe_init_distributed()
+    is_main = rank == 0
+
+    print("Train Variational Autoencoder - model name: %s \n" % model_name)
+    pp = cfg['project_path']
+    if is_main and not os.path.exists(os.path.join(pp, 'model', 'best_model', "")):
+        os.makedirs(os.path.join(pp, 'model', 'best_model', 'snapshots', ""), exist_ok=True)
+        os.makedirs(os.path.join(pp, 'model', 'model_losses', ""), exist_ok=True)
+
+    if not torch.cuda.is_available() and not _lib.emulated():
+        raise _lib.VameHipError("vame_amd.train_model needs an MI355X (torch.cuda.is_available() is False); there is no CPU path")
+    dev = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cpu")
+    if dev.type == "cuda":
+        print("Using HIP device:", torch.cuda.get_device_name(dev), "| ranks:", world)
+
+    SEED = 19
+    TRAIN_BATCH_SIZE = cfg['batch_size']
+    TEST_BATCH_SIZE = int(cfg['batch_size'] / 4)
+    EPOCHS = cfg['max_epochs']
+    ZDIMS = cfg['zdims']
+    BETA = cfg['beta']
+    SNAPSHOT = cfg['model_snapshot']
+    LEARNING_RATE = cfg['learning_rate']
+    NUM_FEATURES = cfg['num_features']
+    if fixed == False:  # noqa: E712
+        NUM_FEATURES = NUM_FEATURES - 2
+    TEMPORAL_WINDOW = cfg['time_window'] * 2
+    FUTURE_DECODER = cfg['prediction_decoder']
+    FUTURE_STEPS = cfg['prediction_steps']
+    noise = cfg['noise']
+    scheduler_step_size = cfg['scheduler_step_size']
+    MSE_REC_REDUCTION = cfg['mse_reconstruction_reduction']
+    MSE_PRED_REDUCTION = cfg['mse_prediction_reduction']
+    KMEANS_LOSS = cfg['kmeans_loss']
+    KMEANS_LAMBDA = cfg['kmeans_lambda']
+    KL_START = cfg['kl_start']
+    ANNEALTIME = cfg['annealtime']
+    anneal_function = cfg['anneal_function']
+    optimizer_scheduler = cfg['scheduler']
+
+    BEST_LOSS = 999999
+    convergence = 0
+    print('Latent Dimensions: %d, Time window: %d, Batch Size: %d, Beta: %d, lr: %.4f\n' % (
+        ZDIMS, cfg['time_window'], TRAIN_BATCH_SIZE, BETA, LEARNING_RATE))
+    train_losses, test_losses, kmeans_losses, kl_losses, weight_values, mse_losses, fut_losses = [], [], [], [], [], [], []
+
+    torch.manual_seed(SEED)
+    if dev.type == "cuda":
+        torch.cuda.manual_seed(SEED)
+    model = RNN_VAE(TEMPORAL_WINDOW, ZDIMS, NUM_FEATURES, FUTURE_DECODER, FUTURE_STEPS, cfg['hidden_size_layer_1'],
+                    cfg['hidden_size_layer_2'], cfg['hidden_size_rec'], cfg['hidden_size_pred'], cfg['dropout_encoder'],
+                    cfg['dropout_rec'], cfg['dropout_pred'], cfg['softplus']).to(dev)
+
+    if pretrained_weights:
+        cand = os.path.join(pp, 'model', 'best_model', pretrained_model + '_' + cfg['Project'] + '.pkl')
+        loaded = False
+        for path in (cand, pretrained_model):
+            try:
+                print("Loading pretrained weights from %s\n" % path)
+                model.load_state_dict(torch.load(path, map_location=dev))
+                KL_START, ANNEALTIME, loaded = 0, 1, True
+                break
+            except (FileNotFoundError, IsADirectoryError, RuntimeError, OSError) as e:
+                print("No usable file at %s (%s)\n" % (path, type(e).__name__))
+        if not loaded:
+            print("Could not load pretrained model. Check file path in config.yaml.")
+
+    data_dir = os.path.join(pp, "data", "train", "")
+    if world > 1 and not is_main:
+        dist.barrier()                      # let rank 0 create seq_mean/std first
+    trainset = SEQUENCE_DATASET(data_dir, data='train_seq.npy', train=True, temporal_window=TEMPORAL_WINDOW)
+    if world > 1 and is_main:
+        dist.barrier()
+    testset = SEQUENCE_DATASET(data_dir, data='test_seq.npy', train=False, temporal_window=TEMPORAL_WINDOW)
+    keep = TEMPORAL_WINDOW // 2 + (FUTURE_STEPS if FUTURE_DECODER else 0)
+    train_loader = DeviceWindowLoader(trainset, TRAIN_BATCH_SIZE, keep, dev, rank, world)
+    test_loader = DeviceWindowLoader(testset, TEST_BATCH_SIZE, TEMPORAL_WINDOW // 2, dev, 0, 1)
+
+    optimizer = FusedAdamAMSGrad(model, lr=LEARNING_RATE)
+    if optimizer_scheduler:
+        print('Scheduler step size: %d, Scheduler gamma: %.2f\n' % (scheduler_step_size, cfg['scheduler_gamma']))
+        scheduler = ReduceLROnPlateau(optimizer, 'min', factor=cfg['scheduler_gamma'], patience=cfg['scheduler_step_size'],
+                                      threshold=1e-3, threshold_mode='rel')
+    else:
+        scheduler = StepLR(optimizer, step_size=scheduler_step_size, gamma=1, last_epoch=-1)
+
+    print("Start training... ")
+    best_dir = os.path.join(pp, "model", "best_model")
+    loss_dir = os.path.join(pp, 'model', 'model_losses')
+    for epoch in range(1, EPOCHS):
+        print("Epoch: %d" % epoch)
+        weight, train_loss, km_loss, kl_loss, mse_loss, fut_loss = train(
+            train_loader, epoch, model, optimizer, anneal_function, BETA, KL_START, ANNEALTIME, TEMPORAL_WINDOW, FUTURE_DECODER,
+            FUTURE_STEPS, scheduler, MSE_REC_REDUCTION, MSE_PRED_REDUCTION, KMEANS_LOSS, KMEANS_LAMBDA, TRAIN_BATCH_SIZE, noise)
+        current_loss, test_loss, test_list = test(test_loader, epoch, model, optimizer, BETA, weight, TEMPORAL_WINDOW,
+                                                  MSE_REC_REDUCTION, KMEANS_LOSS, KMEANS_LAMBDA, FUTURE_DECODER, TEST_BATCH_SIZE)
+        train_losses.append(train_loss); test_losses.append(test_loss); kmeans_losses.append(km_loss)
+        kl_losses.append(kl_loss); weight_values.append(weight); mse_losses.append(mse_loss); fut_losses.append(fut_loss)
+
+        if weight > 0.99 and current_loss <= BEST_LOSS:
+            BEST_LOSS = current_loss
+            print("Saving model!")
+            if is_main:
+                torch.save(model.state_dict(), os.path.join(best_dir, model_name + '_' + cfg['Project'] + '.pkl'))
+            convergence = 0
+        else:
+            convergence += 1
+
+        if epoch % SNAPSHOT == 0 and is_main:
+            print("Saving model snapshot!\n")
+            torch.save(model.state_dict(), os.path.join(best_dir, 'snapshots', model_name + '_' + cfg['Project'] + '_epoch_' + str(epoch) + '.pkl'))
+
+        if convergence > cfg['model_convergence']:
+            print('Finished training...')
+            print('Model converged. Please check your model with vame.evaluate_model(). \n'
+                  'You can also re-run vame.trainmodel() to further improve your model. \n'
+                  'Make sure to set _pretrained_weights_ in your config.yaml to "true" \n'
+                  'and plug your current model name into _pretrained_model_. \n'
+                  'Hint: Set "model_convergence" in your config.yaml to a higher value. \n\n'
+                  'Next: \nUse vame.pose_segmentation() to identify behavioral motifs in your dataset!')
+            break
+
+        if is_main:
+            for nm, arr in (('train_losses_', train_losses), ('test_losses_', test_losses), ('kmeans_losses_', kmeans_losses),
+                            ('kl_losses_', kl_losses), ('weight_values_', weight_values), ('mse_train_losses_', mse_losses),
+                            ('mse_test_losses_', current_loss), ('fut_losses_', fut_losses)):
+                np.save(os.path.join(loss_dir, nm + model_name), arr)
+        print("\n")
+
+    if convergence < cfg['model_convergence']:
+        print('Finished training...')
+        print('Model seems to have not reached convergence. You may want to check your model \n'
+              'with vame.evaluate_model(). If your satisfied you can continue. \n'
+              'Use vame.pose_segmentation() to identify behavioral motifs! \n'
+              'OPTIONAL: You can re-run vame.train_model() to improve performance.')

@@ -102,9 +102,9 @@ def mse_fwd_bwd(pred, target, tgt_off, tgt_row, B, TF, gscale, dpred, loss_out, 
     _lib.check(rc, "vame_mse_fwd_bwd_f32")
 
 
-def nuclear(G, Z, kloss, nrows, lmbda, bsize, loss_out, loss_off, Minv):
-    rc = _lib.lib().vame_nuclear_f32(_ptr(G), Z, kloss, nrows, float(lmbda), float(bsize), _ptr(loss_out, loss_off),
-                                     _ptr(Minv), _stream())
+def nuclear(G, Z, kloss, nrows, lmbda, bsize, loss_out, loss_off, Minv, gscale=1.0):
+    rc = _lib.lib().vame_nuclear_f32(_ptr(G), Z, kloss, nrows, float(lmbda), float(bsize), float(gscale),
+                                     _ptr(loss_out, loss_off), _ptr(Minv), _stream())
     _lib.check(rc, "vame_nuclear_f32")
 
 
