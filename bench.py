@@ -103,6 +103,28 @@ def profile_kernels(model, loader, steps=3):
     return agg
 
 
+def cpu_baseline():
+    """Reference-equivalent torch-CPU train step (oracle/torch_ref.py) on this box's host cores, in a
+    subprocess with a hard time limit (a bounded sample: <= 12 steps of B=256 or 25 s)."""
+    import subprocess
+    avail = len(os.sched_getaffinity(0))
+    code = ("import json,sys; sys.path.insert(0, %r); from oracle.torch_ref import time_train_steps; "
+            "print('CPUBASE ' + json.dumps(time_train_steps(B=256, steps=12, warmup=2, threads=int(sys.argv[1]))))" % ROOT)
+    for threads in (min(avail, 64), 8):
+        try:
+            r = subprocess.run([sys.executable, "-c", code, str(threads)], capture_output=True, text=True, timeout=150)
+            for line in r.stdout.splitlines():
+                if line.startswith("CPUBASE "):
+                    d = json.loads(line[8:])
+                    d["value"] = round(d["value"], 1)
+                    d["host_cpus_visible"] = avail
+                    return d
+            print("cpu baseline failed:", r.stderr[-500:], file=sys.stderr)
+        except subprocess.TimeoutExpired:
+            print(f"cpu baseline with {threads} threads exceeded 150 s", file=sys.stderr)
+    return dict(value=None, unit="windows/s", cores=0, kind="port", sample="timed out on this host")
+
+
 def main():
     global B_LOCAL
     ap = argparse.ArgumentParser()
@@ -199,9 +221,7 @@ def main():
                                parallelism=f"dp{world}", last_loss_terms=last),
                    roofline=roof)
         if not args.no_cpu_baseline and world == 1:
-            from oracle.torch_ref import time_train_steps
-            out["cpu_baseline"] = time_train_steps(B=256, steps=12, warmup=2)
-            out["cpu_baseline"]["value"] = round(out["cpu_baseline"]["value"], 1)
+            out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out))
     if world > 1:
         dist.barrier()

@@ -110,8 +110,10 @@ int vame_mse_fwd_bwd_f32(const float* pred, const float* target, int64_t tgt_row
 int vame_nuclear_f32(const float* G, int Z, int kloss, int nrows, float lmbda, float bsize, float gscale,
                      float* loss_out, float* Minv, void* stream);
 
-/* out[c] (+)= sum_r in[r*ld + c] */
-int vame_colsum_f32(const float* in, int64_t R, int C, int64_t ld, float* out, int accumulate, void* stream);
+/* out[c] (+)= sum_r in[r*ld + c]  (bias gradients: column sums of dG / dpred / dmu).  Deterministic
+ * two-pass reduction; ws must hold vame_colsum_ws_floats(R, C) floats. */
+int64_t vame_colsum_ws_floats(int64_t R, int C);
+int vame_colsum_f32(const float* in, int64_t R, int C, int64_t ld, float* out, int accumulate, float* ws, void* stream);
 
 /* Fused Adam with AMSGrad over a flat parameter buffer (torch.optim.Adam(amsgrad=True), rnn_vae.py:332,143).
  * gscale multiplies the gradient first (1/world_size after an all-reduce SUM). */

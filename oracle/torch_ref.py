@@ -78,11 +78,12 @@ def reference_loss(out, x, xfut, kl_weight, beta=1.0, kloss=30, klmbda=0.1, bsiz
     return rec + fl + beta * kl_weight * kl + kl_weight * km, (rec, fl, kl, km)
 
 
-def time_train_steps(B=256, steps=10, warmup=3, threads=None, seed=19):
-    """CPU baseline: windows/s of fwd + loss (incl. the (B,B) SVD) + bwd + Adam-AMSGrad at the default config."""
+def time_train_steps(B=256, steps=10, warmup=3, threads=None, seed=19, budget_s=25.0):
+    """CPU baseline: windows/s of fwd + loss (incl. the (B,B) SVD) + bwd + Adam-AMSGrad at the default config.
+    Bounded: stops after `steps` timed steps or `budget_s` seconds of timed work, whichever comes first."""
     import os
     import time
-    threads = threads or os.cpu_count()
+    threads = threads or len(os.sched_getaffinity(0))
     torch.set_num_threads(threads)
     torch.manual_seed(seed)
     m = TorchRef()
@@ -91,7 +92,7 @@ def time_train_steps(B=256, steps=10, warmup=3, threads=None, seed=19):
     g = torch.Generator().manual_seed(0)
     x = torch.randn(B, 30, 24, generator=g)
     xf = torch.randn(B, 15, 24, generator=g)
-    t0 = None
+    t0, done = None, 0
     for i in range(warmup + steps):
         if i == warmup:
             t0 = time.perf_counter()
@@ -99,7 +100,12 @@ def time_train_steps(B=256, steps=10, warmup=3, threads=None, seed=19):
         opt.zero_grad()
         loss.backward()
         opt.step()
+        if t0 is not None:
+            done += 1
+            if time.perf_counter() - t0 > budget_s:
+                break
     dt = time.perf_counter() - t0
+    steps = done
     return dict(value=B * steps / dt, unit="windows/s", cores=threads, kind="port",
                 sample=f"{steps} train steps of B={B} (T=30,F=24,H=256,Z=30,FS=15, fp32, torch {torch.__version__} CPU nn.GRU + (B,B) svd "
                        f"+ Adam-amsgrad), {dt:.1f} s")

@@ -152,20 +152,51 @@ extern "C" int vame_mse_fwd_bwd_f32(const float* pred, const float* target, int6
 }
 
 // --------------------------------------------------------------------------------- column sums
-__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ in, int64_t R, int C, int64_t ld,
-                                                     float* __restrict__ out, int accumulate) {
+// out[c] (+)= sum_r in[r*ld + c].  Row slabs are reduced by a 64-column x 4-row-lane workgroup each
+// (coalesced 256 B row segments), slab partials land in `ws` and a second tiny pass adds them in a fixed
+// order (deterministic, no float atomics).
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __restrict__ in, int64_t R, int C, int64_t ld,
+                                                             int64_t rows_per_slab, float* __restrict__ part) {
+    __shared__ float red[4][64];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + tx;
+    const int64_t lo = (int64_t)blockIdx.y * rows_per_slab;
+    const int64_t hi = lo + rows_per_slab < R ? lo + rows_per_slab : R;
+    float s0 = 0.f, s1 = 0.f;
+    if (c < C) {
+        int64_t r = lo + ty;
+        for (; r + 4 < hi; r += 8) { s0 += in[r * ld + c]; s1 += in[(r + 4) * ld + c]; }
+        if (r < hi) s0 += in[r * ld + c];
+    }
+    red[ty][tx] = s0 + s1;
+    __syncthreads();
+    if (ty == 0 && c < C) part[(int64_t)blockIdx.y * C + c] = red[0][tx] + red[1][tx] + red[2][tx] + red[3][tx];
+}
+__global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restrict__ part, int nslabs, int C,
+                                                           float* __restrict__ out, int accumulate) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
     float s = 0.f;
-    for (int64_t r = 0; r < R; ++r) s += in[r * ld + c];
+    for (int i = 0; i < nslabs; ++i) s += part[(int64_t)i * C + c];
     out[c] = accumulate ? out[c] + s : s;
 }
 
-extern "C" int vame_colsum_f32(const float* in, int64_t R, int C, int64_t ld, float* out, int accumulate, void* stream) {
-    VAME_CHECK_ARG(in && out && R >= 1 && C >= 1, VAME_E_BADARG, "colsum: bad argument");
-    hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)cdiv64(C, 256)), dim3(256), 0, (hipStream_t)stream, in, R, C, ld, out,
-                       accumulate);
-    VAME_LAUNCH_CHECK("colsum");
+extern "C" int64_t vame_colsum_ws_floats(int64_t R, int C) {
+    const int64_t nslabs = R <= 64 ? 1 : (cdiv64(R, 64) < 512 ? cdiv64(R, 64) : 512);
+    return nslabs * C;
+}
+
+extern "C" int vame_colsum_f32(const float* in, int64_t R, int C, int64_t ld, float* out, int accumulate, float* ws,
+                               void* stream) {
+    VAME_CHECK_ARG(in && out && ws && R >= 1 && C >= 1, VAME_E_BADARG, "colsum: bad argument");
+    const int64_t nslabs = vame_colsum_ws_floats(R, C) / C;
+    const int64_t rps = cdiv64(R, nslabs);
+    hipLaunchKernelGGL(colsum_partial_kernel, dim3((unsigned)cdiv64(C, 64), (unsigned)nslabs), dim3(256), 0,
+                       (hipStream_t)stream, in, R, C, ld, rps, ws);
+    VAME_LAUNCH_CHECK("colsum partial");
+    hipLaunchKernelGGL(colsum_final_kernel, dim3((unsigned)cdiv64(C, 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const float*)ws, (int)nslabs, C, out, accumulate);
+    VAME_LAUNCH_CHECK("colsum final");
     return VAME_OK;
 }
 

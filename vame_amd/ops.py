@@ -108,8 +108,15 @@ def nuclear(G, Z, kloss, nrows, lmbda, bsize, loss_out, loss_off, Minv, gscale=1
     _lib.check(rc, "vame_nuclear_f32")
 
 
+_colsum_ws = {}
+
+
 def colsum(inp, in_off, R, C, ld, out, out_off=0, accumulate=False):
-    rc = _lib.lib().vame_colsum_f32(_ptr(inp, in_off), R, C, ld, _ptr(out, out_off), int(accumulate), _stream())
+    need = int(_lib.lib().vame_colsum_ws_floats(R, C))
+    ws = _colsum_ws.get(inp.device)
+    if ws is None or ws.numel() < need:
+        ws = _colsum_ws[inp.device] = torch.empty(max(need, 1 << 16), device=inp.device)
+    rc = _lib.lib().vame_colsum_f32(_ptr(inp, in_off), R, C, ld, _ptr(out, out_off), int(accumulate), _ptr(ws), _stream())
     _lib.check(rc, "vame_colsum_f32")
 
 
