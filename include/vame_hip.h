@@ -71,7 +71,7 @@ int64_t vame_gru_stash_floats(int B, int T, int H);
 int vame_gru_seq_fwd_f32(const int64_t* desc, int nstreams, int B, int H, void* stream);
 
 /* GRU sequence backward (BPTT) for the same streams.  Writes dG (B,T,4H) = [da_r|da_z|dgi_n|dgh_n]
- * for the weight-gradient GEMMs, per-tile bias-gradient partials, optional dh0 and sum_t dG. */
+ * for the weight-gradient GEMMs, per-tile bias-gradient partials and optional dh0. */
 enum vame_gru_bwd_field {
     GB_STASH = 0, GB_Y, GB_Y_ROW, GB_Y_T,   /* forward stash and h sequence */
     GB_H0, GB_H0_ROW,
@@ -81,7 +81,7 @@ enum vame_gru_bwd_field {
     GB_DG,                                  /* out (B,T,4H) contiguous */
     GB_DH0, GB_DH0_ROW,                     /* out grad wrt initial state (0 = none) */
     GB_DBIAS,                               /* out (ntiles,4H) per-tile column sums of dG over rows and time */
-    GB_DGSUM,                               /* out (B,3H) sum over time of [da_r|da_z|dgi_n] (0 = none) */
+    GB_RESERVED,
     GB_T, GB_REVERSE, GB_PAD,
     VAME_GRU_BWD_FIELDS
 };
@@ -109,6 +109,10 @@ int vame_mse_fwd_bwd_f32(const float* pred, const float* target, int64_t tgt_row
  * cyclic Jacobi in fp64. */
 int vame_nuclear_f32(const float* G, int Z, int kloss, int nrows, float lmbda, float bsize, float gscale,
                      float* loss_out, float* Minv, void* stream);
+
+/* out[b,c] = sum_t in[(b*T+t)*ld + c], c < C (C % 4 == 0): sum over time of a (B,T,ld) sequence -- the
+ * gradient wrt the time-constant decoder input z (vame/model/rnn_model.py:169-170). */
+int vame_timesum_f32(const float* in, int B, int T, int C, int64_t ld, float* out, void* stream);
 
 /* out[c] (+)= sum_r in[r*ld + c]  (bias gradients: column sums of dG / dpred / dmu).  Deterministic
  * two-pass reduction; ws must hold vame_colsum_ws_floats(R, C) floats. */

@@ -123,10 +123,12 @@ def check_gru_bwd(dev, H, B, T):
         rows.append({GB["STASH"]: ops.addr(s["stash"]), GB["Y"]: ops.addr(Y, 2 * H + d * H), GB["Y_ROW"]: (T + 2) * 2 * H,
                      GB["Y_T"]: 2 * H, GB["WPT"]: ops.addr(s["wpb"]), GB["DY"]: ops.addr(dYt, d * H), GB["DY_ROW"]: T * 2 * H,
                      GB["DY_T"]: 2 * H, GB["DHN"]: ops.addr(dhNt, d * H), GB["DHN_ROW"]: 2 * H, GB["DG"]: ops.addr(dG),
-                     GB["DH0"]: ops.addr(dh0), GB["DH0_ROW"]: H, GB["DBIAS"]: ops.addr(dbias), GB["DGSUM"]: ops.addr(dgsum),
+                     GB["DH0"]: ops.addr(dh0), GB["DH0_ROW"]: H, GB["DBIAS"]: ops.addr(dbias),
                      GB["T"]: T, GB["REVERSE"]: d, GB["PAD"]: 1})
         outs.append((dG, dh0, dbias, dgsum))
     ops.gru_seq_bwd(rows, B, H)
+    for dG, _, _, dgsum in outs:
+        ops.timesum(dG, B, T, 3 * H, 4 * H, dgsum)
     for d, s in enumerate(st):
         _, _, cache = vo.gru_dir_forward(x, s["h0"], s["W_ih"], s["W_hh"], s["b_ih"], s["b_hh"], reverse=bool(d))
         dx, dh0, dWi, dWh, dbi, dbh = vo.gru_dir_backward(x, cache, np.ascontiguousarray(dY[:, :, d * H:(d + 1) * H]),

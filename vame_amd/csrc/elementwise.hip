@@ -200,6 +200,33 @@ extern "C" int vame_colsum_f32(const float* in, int64_t R, int C, int64_t ld, fl
     return VAME_OK;
 }
 
+// --------------------------------------------------------------------------------- sum over time
+__global__ __launch_bounds__(256) void timesum_kernel(const float* __restrict__ in, int B, int T, int C4, int64_t ld,
+                                                      float* __restrict__ out) {
+    const int64_t n = (int64_t)B * C4;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t b = i / C4;
+        const int c = (int)(i % C4) * 4;
+        const float* p = in + b * T * ld + c;
+        float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int t = 0; t < T; ++t) {
+            const float4 v = *reinterpret_cast<const float4*>(p + (int64_t)t * ld);
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
+        *reinterpret_cast<float4*>(out + b * (C4 * 4) + c) = s;
+    }
+}
+
+extern "C" int vame_timesum_f32(const float* in, int B, int T, int C, int64_t ld, float* out, void* stream) {
+    VAME_CHECK_ARG(in && out && B >= 1 && T >= 1, VAME_E_BADARG, "timesum: bad argument");
+    VAME_CHECK_ARG(C >= 4 && C % 4 == 0 && ld % 4 == 0 && (uintptr_t)in % 16 == 0 && (uintptr_t)out % 16 == 0, VAME_E_SHAPE,
+                   "timesum: C, ld must be multiples of 4 and pointers 16-byte aligned");
+    hipLaunchKernelGGL(timesum_kernel, dim3(ew_blocks((int64_t)B * C / 4)), dim3(256), 0, (hipStream_t)stream, in, B, T, C / 4,
+                       ld, out);
+    VAME_LAUNCH_CHECK("timesum");
+    return VAME_OK;
+}
+
 // --------------------------------------------------------------------------------- Adam (AMSGrad)
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                    float* __restrict__ v, float* __restrict__ vmax, int64_t n, float step_size,

@@ -17,10 +17,26 @@ struct GemmParams {
     float* C; int64_t ldc;
     float* ws;
     int M, N, K, kper, splitk, accumulate;
+    int tiles_m, tiles_n, by_z;      // XCD-aware block->tile mapping (see map_tile)
 };
 
 __device__ __forceinline__ int64_t op_row(const GemmOperand& o, int64_t i) {
     return o.seg ? (i / o.seg) * o.seg_stride + (i % o.seg) * o.ld : i * o.ld;
+}
+
+// 1-D grid -> (m-tile, n-tile, k-split).  Workgroup b runs on XCD b%8 (observed; speed only) and each XCD
+// has a private 4 MiB L2, so tiles that stream the same operand panel are kept on ONE XCD: with
+// split-K >= 8 a whole k-slab (all its m,n tiles) is a unit, otherwise an (k-split, m-panel) row of n-tiles.
+// Units are dealt round-robin to XCDs; inside an XCD consecutive workgroups walk one unit's tiles.
+__device__ __forceinline__ bool map_tile(const GemmParams& p, int& tm, int& tn, int& z) {
+    const int L = blockIdx.x, xcd = L & 7, slot = L >> 3;
+    const int per_unit = p.by_z ? p.tiles_m * p.tiles_n : p.tiles_n;
+    const int nunits = p.by_z ? p.splitk : p.splitk * p.tiles_m;
+    const int u = (slot / per_unit) * 8 + xcd, w = slot % per_unit;
+    if (u >= nunits) return false;
+    if (p.by_z) { z = u; tm = w / p.tiles_n; tn = w % p.tiles_n; }
+    else { z = u / p.tiles_m; tm = u % p.tiles_m; tn = w; }
+    return true;
 }
 
 // Fetch this thread's share of a (BK x BX) operand tile into registers.
@@ -81,11 +97,13 @@ struct TileIO {
 template <int BM, int BN, int WM, int WN, bool AKM, bool BKM>
 __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmParams p) {
     constexpr int BK = 16, NT = WM * WN * 64, TM = BM / WM / 32, TN = BN / WN / 32, LDA = BM + 4, LDB = BN + 4;
-    __shared__ __attribute__((aligned(16))) float As[BK * LDA];
-    __shared__ __attribute__((aligned(16))) float Bs[BK * LDB];
+    __shared__ __attribute__((aligned(16))) float As[2][BK * LDA];
+    __shared__ __attribute__((aligned(16))) float Bs[2][BK * LDB];
+    int tm_, tn_, z;
+    if (!map_tile(p, tm_, tn_, z)) return;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, li = lane & 31, hh = lane >> 5;
     const int wm = wv / WN, wn = wv % WN;
-    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN, z = blockIdx.z;
+    const int m0 = tm_ * BM, n0 = tn_ * BN;
     const int kb = z * p.kper, ke = (kb + p.kper < p.K) ? kb + p.kper : p.K;
 
     f32x16 acc[TM][TN];
@@ -98,14 +116,17 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmParams p) {
 
     TileIO<BK, BM, NT, AKM> ta;
     TileIO<BK, BN, NT, BKM> tb;
-    if (kb < ke) { ta.fetch(p.A, m0, p.M, kb, ke, tid); tb.fetch(p.B, n0, p.N, kb, ke, tid); }
+    int cur = 0;
+    if (kb < ke) {
+        ta.fetch(p.A, m0, p.M, kb, ke, tid); tb.fetch(p.B, n0, p.N, kb, ke, tid);
+        ta.store(As[0], LDA, tid); tb.store(Bs[0], LDB, tid);
+    }
+    __syncthreads();
     for (int k0 = kb; k0 < ke; k0 += BK) {
-        ta.store(As, LDA, tid);
-        tb.store(Bs, LDB, tid);
-        __syncthreads();
-        if (k0 + BK < ke) { ta.fetch(p.A, m0, p.M, k0 + BK, ke, tid); tb.fetch(p.B, n0, p.N, k0 + BK, ke, tid); }
-        const float* ap = &As[hh * LDA + wm * (BM / WM) + li];
-        const float* bp = &Bs[hh * LDB + wn * (BN / WN) + li];
+        const bool more = k0 + BK < ke;
+        if (more) { ta.fetch(p.A, m0, p.M, k0 + BK, ke, tid); tb.fetch(p.B, n0, p.N, k0 + BK, ke, tid); }   // in flight during the MFMAs
+        const float* ap = &As[cur][hh * LDA + wm * (BM / WM) + li];
+        const float* bp = &Bs[cur][hh * LDB + wn * (BN / WN) + li];
 #pragma unroll
         for (int kk = 0; kk < BK / 2; ++kk) {
             float a[TM], b[TN];
@@ -118,7 +139,9 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmParams p) {
 #pragma unroll
                 for (int j = 0; j < TN; ++j) acc[i][j] = MFMA_32x32x2(a[i], b[j], acc[i][j]);
         }
+        if (more) { ta.store(As[cur ^ 1], LDA, tid); tb.store(Bs[cur ^ 1], LDB, tid); }
         __syncthreads();
+        cur ^= 1;
     }
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -160,8 +183,12 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 }
 
 template <int BM, int BN, int WM, int WN>
-static int launch_gemm(const GemmParams& p, int akm, int bkm, hipStream_t st) {
-    dim3 grid((unsigned)cdiv64(p.N, BN), (unsigned)cdiv64(p.M, BM), (unsigned)p.splitk), block(WM * WN * 64);
+static int launch_gemm(GemmParams p, int akm, int bkm, hipStream_t st) {
+    p.tiles_m = (int)cdiv64(p.M, BM); p.tiles_n = (int)cdiv64(p.N, BN);
+    p.by_z = p.splitk >= 8;
+    const int64_t per_unit = p.by_z ? (int64_t)p.tiles_m * p.tiles_n : p.tiles_n;
+    const int64_t nunits = p.by_z ? p.splitk : (int64_t)p.splitk * p.tiles_m;
+    dim3 grid((unsigned)(cdiv64(nunits, 8) * per_unit * 8)), block(WM * WN * 64);
     if (!akm && !bkm) hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, false, false>), grid, block, 0, st, p);
     else if (!akm && bkm) hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, false, true>), grid, block, 0, st, p);
     else if (akm && bkm) hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, true, true>), grid, block, 0, st, p);

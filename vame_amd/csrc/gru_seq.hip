@@ -33,7 +33,6 @@ struct GruBwdStream {
     float* dg;
     float* dh0; int64_t dh0_row;
     float* dbias;
-    float* dgsum;
     int64_t T, reverse, pad;
 };
 struct GruBwdParams { GruBwdStream s[8]; int nstreams; int B; int ntiles; };
@@ -101,6 +100,17 @@ extern "C" int64_t vame_gru_stash_floats(int B, int T, int H) {
 }
 
 // ------------------------------------------------------------------------------------------- forward
+// Addressing: in the 32x32 accumulator layout register r of lane l holds row CR(r) + 4*(l>>5), column l&31.
+// Every row-major operand is therefore addressed as  uniform_row_pointer(r) [ lane_offset ]  with
+// lane_offset = 4*(l>>5)*row_stride + (l&31): one VGPR per array, row pointers stay in SGPRs.
+#define CR(r) (((r) & 3) + 8 * ((r) >> 2))
+
+#ifdef VAME_EMU
+#define UNIFORM(x) (x)
+#else
+#define UNIFORM(x) __builtin_amdgcn_readfirstlane(x)
+#endif
+
 // stash index: ((((tile*T + t)*NW + w)*4 + gate)*4 + rq)*64 + lane   (float4 units), gate = r,u,n,gh_n
 template <int H>
 __global__ __launch_bounds__(H / 32 * 64) void gru_seq_fwd_kernel(GruFwdParams P) {
@@ -110,59 +120,76 @@ __global__ __launch_bounds__(H / 32 * 64) void gru_seq_fwd_kernel(GruFwdParams P
     if (!map_block(P.nstreams, P.ntiles, sidx, tile)) return;
     const GruFwdStream& S = P.s[sidx];
     const int B = P.B, T = (int)S.T;
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, li = lane & 31, hh = lane >> 5;
-    const int row0 = tile * 32, col = 32 * w + li;
+    const int tid = threadIdx.x, lane = tid & 63, li = lane & 31, hh = lane >> 5;
+    const int w = UNIFORM(tid >> 6);
+    const int row0 = tile * 32, col0 = 32 * w;
+    const int nvalid = B - row0;                        // rows of this tile inside the batch (>= 32: full tile)
+    const bool full = nvalid >= 32;
+    const int lrow = 4 * hh;                            // lane part of the fragment row
+    const int lo_gi = lrow * (int)S.gi_row + li, lo_y = lrow * (int)S.y_row + li;
+    const float* gi_base = S.gi + (int64_t)row0 * S.gi_row + col0;
+    float* y_base = S.y ? S.y + (int64_t)row0 * S.y_row + col0 : nullptr;
 
     f32x16 hprev;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-        const int row = frag_row(r, lane), grow = row0 + row;
+        const int row = CR(r) + lrow, grow = row0 + row;
         float v = 0.0f;
-        if (S.h0 && grow < B) v = S.h0[(int64_t)grow * S.h0_row + col];
+        if (S.h0 && grow < B) v = S.h0[(int64_t)grow * S.h0_row + col0 + li];
         hprev[r] = v;
-        hs[0][row * LDH + col] = v;
-        if (S.y && S.pad && grow < B) S.y[(int64_t)grow * S.y_row + (S.reverse ? T : -1) * S.y_t + col] = v;
+        hs[0][row * LDH + col0 + li] = v;
+        if (y_base && S.pad && grow < B) (y_base + (int64_t)CR(r) * S.y_row + (int64_t)(S.reverse ? T : -1) * S.y_t)[lo_y] = v;
     }
     __syncthreads();
-    const float bhn = S.bhn[col];
+    const float bhn = S.bhn[col0 + li];
     const float4* __restrict__ wp = reinterpret_cast<const float4*>(S.wp) + (int64_t)w * KC * 3 * 64 + lane;
     float4* stash = S.stash ? reinterpret_cast<float4*>(S.stash) : nullptr;
     int cur = 0;
-    for (int step = 0; step < T; ++step) {
-        const int t = S.reverse ? T - 1 - step : step;
-        f32x16 ar, au, ani, anh;
+    // gi of the first step; later steps are prefetched during the previous step's MFMA loop
+    f32x16 gr, gu, gn;
+    auto load_gi = [&](int t) {
+        const float* gt = gi_base + (int64_t)t * S.gi_t;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int grow = row0 + frag_row(r, lane);
-            float vr = 0.f, vu = 0.f, vn = 0.f;
-            if (grow < B) {
-                const float* g = S.gi + (int64_t)grow * S.gi_row + (int64_t)t * S.gi_t + col;
-                vr = g[0]; vu = g[H]; vn = g[2 * H];
-            }
-            ar[r] = vr; au[r] = vu; ani[r] = vn; anh[r] = bhn;
+            const float* g = gt + (int64_t)CR(r) * S.gi_row;
+            if (full || CR(r) + lrow < nvalid) { gr[r] = g[lo_gi]; gu[r] = g[lo_gi + H]; gn[r] = g[lo_gi + 2 * H]; }
+            else { gr[r] = 0.f; gu[r] = 0.f; gn[r] = 0.f; }
         }
+    };
+    load_gi(S.reverse ? T - 1 : 0);
+    for (int step = 0; step < T; ++step) {
+        const int t = S.reverse ? T - 1 - step : step;
+        f32x16 ar = gr, au = gu, ani = gn, anh;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) anh[r] = bhn;
+        if (step + 1 < T && S.gi_t != 0) load_gi(S.reverse ? t - 1 : t + 1);     // in flight during the k-loop
         const float* hrow = &hs[cur][li * LDH + 4 * hh];
+        // software pipeline: fragments of chunk c+1 are requested before the 12 MFMAs of chunk c
+        float4 a = *reinterpret_cast<const float4*>(hrow);
+        float4 b0 = wp[0], b1 = wp[64], b2 = wp[128];
 #pragma unroll 2
         for (int c = 0; c < KC; ++c) {
-            const float4 a = *reinterpret_cast<const float4*>(hrow + 8 * c);
-            const float4 b0 = wp[(c * 3 + 0) * 64], b1 = wp[(c * 3 + 1) * 64], b2 = wp[(c * 3 + 2) * 64];
+            const int cn = c + 1 < KC ? c + 1 : c;
+            const float4 an = *reinterpret_cast<const float4*>(hrow + 8 * cn);
+            const float4 b0n = wp[(cn * 3 + 0) * 64], b1n = wp[(cn * 3 + 1) * 64], b2n = wp[(cn * 3 + 2) * 64];
             ar = MFMA_32x32x2(a.x, b0.x, ar); au = MFMA_32x32x2(a.x, b1.x, au); anh = MFMA_32x32x2(a.x, b2.x, anh);
             ar = MFMA_32x32x2(a.y, b0.y, ar); au = MFMA_32x32x2(a.y, b1.y, au); anh = MFMA_32x32x2(a.y, b2.y, anh);
             ar = MFMA_32x32x2(a.z, b0.z, ar); au = MFMA_32x32x2(a.z, b1.z, au); anh = MFMA_32x32x2(a.z, b2.z, anh);
             ar = MFMA_32x32x2(a.w, b0.w, ar); au = MFMA_32x32x2(a.w, b1.w, au); anh = MFMA_32x32x2(a.w, b2.w, anh);
+            a = an; b0 = b0n; b1 = b1n; b2 = b2n;
         }
-        float* hnext = hs[cur ^ 1];
+        float* hnext = &hs[cur ^ 1][lrow * LDH + col0 + li];
+        float* yt = y_base ? y_base + (int64_t)t * S.y_t : nullptr;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int row = frag_row(r, lane), grow = row0 + row;
             const float rr = fast_sigmoid(ar[r]);
             const float uu = fast_sigmoid(au[r]);
             const float nn = fast_tanh(ani[r] + rr * anh[r]);
             const float hv = nn + uu * (hprev[r] - nn);
             ar[r] = rr; au[r] = uu; ani[r] = nn;
             hprev[r] = hv;
-            hnext[row * LDH + col] = hv;
-            if (S.y && grow < B) S.y[(int64_t)grow * S.y_row + (int64_t)t * S.y_t + col] = hv;
+            hnext[CR(r) * LDH] = hv;
+            if (yt && (full || CR(r) + lrow < nvalid)) (yt + (int64_t)CR(r) * S.y_row)[lo_y] = hv;
         }
         if (stash) {
             float4* sp = stash + ((((int64_t)tile * T + t) * NW + w) * 16) * 64 + lane;
@@ -180,14 +207,14 @@ __global__ __launch_bounds__(H / 32 * 64) void gru_seq_fwd_kernel(GruFwdParams P
     if (S.hn) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int grow = row0 + frag_row(r, lane);
-            if (grow < B) S.hn[(int64_t)grow * S.hn_row + col] = hprev[r];
+            const int grow = row0 + CR(r) + lrow;
+            if (grow < B) S.hn[(int64_t)grow * S.hn_row + col0 + li] = hprev[r];
         }
     }
 }
 
 // ------------------------------------------------------------------------------------------- backward
-template <int H, bool DGSUM>
+template <int H>
 __global__ __launch_bounds__(H / 32 * 64) void gru_seq_bwd_kernel(GruBwdParams P) {
     constexpr int NW = H / 32, K3 = 3 * H, LDG = K3 + 4, KC = K3 / 8;
     __shared__ float gs[32 * LDG];
@@ -195,48 +222,69 @@ __global__ __launch_bounds__(H / 32 * 64) void gru_seq_bwd_kernel(GruBwdParams P
     if (!map_block(P.nstreams, P.ntiles, sidx, tile)) return;
     const GruBwdStream& S = P.s[sidx];
     const int B = P.B, T = (int)S.T;
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, li = lane & 31, hh = lane >> 5;
-    const int row0 = tile * 32, col = 32 * w + li;
+    const int tid = threadIdx.x, lane = tid & 63, li = lane & 31, hh = lane >> 5;
+    const int w = UNIFORM(tid >> 6);
+    const int row0 = tile * 32, col0 = 32 * w, lrow = 4 * hh;
+    const int nvalid = B - row0;
+    const bool full = nvalid >= 32;
+    const int lo_y = lrow * (int)S.y_row + li, lo_dy = lrow * (int)S.dy_row + li, lo_dg = lrow * T * 4 * H + li;
+    const float* y_base = S.y + (int64_t)row0 * S.y_row + col0;
+    const float* dy_base = S.dy ? S.dy + (int64_t)row0 * S.dy_row + col0 : nullptr;
+    float* dg_base = S.dg + (int64_t)row0 * T * 4 * H + col0;
 
     f32x16 dh;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-        const int grow = row0 + frag_row(r, lane);
-        dh[r] = (S.dhn && grow < B) ? S.dhn[(int64_t)grow * S.dhn_row + col] : 0.0f;
+        const int grow = row0 + CR(r) + lrow;
+        dh[r] = (S.dhn && grow < B) ? S.dhn[(int64_t)grow * S.dhn_row + col0 + li] : 0.0f;
     }
     float dbs0 = 0.f, dbs1 = 0.f, dbs2 = 0.f, dbs3 = 0.f;
-    f32x16 sgr, sgu, sgn;
-    if (DGSUM) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { sgr[r] = 0.f; sgu[r] = 0.f; sgn[r] = 0.f; }
-    }
     const float4* __restrict__ wpt = reinterpret_cast<const float4*>(S.wpt) + (int64_t)w * KC * 64 + lane;
     const float4* stash = reinterpret_cast<const float4*>(S.stash);
     const float* grow_a = &gs[li * LDG + 4 * hh];
+    float* gs_w = &gs[lrow * LDG + col0 + li];
 
-    for (int step = 0; step < T; ++step) {
+    // per-step operands (forward stash r,u,n,gh_n; h_{t-1}; dy_t), loaded one step ahead: the loads for
+    // step s+1 are issued right before the MFMA loop of step s into registers that are dead during it
+    float4 sr[4], su[4], sn[4], sg[4];
+    f32x16 hpv, dyv;
+    auto load_step = [&](int step) {
         const int fstep = T - 1 - step;
         const int t = S.reverse ? T - 1 - fstep : fstep;
         const int tprev = S.reverse ? t + 1 : t - 1;
         const float4* sp = stash + ((((int64_t)tile * T + t) * NW + w) * 16) * 64 + lane;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            sr[q] = sp[(0 * 4 + q) * 64]; su[q] = sp[(1 * 4 + q) * 64]; sn[q] = sp[(2 * 4 + q) * 64]; sg[q] = sp[(3 * 4 + q) * 64];
+        }
+        const bool have_prev = fstep > 0 || S.pad;
+        const float* yp = y_base + (int64_t)tprev * S.y_t;
+        const float* dyt = dy_base ? dy_base + (int64_t)t * S.dy_t : nullptr;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            float hp = 0.f, dv = 0.f;
+            if (full || CR(r) + lrow < nvalid) {
+                if (have_prev) hp = (yp + (int64_t)CR(r) * S.y_row)[lo_y];
+                else if (S.h0) hp = S.h0[(int64_t)(row0 + CR(r) + lrow) * S.h0_row + col0 + li];
+                if (dyt) dv = (dyt + (int64_t)CR(r) * S.dy_row)[lo_dy];
+            }
+            hpv[r] = hp; dyv[r] = dv;
+        }
+    };
+    load_step(0);
+    for (int step = 0; step < T; ++step) {
+        const int fstep = T - 1 - step;
+        const int t = S.reverse ? T - 1 - fstep : fstep;
+        float* dgt = dg_base + (int64_t)t * 4 * H;
         f32x16 dhp;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const float4 r4 = sp[(0 * 4 + q) * 64], u4 = sp[(1 * 4 + q) * 64], n4 = sp[(2 * 4 + q) * 64],
-                         g4 = sp[(3 * 4 + q) * 64];
-            const float rv[4] = {r4.x, r4.y, r4.z, r4.w}, uv[4] = {u4.x, u4.y, u4.z, u4.w},
-                        nv[4] = {n4.x, n4.y, n4.z, n4.w}, gv[4] = {g4.x, g4.y, g4.z, g4.w};
+            const float rv[4] = {sr[q].x, sr[q].y, sr[q].z, sr[q].w}, uv[4] = {su[q].x, su[q].y, su[q].z, su[q].w},
+                        nv[4] = {sn[q].x, sn[q].y, sn[q].z, sn[q].w}, gv[4] = {sg[q].x, sg[q].y, sg[q].z, sg[q].w};
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int r = 4 * q + j;
-                const int row = frag_row(r, lane), grow = row0 + row;
-                const bool ok = grow < B;
-                float hp = 0.f, d = dh[r];
-                if (ok) {
-                    if (fstep > 0 || S.pad) hp = S.y[(int64_t)grow * S.y_row + (int64_t)tprev * S.y_t + col];
-                    else if (S.h0) hp = S.h0[(int64_t)grow * S.h0_row + col];
-                    if (S.dy) d += S.dy[(int64_t)grow * S.dy_row + (int64_t)t * S.dy_t + col];
-                }
+                const float hp = hpv[r], d = dh[r] + dyv[r];
                 const float rr = rv[j], uu = uv[j], nn = nv[j], gh = gv[j];
                 const float dn = d * (1.0f - uu);
                 const float du = d * (hp - nn);
@@ -245,30 +293,32 @@ __global__ __launch_bounds__(H / 32 * 64) void gru_seq_bwd_kernel(GruBwdParams P
                 const float dau = du * uu * (1.0f - uu);
                 const float dar = dan * gh * rr * (1.0f - rr);
                 const float dgh = dan * rr;
-                gs[row * LDG + col] = dar;
-                gs[row * LDG + H + col] = dau;
-                gs[row * LDG + 2 * H + col] = dgh;
-                if (ok) {
-                    float* o = S.dg + ((int64_t)grow * T + t) * (4 * H) + col;
-                    o[0] = dar; o[H] = dau; o[2 * H] = dan; o[3 * H] = dgh;
+                float* gw = gs_w + CR(r) * LDG;
+                gw[0] = dar; gw[H] = dau; gw[2 * H] = dgh;
+                if (full || CR(r) + lrow < nvalid) {
+                    float* o = dgt + (int64_t)CR(r) * T * 4 * H;
+                    o[lo_dg] = dar; o[lo_dg + H] = dau; o[lo_dg + 2 * H] = dan; o[lo_dg + 3 * H] = dgh;
                 }
                 dbs0 += dar; dbs1 += dau; dbs2 += dan; dbs3 += dgh;
-                if (DGSUM) { sgr[r] += dar; sgu[r] += dau; sgn[r] += dan; }
             }
         }
         __syncthreads();
+        if (step + 1 < T) load_step(step + 1);
         f32x16 acc0, acc1;
 #pragma unroll
         for (int r = 0; r < 16; ++r) { acc0[r] = dhp[r]; acc1[r] = 0.f; }
+        float4 b0 = wpt[0], b1 = wpt[64];
 #pragma unroll 2
         for (int c = 0; c < KC; c += 2) {
+            const int cn = c + 2 < KC ? c + 2 : c;
             const float4 a0 = *reinterpret_cast<const float4*>(grow_a + 8 * c);
             const float4 a1 = *reinterpret_cast<const float4*>(grow_a + 8 * c + 8);
-            const float4 b0 = wpt[c * 64], b1 = wpt[(c + 1) * 64];
+            const float4 b0n = wpt[cn * 64], b1n = wpt[(cn + 1) * 64];      // weights of the next chunk pair (L2) in flight
             acc0 = MFMA_32x32x2(a0.x, b0.x, acc0); acc1 = MFMA_32x32x2(a1.x, b1.x, acc1);
             acc0 = MFMA_32x32x2(a0.y, b0.y, acc0); acc1 = MFMA_32x32x2(a1.y, b1.y, acc1);
             acc0 = MFMA_32x32x2(a0.z, b0.z, acc0); acc1 = MFMA_32x32x2(a1.z, b1.z, acc1);
             acc0 = MFMA_32x32x2(a0.w, b0.w, acc0); acc1 = MFMA_32x32x2(a1.w, b1.w, acc1);
+            b0 = b0n; b1 = b1n;
         }
 #pragma unroll
         for (int r = 0; r < 16; ++r) dh[r] = acc0[r] + acc1[r];
@@ -277,28 +327,16 @@ __global__ __launch_bounds__(H / 32 * 64) void gru_seq_bwd_kernel(GruBwdParams P
     if (S.dh0) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int grow = row0 + frag_row(r, lane);
-            if (grow < B) S.dh0[(int64_t)grow * S.dh0_row + col] = dh[r];
+            const int grow = row0 + CR(r) + lrow;
+            if (grow < B) S.dh0[(int64_t)grow * S.dh0_row + col0 + li] = dh[r];
         }
     }
     if (S.dbias) {
         dbs0 += __shfl_xor(dbs0, 32); dbs1 += __shfl_xor(dbs1, 32);
         dbs2 += __shfl_xor(dbs2, 32); dbs3 += __shfl_xor(dbs3, 32);
         if (hh == 0) {
-            float* o = S.dbias + (int64_t)tile * 4 * H + col;
+            float* o = S.dbias + (int64_t)tile * 4 * H + col0 + li;
             o[0] = dbs0; o[H] = dbs1; o[2 * H] = dbs2; o[3 * H] = dbs3;
-        }
-    }
-    if (DGSUM) {
-        if (S.dgsum) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int grow = row0 + frag_row(r, lane);
-                if (grow < B) {
-                    float* o = S.dgsum + (int64_t)grow * 3 * H + col;
-                    o[0] = sgr[r]; o[H] = sgu[r]; o[2 * H] = sgn[r];
-                }
-            }
         }
     }
 }
@@ -309,11 +347,8 @@ static void launch_fwd(const GruFwdParams& P, hipStream_t st) {
     hipLaunchKernelGGL(gru_seq_fwd_kernel<H>, dim3(grid_blocks(P.nstreams, P.ntiles)), dim3(H / 32 * 64), 0, st, P);
 }
 template <int H>
-static void launch_bwd(const GruBwdParams& P, bool dgsum, hipStream_t st) {
-    if (dgsum)
-        hipLaunchKernelGGL((gru_seq_bwd_kernel<H, true>), dim3(grid_blocks(P.nstreams, P.ntiles)), dim3(H / 32 * 64), 0, st, P);
-    else
-        hipLaunchKernelGGL((gru_seq_bwd_kernel<H, false>), dim3(grid_blocks(P.nstreams, P.ntiles)), dim3(H / 32 * 64), 0, st, P);
+static void launch_bwd(const GruBwdParams& P, hipStream_t st) {
+    hipLaunchKernelGGL(gru_seq_bwd_kernel<H>, dim3(grid_blocks(P.nstreams, P.ntiles)), dim3(H / 32 * 64), 0, st, P);
 }
 
 extern "C" int vame_gru_seq_fwd_f32(const int64_t* desc, int nstreams, int B, int H, void* stream) {
@@ -351,7 +386,6 @@ extern "C" int vame_gru_seq_bwd_f32(const int64_t* desc, int nstreams, int B, in
     VAME_CHECK_ARG(B >= 1, VAME_E_SHAPE, "gru_seq_bwd: empty batch");
     GruBwdParams P;
     P.nstreams = nstreams; P.B = B; P.ntiles = (int)cdiv64(B, 32);
-    bool dgsum = false;
     for (int i = 0; i < nstreams; ++i) {
         const int64_t* d = desc + (int64_t)i * VAME_GRU_BWD_FIELDS;
         GruBwdStream& s = P.s[i];
@@ -362,18 +396,17 @@ extern "C" int vame_gru_seq_bwd_f32(const int64_t* desc, int nstreams, int B, in
         s.dhn = (const float*)d[GB_DHN]; s.dhn_row = d[GB_DHN_ROW];
         s.dg = (float*)d[GB_DG];
         s.dh0 = (float*)d[GB_DH0]; s.dh0_row = d[GB_DH0_ROW];
-        s.dbias = (float*)d[GB_DBIAS]; s.dgsum = (float*)d[GB_DGSUM];
+        s.dbias = (float*)d[GB_DBIAS];
         s.T = d[GB_T]; s.reverse = d[GB_REVERSE]; s.pad = d[GB_PAD];
         VAME_CHECK_ARG(s.stash && s.y && s.wpt && s.dg, VAME_E_BADARG, "gru_seq_bwd: stream %d: stash/y/wpt/dg null", i);
         VAME_CHECK_ARG(s.T >= 1, VAME_E_SHAPE, "gru_seq_bwd: stream %d: T=%lld", i, (long long)s.T);
-        dgsum = dgsum || s.dgsum;
     }
     hipStream_t st = (hipStream_t)stream;
     switch (H) {
-        case 32: launch_bwd<32>(P, dgsum, st); break;
-        case 64: launch_bwd<64>(P, dgsum, st); break;
-        case 128: launch_bwd<128>(P, dgsum, st); break;
-        case 256: launch_bwd<256>(P, dgsum, st); break;
+        case 32: launch_bwd<32>(P, st); break;
+        case 64: launch_bwd<64>(P, st); break;
+        case 128: launch_bwd<128>(P, st); break;
+        case 256: launch_bwd<256>(P, st); break;
         default: VAME_CHECK_ARG(false, VAME_E_UNSUPPORTED, "gru_seq_bwd: H=%d unsupported (32,64,128,256)", H);
     }
     VAME_LAUNCH_CHECK("gru_seq_bwd");

@@ -22,7 +22,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define VAME_DYN_SMEM(name) extern __shared__ __attribute__((aligned(16))) char name[]
 #define SETPRIO(n) __builtin_amdgcn_s_setprio(n)
 #define VAME_EXPF(x) __expf(x)
-#define VAME_RCP(x) __frcp_rn(x)
+#define VAME_RCP(x) __builtin_amdgcn_rcpf(x)   /* v_rcp_f32, 1 ulp */
 #endif
 #include <stdint.h>
 

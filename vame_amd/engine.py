@@ -250,14 +250,14 @@ class VAEEngine:
         return losses
 
     # ------------------------------------------------------------------ backward
-    def _gru_bwd_stream(self, d, stash, Y, y_T, dirn, dY, dy_T, dhn, dhn_off, dhn_row, dG, dh0, dh0_off, dbias, dgsum, T):
+    def _gru_bwd_stream(self, d, stash, Y, y_T, dirn, dY, dy_T, dhn, dhn_off, dhn_row, dG, dh0, dh0_off, dbias, T):
         H = self.spec.H
         return {GB["STASH"]: ops.addr(stash), GB["Y"]: ops.addr(Y, 2 * H + dirn * H), GB["Y_ROW"]: (y_T + 2) * 2 * H,
                 GB["Y_T"]: 2 * H, GB["WPT"]: ops.addr(d.wp_bwd),
                 GB["DY"]: ops.addr(dY, dirn * H) if dY is not None else 0, GB["DY_ROW"]: dy_T * 2 * H, GB["DY_T"]: 2 * H,
                 GB["DHN"]: ops.addr(dhn, dhn_off) if dhn is not None else 0, GB["DHN_ROW"]: dhn_row, GB["DG"]: ops.addr(dG),
                 GB["DH0"]: ops.addr(dh0, dh0_off) if dh0 is not None else 0, GB["DH0_ROW"]: H, GB["DBIAS"]: ops.addr(dbias),
-                GB["DGSUM"]: ops.addr(dgsum) if dgsum is not None else 0, GB["T"]: T, GB["REVERSE"]: dirn, GB["PAD"]: 1}
+                GB["T"]: T, GB["REVERSE"]: dirn, GB["PAD"]: 1}
 
     def _gru_param_grads(self, d: GruDir, dG, dbias, ntiles, B, T, Yseq, dirn, x_op, x_K, const_in=None):
         """dW_ih, dW_hh, db_ih, db_hh of one (layer,direction) from its dG (B,T,4H) stash."""
@@ -295,7 +295,7 @@ class VAEEngine:
             dbias = self.buf(f"db_{tag}_{dirn}", ntiles, 4 * H)
             dgsum = self.buf(f"dgs_{tag}_{dirn}", B, 3 * H)
             st = self.buf(f"st_{tag}_{dirn}", ops.gru_stash_floats(B, steps, H))
-            rows.append(self._gru_bwd_stream(d, st, Y, steps, dirn, dY, steps, None, 0, 0, dG, dhid, dirn * B * H, dbias, dgsum, steps))
+            rows.append(self._gru_bwd_stream(d, st, Y, steps, dirn, dY, steps, None, 0, 0, dG, dhid, dirn * B * H, dbias, steps))
             per.append((d, dG, dbias, dgsum))
         return rows, per, Y, dhid
 
@@ -316,6 +316,7 @@ class VAEEngine:
         first = True
         for name, per, Y, dhid, steps in groups:
             for dirn, (d, dG, dbias, dgsum) in enumerate(per):
+                ops.timesum(dG, B, steps, 3 * H, 4 * H, dgsum)       # z is constant in time: sum_t dG first
                 self._gru_param_grads(d, dG, dbias, ntiles, B, steps, Y, dirn, None, Z, const_in=(dgsum, z))
                 ops.gemm(B, Z, 3 * H, Operand(dgsum, 3 * H), 0, self.P(d.w_ih, Z), 1, dz, Z, accumulate=not first)
                 first = False
@@ -349,7 +350,7 @@ class VAEEngine:
             dG = self.buf(f"dG_e1_{dirn}", B, T, 4 * H)
             dbias = self.buf(f"db_e1_{dirn}", ntiles, 4 * H)
             st = self.buf(f"st_e1_{dirn}", ops.gru_stash_floats(B, T, H))
-            rows.append(self._gru_bwd_stream(d, st, Y1, T, dirn, None, T, dhn, (2 + dirn) * H, 4 * H, dG, None, 0, dbias, None, T))
+            rows.append(self._gru_bwd_stream(d, st, Y1, T, dirn, None, T, dhn, (2 + dirn) * H, 4 * H, dG, None, 0, dbias, T))
             per.append((d, dG, dbias))
         ops.gru_seq_bwd(rows, B, H)
         dY0 = self.buf("dY0", B, T, 2 * H)
@@ -363,7 +364,7 @@ class VAEEngine:
             dG = self.buf(f"dG_e0_{dirn}", B, T, 4 * H)
             dbias = self.buf(f"db_e0_{dirn}", ntiles, 4 * H)
             st = self.buf(f"st_e0_{dirn}", ops.gru_stash_floats(B, T, H))
-            rows.append(self._gru_bwd_stream(d, st, Y0, T, dirn, dY0, T, dhn, dirn * H, 4 * H, dG, None, 0, dbias, None, T))
+            rows.append(self._gru_bwd_stream(d, st, Y0, T, dirn, dY0, T, dhn, dirn * H, 4 * H, dG, None, 0, dbias, T))
             per.append((d, dG, dbias))
         ops.gru_seq_bwd(rows, B, H)
         xrows = Operand(self._win, F, seg=T, seg_stride=self._win_row)

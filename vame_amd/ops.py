@@ -7,7 +7,7 @@ from . import _lib
 GF = dict(GI=0, GI_ROW=1, GI_T=2, WP=3, BHN=4, H0=5, H0_ROW=6, Y=7, Y_ROW=8, Y_T=9, HN=10, HN_ROW=11, STASH=12, T=13,
           REVERSE=14, PAD=15, N=16)
 GB = dict(STASH=0, Y=1, Y_ROW=2, Y_T=3, H0=4, H0_ROW=5, WPT=6, DY=7, DY_ROW=8, DY_T=9, DHN=10, DHN_ROW=11, DG=12, DH0=13,
-          DH0_ROW=14, DBIAS=15, DGSUM=16, T=17, REVERSE=18, PAD=19, N=20)
+          DH0_ROW=14, DBIAS=15, RESERVED=16, T=17, REVERSE=18, PAD=19, N=20)
 
 
 def _stream():
@@ -106,6 +106,11 @@ def nuclear(G, Z, kloss, nrows, lmbda, bsize, loss_out, loss_off, Minv, gscale=1
     rc = _lib.lib().vame_nuclear_f32(_ptr(G), Z, kloss, nrows, float(lmbda), float(bsize), float(gscale),
                                      _ptr(loss_out, loss_off), _ptr(Minv), _stream())
     _lib.check(rc, "vame_nuclear_f32")
+
+
+def timesum(inp, B, T, C, ld, out):
+    rc = _lib.lib().vame_timesum_f32(_ptr(inp), B, T, C, ld, _ptr(out), _stream())
+    _lib.check(rc, "vame_timesum_f32")
 
 
 _colsum_ws = {}
