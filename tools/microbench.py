@@ -1,0 +1,87 @@
+#!/usr/bin/env python3
+"""Kernel micro-benchmarks on the MI355X (HIP events on the launch stream): the GEMM shapes and GRU
+sequence launches of the B=4096 train step.  Usage: python tools/microbench.py [reps]"""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+import torch  # noqa: E402
+
+from vame_amd import ops  # noqa: E402
+from vame_amd.ops import GB, GF, Operand  # noqa: E402
+
+dev = "cuda"
+REPS = int(sys.argv[1]) if len(sys.argv) > 1 else 10
+
+
+def timeit(fn, reps=REPS):
+    for _ in range(2):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps
+
+
+def bench_gemm(M, N, K, akm, bkm, sk=1, label=""):
+    A = torch.randn((K, M) if akm else (M, K), device=dev)
+    B = torch.randn((K, N) if bkm else (N, K), device=dev)
+    C = torch.empty(M, N, device=dev)
+    ws = torch.empty(sk * M * N, device=dev) if sk > 1 else None
+    ms = timeit(lambda: ops.gemm(M, N, K, Operand(A, A.shape[1]), akm, Operand(B, B.shape[1]), bkm, C, N, splitk=sk, ws=ws))
+    print(f"gemm {label:10s} M={M:6d} N={N:4d} K={K:6d} akm={akm} bkm={bkm} sk={sk:3d}: {ms*1e3:8.1f} us  {2.0*M*N*K/ms/1e9:7.1f} TF")
+
+
+def bench_gru(H, B, T, nstreams):
+    from kernel_cases import _gru_weights, _pack
+    import numpy as np
+    rng = np.random.default_rng(0)
+    rows_f, rows_b, keep = [], [], []
+    ntiles = (B + 31) // 32
+    for s in range(nstreams):
+        W_ih, W_hh, b_ih, b_hh = _gru_weights(rng, 8, H)
+        wpf, wpb, bgi, bhn = _pack(dev, W_hh, b_ih, b_hh, H)
+        gi = torch.randn(B, T, 3 * H, device=dev)
+        Y = torch.zeros(B, T + 2, 2 * H, device=dev)
+        stash = torch.zeros(ops.gru_stash_floats(B, T, H), device=dev)
+        dG = torch.zeros(B, T, 4 * H, device=dev)
+        dY = torch.randn(B, T, 2 * H, device=dev)
+        dbias = torch.zeros(ntiles, 4 * H, device=dev)
+        d = s % 2
+        rows_f.append({GF["GI"]: ops.addr(gi), GF["GI_ROW"]: T * 3 * H, GF["GI_T"]: 3 * H, GF["WP"]: ops.addr(wpf),
+                       GF["BHN"]: ops.addr(bhn), GF["Y"]: ops.addr(Y, 2 * H + d * H), GF["Y_ROW"]: (T + 2) * 2 * H,
+                       GF["Y_T"]: 2 * H, GF["STASH"]: ops.addr(stash), GF["T"]: T, GF["REVERSE"]: d, GF["PAD"]: 1})
+        rows_b.append({GB["STASH"]: ops.addr(stash), GB["Y"]: ops.addr(Y, 2 * H + d * H), GB["Y_ROW"]: (T + 2) * 2 * H,
+                       GB["Y_T"]: 2 * H, GB["WPT"]: ops.addr(wpb), GB["DY"]: ops.addr(dY, d * H), GB["DY_ROW"]: T * 2 * H,
+                       GB["DY_T"]: 2 * H, GB["DG"]: ops.addr(dG), GB["DBIAS"]: ops.addr(dbias), GB["T"]: T, GB["REVERSE"]: d,
+                       GB["PAD"]: 1})
+        keep.append((wpf, wpb, bgi, bhn, gi, Y, stash, dG, dY, dbias))
+    fl = nstreams * 2.0 * 3 * H * H * B * T
+    ms = timeit(lambda: ops.gru_seq_fwd(rows_f, B, H))
+    print(f"gru_fwd H={H} B={B} T={T} streams={nstreams}: {ms*1e3:8.1f} us  {fl/ms/1e9:7.1f} TF")
+    ms = timeit(lambda: ops.gru_seq_bwd(rows_b, B, H))
+    print(f"gru_bwd H={H} B={B} T={T} streams={nstreams}: {ms*1e3:8.1f} us  {fl/ms/1e9:7.1f} TF")
+
+
+if __name__ == "__main__":
+    BT = 4096 * 30
+    bench_gemm(BT, 768, 512, 0, 0, label="gi_L1")
+    bench_gemm(BT, 768, 24, 0, 0, label="gi_L0")
+    bench_gemm(BT, 512, 768, 0, 1, label="dY0")
+    bench_gemm(BT, 512, 24, 0, 1, label="dYdec")
+    for sk in (16, 32, 64):
+        bench_gemm(768, 512, BT, 1, 1, sk, label="dWih_L1")
+    for sk in (32, 64, 128):
+        bench_gemm(512, 256, BT, 1, 1, sk, label="dWhh_a")
+    bench_gemm(256, 256, BT, 1, 1, 64, label="dWhh_b")
+    bench_gemm(768, 24, BT, 1, 1, 128, label="dWih_L0")
+    bench_gemm(4096, 4096, 4096, 0, 0, label="square")
+    bench_gemm(4096, 4096, 4096, 1, 1, label="squareTN")
+    bench_gru(256, 4096, 30, 2)
+    bench_gru(256, 4096, 30, 4)
+    bench_gru(256, 8192, 30, 2)

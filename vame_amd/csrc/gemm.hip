@@ -39,39 +39,68 @@ __device__ __forceinline__ bool map_tile(const GemmParams& p, int& tm, int& tn, 
     return true;
 }
 
-// Fetch this thread's share of a (BK x BX) operand tile into registers.
-//   KM  (stored K x X, X contiguous): item = (k, x-quad)   -> float4 along X
-//   !KM (stored X x K, K contiguous): item = (x, k-quad)   -> float4 along K
+// One thread's share of a (BK x BX) operand tile: fetched into registers (global, 16 B), stored k-major to LDS.
+//   !KM (stored X x K, K contiguous): item = (x, k-quad); the thread's rows never change, so their
+//        (two-level) row offsets are resolved once; 8 lanes cover one 128-byte line of a row.
+//    KM (stored K x X, X contiguous): item = (k, x-quad); rows advance by BK per k-tile, the (segment,
+//        index) pair of the two-level addressing is advanced incrementally (no division in the loop).
 template <int BK, int BX, int NT, bool KM>
 struct TileIO {
     static constexpr int ITEMS = BK * BX / 4;
     static constexpr int PER = (ITEMS + NT - 1) / NT;
+    static constexpr int KQ = BK / 4, XQ = BX / 4;
     float4 v[PER];
-    __device__ __forceinline__ void fetch(const GemmOperand& o, int x0, int X, int k0, int ke, int tid) {
+    int rowo[KM ? 1 : PER];               // !KM: row offsets in elements (-1 = out of range)
+    int seg_b, seg_t;                      // KM: (segment, index) of row k0 + tid/XQ
+    int kstep;                             // KM: rows between consecutive items of this thread
+
+    __device__ __forceinline__ void init(const GemmOperand& o, int x0, int X, int kb, int tid) {
+        if (!KM) {
 #pragma unroll
-        for (int it = 0; it < PER; ++it) {
-            const int idx = tid + it * NT;
-            float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (ITEMS % NT == 0 || idx < ITEMS) {
-                if (KM) {
-                    const int k = idx / (BX / 4), xq = idx % (BX / 4);
-                    const int gk = k0 + k, gx = x0 + 4 * xq;
-                    if (gk < ke && gx < X) {
-                        const float* src = o.p + op_row(o, gk) + gx;
-                        if (o.vec && gx + 3 < X) r = *reinterpret_cast<const float4*>(src);
-                        else { r.x = src[0]; if (gx + 1 < X) r.y = src[1]; if (gx + 2 < X) r.z = src[2]; if (gx + 3 < X) r.w = src[3]; }
-                    }
-                } else {
-                    const int x = idx / (BK / 4), kq = idx % (BK / 4);
-                    const int gx = x0 + x, gk = k0 + 4 * kq;
-                    if (gx < X && gk < ke) {
-                        const float* src = o.p + op_row(o, gx) + gk;
-                        if (o.vec && gk + 3 < ke) r = *reinterpret_cast<const float4*>(src);
-                        else { r.x = src[0]; if (gk + 1 < ke) r.y = src[1]; if (gk + 2 < ke) r.z = src[2]; if (gk + 3 < ke) r.w = src[3]; }
-                    }
-                }
+            for (int it = 0; it < PER; ++it) {
+                const int idx = tid + it * NT, x = idx / KQ, gx = x0 + x;
+                rowo[it] = ((ITEMS % NT == 0 || idx < ITEMS) && gx < X) ? (int)op_row(o, gx) : -1;
             }
-            v[it] = r;
+        } else {
+            const unsigned g = (unsigned)(kb + tid / XQ);
+            if (o.seg) { seg_b = (int)(g / (unsigned)o.seg); seg_t = (int)(g % (unsigned)o.seg); }
+            else { seg_b = 0; seg_t = (int)g; }
+            kstep = NT / XQ;
+            rowo[0] = 0;
+        }
+    }
+    __device__ __forceinline__ void fetch(const GemmOperand& o, int x0, int X, int k0, int ke, int tid) {
+        if (!KM) {
+            const int gk = k0 + 4 * (tid % KQ);
+#pragma unroll
+            for (int it = 0; it < PER; ++it) {
+                float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (rowo[it] >= 0 && gk < ke) {
+                    const float* src = o.p + rowo[it] + gk;
+                    if (o.vec && gk + 3 < ke) r = *reinterpret_cast<const float4*>(src);
+                    else { r.x = src[0]; if (gk + 1 < ke) r.y = src[1]; if (gk + 2 < ke) r.z = src[2]; if (gk + 3 < ke) r.w = src[3]; }
+                }
+                v[it] = r;
+            }
+        } else {
+            const int gx = x0 + 4 * (tid % XQ);
+            int b = seg_b, t = seg_t;
+#pragma unroll
+            for (int it = 0; it < PER; ++it) {
+                const int gk = k0 + tid / XQ + it * kstep;
+                float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+                if ((ITEMS % NT == 0 || tid + it * NT < ITEMS) && gk < ke && gx < X) {
+                    const float* src = o.p + (o.seg ? (int64_t)b * o.seg_stride + (int64_t)t * o.ld : (int64_t)t * o.ld) + gx;
+                    if (o.vec && gx + 3 < X) r = *reinterpret_cast<const float4*>(src);
+                    else { r.x = src[0]; if (gx + 1 < X) r.y = src[1]; if (gx + 2 < X) r.z = src[2]; if (gx + 3 < X) r.w = src[3]; }
+                }
+                v[it] = r;
+                t += kstep;
+                if (o.seg) while (t >= (int)o.seg) { t -= (int)o.seg; ++b; }
+            }
+            // advance the thread's first row by BK for the next k-tile
+            seg_t += BK;
+            if (o.seg) while (seg_t >= (int)o.seg) { seg_t -= (int)o.seg; ++seg_b; }
         }
     }
     __device__ __forceinline__ void store(float* lds, int LD, int tid) const {
@@ -80,10 +109,10 @@ struct TileIO {
             const int idx = tid + it * NT;
             if (ITEMS % NT == 0 || idx < ITEMS) {
                 if (KM) {
-                    const int k = idx / (BX / 4), xq = idx % (BX / 4);
+                    const int k = idx / XQ, xq = idx % XQ;
                     *reinterpret_cast<float4*>(&lds[k * LD + 4 * xq]) = v[it];
                 } else {
-                    const int x = idx / (BK / 4), kq = idx % (BK / 4);
+                    const int x = idx / KQ, kq = idx % KQ;
                     lds[(4 * kq + 0) * LD + x] = v[it].x;
                     lds[(4 * kq + 1) * LD + x] = v[it].y;
                     lds[(4 * kq + 2) * LD + x] = v[it].z;
@@ -95,10 +124,10 @@ struct TileIO {
 };
 
 template <int BM, int BN, int WM, int WN, bool AKM, bool BKM>
-__global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmParams p) {
-    constexpr int BK = 16, NT = WM * WN * 64, TM = BM / WM / 32, TN = BN / WN / 32, LDA = BM + 4, LDB = BN + 4;
-    __shared__ __attribute__((aligned(16))) float As[2][BK * LDA];
-    __shared__ __attribute__((aligned(16))) float Bs[2][BK * LDB];
+__global__ __launch_bounds__(WM * WN * 64, 3) void gemm_kernel(GemmParams p) {
+    constexpr int BK = 32, NT = WM * WN * 64, TM = BM / WM / 32, TN = BN / WN / 32, LDA = BM + 4, LDB = BN + 4;
+    __shared__ __attribute__((aligned(16))) float As[BK * LDA];
+    __shared__ __attribute__((aligned(16))) float Bs[BK * LDB];
     int tm_, tn_, z;
     if (!map_tile(p, tm_, tn_, z)) return;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, li = lane & 31, hh = lane >> 5;
@@ -116,17 +145,16 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmParams p) {
 
     TileIO<BK, BM, NT, AKM> ta;
     TileIO<BK, BN, NT, BKM> tb;
-    int cur = 0;
-    if (kb < ke) {
-        ta.fetch(p.A, m0, p.M, kb, ke, tid); tb.fetch(p.B, n0, p.N, kb, ke, tid);
-        ta.store(As[0], LDA, tid); tb.store(Bs[0], LDB, tid);
-    }
-    __syncthreads();
+    ta.init(p.A, m0, p.M, kb, tid);
+    tb.init(p.B, n0, p.N, kb, tid);
+    if (kb < ke) { ta.fetch(p.A, m0, p.M, kb, ke, tid); tb.fetch(p.B, n0, p.N, kb, ke, tid); }
+    const float* ap = &As[hh * LDA + wm * (BM / WM) + li];
+    const float* bp = &Bs[hh * LDB + wn * (BN / WN) + li];
     for (int k0 = kb; k0 < ke; k0 += BK) {
-        const bool more = k0 + BK < ke;
-        if (more) { ta.fetch(p.A, m0, p.M, k0 + BK, ke, tid); tb.fetch(p.B, n0, p.N, k0 + BK, ke, tid); }   // in flight during the MFMAs
-        const float* ap = &As[cur][hh * LDA + wm * (BM / WM) + li];
-        const float* bp = &Bs[cur][hh * LDB + wn * (BN / WN) + li];
+        ta.store(As, LDA, tid);
+        tb.store(Bs, LDB, tid);
+        __syncthreads();
+        if (k0 + BK < ke) { ta.fetch(p.A, m0, p.M, k0 + BK, ke, tid); tb.fetch(p.B, n0, p.N, k0 + BK, ke, tid); }   // in flight during the MFMAs
 #pragma unroll
         for (int kk = 0; kk < BK / 2; ++kk) {
             float a[TM], b[TN];
@@ -139,9 +167,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmParams p) {
 #pragma unroll
                 for (int j = 0; j < TN; ++j) acc[i][j] = MFMA_32x32x2(a[i], b[j], acc[i][j]);
         }
-        if (more) { ta.store(As[cur ^ 1], LDA, tid); tb.store(Bs[cur ^ 1], LDB, tid); }
         __syncthreads();
-        cur ^= 1;
     }
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -213,7 +239,7 @@ extern "C" int vame_gemm_f32(int M, int N, int K, const float* A, int64_t lda, i
     p.B = {B, ldb, b_seg, b_seg_stride, operand_vec(B, ldb, b_seg, b_seg_stride)};
     p.bias = bias; p.C = C; p.ldc = ldc; p.ws = ws;
     p.M = M; p.N = N; p.K = K; p.accumulate = accumulate;
-    int kper = (int)(cdiv64(cdiv64(K, splitk), 16) * 16);
+    int kper = (int)(cdiv64(cdiv64(K, splitk), 32) * 32);
     p.kper = kper;
     p.splitk = (int)cdiv64(K, kper);
     hipStream_t st = (hipStream_t)stream;

@@ -124,8 +124,12 @@ class VAEEngine:
         return self.ws.get(name, n, self.dev, zero=zero)
 
     def _splitk(self, M, N, K):
+        # ~3 workgroups per CU on all 256 CUs; with split-K >= 8 a whole k-slab lives on one XCD (gemm.hip
+        # map_tile), so keep split-K a multiple of 8 to load the 8 XCDs evenly
         tiles = ((M + 127) // 128) * ((N + 127) // 128 if N > 64 else 1)
-        sk = max(1, min(512 // max(tiles, 1), K // 256))
+        sk = max(1, min(768 // max(tiles, 1), K // 256))
+        if sk >= 8:
+            sk = sk // 8 * 8
         return sk
 
     def _gemm_wgrad(self, M, N, K, A, B, gname, row_off=0):
