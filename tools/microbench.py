@@ -68,7 +68,19 @@ def bench_gru(H, B, T, nstreams):
     print(f"gru_bwd H={H} B={B} T={T} streams={nstreams}: {ms*1e3:8.1f} us  {fl/ms/1e9:7.1f} TF")
 
 
+def ablate():
+    for var, masks in (("VAME_ABL_FWD", (0, 1, 2, 4, 8, 16, 32, 7, 63)), ("VAME_ABL_BWD", (0, 1, 2, 3, 16, 32, 51))):
+        for m in masks:
+            os.environ[var] = str(m)
+            print(f"--- {var}={m}")
+            bench_gru(256, 4096, 30, 2)
+        os.environ[var] = "0"
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 2 and sys.argv[2] == "ablate":
+        ablate()
+        sys.exit(0)
     BT = 4096 * 30
     bench_gemm(BT, 768, 512, 0, 0, label="gi_L1")
     bench_gemm(BT, 768, 24, 0, 0, label="gi_L0")

@@ -96,7 +96,7 @@ extern "C" int vame_gru_pack_f32(const float* W_hh, const float* b_ih, const flo
 }
 
 extern "C" int64_t vame_gru_stash_floats(int B, int T, int H) {
-    return cdiv64(B, 32) * 32 * (int64_t)T * 4 * H;
+    return cdiv64(B, 32) * 32 * (int64_t)T * 5 * H;
 }
 
 // ------------------------------------------------------------------------------------------- forward
@@ -111,8 +111,13 @@ extern "C" int64_t vame_gru_stash_floats(int B, int T, int H) {
 #define UNIFORM(x) __builtin_amdgcn_readfirstlane(x)
 #endif
 
-// stash index: ((((tile*T + t)*NW + w)*4 + gate)*4 + rq)*64 + lane   (float4 units), gate = r,u,n,gh_n
-template <int H>
+// Backward stash, written in the accumulator-fragment order it is read back in (opaque to the host):
+//   float4 index ((((tile*T + t)*NW + w)*5 + k)*4 + rq)*64 + lane,  k = cA, cB, u, r, gh_n  with
+//   cA = (1-u)(1-n^2) (d a_n / d h'),  cB = (h_prev - n) u (1-u) (d a_z / d h'):  every BPTT gate gradient is
+//   d * {cA, cB, u} or a product with r / gh_n, so the backward kernel needs neither n nor h_prev.
+// ABL (ablation mask, 0 in production; tools/microbench.py VAME_ABL_FWD): 1 no stash stores, 2 no gi loads,
+// 4 no y stores, 8 no gate transcendental math, 16 W fragments not re-streamed, 32 no per-step barrier
+template <int H, int ABL = 0>
 __global__ __launch_bounds__(H / 32 * 64) void gru_seq_fwd_kernel(GruFwdParams P) {
     constexpr int NW = H / 32, LDH = H + 4, KC = H / 8;
     __shared__ float hs[2][32 * LDH];
@@ -126,10 +131,20 @@ __global__ __launch_bounds__(H / 32 * 64) void gru_seq_fwd_kernel(GruFwdParams P
     const int nvalid = B - row0;                        // rows of this tile inside the batch (>= 32: full tile)
     const bool full = nvalid >= 32;
     const int lrow = 4 * hh;                            // lane part of the fragment row
-    const int lo_gi = lrow * (int)S.gi_row + li, lo_y = lrow * (int)S.y_row + li;
+    const int lo_gi = lrow * (int)S.gi_row + li;
     const float* gi_base = S.gi + (int64_t)row0 * S.gi_row + col0;
-    float* y_base = S.y ? S.y + (int64_t)row0 * S.y_row + col0 : nullptr;
-
+    float* y_tile = S.y ? S.y + (int64_t)row0 * S.y_row : nullptr;
+    // h_t leaves through LDS: after the step's barrier the whole 32 x H tile is copied row-major with 16-byte
+    // stores (4 per thread) instead of 16 dword stores per lane from the accumulator layout
+    const int crow = tid / (H / 4), cc4 = tid % (H / 4);          // copy pass: 8 rows x (H/4) float4 per pass, 4 passes
+    auto store_h = [&](const float* hbuf, int t) {
+        float* yt = y_tile + (int64_t)t * S.y_t + (int64_t)crow * S.y_row + 4 * cc4;
+        const float* src = hbuf + crow * LDH + 4 * cc4;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (full || crow + 8 * i < nvalid)
+                *reinterpret_cast<float4*>(yt + (int64_t)(8 * i) * S.y_row) = *reinterpret_cast<const float4*>(src + 8 * i * LDH);
+    };
     f32x16 hprev;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -138,9 +153,9 @@ __global__ __launch_bounds__(H / 32 * 64) void gru_seq_fwd_kernel(GruFwdParams P
         if (S.h0 && grow < B) v = S.h0[(int64_t)grow * S.h0_row + col0 + li];
         hprev[r] = v;
         hs[0][row * LDH + col0 + li] = v;
-        if (y_base && S.pad && grow < B) (y_base + (int64_t)CR(r) * S.y_row + (int64_t)(S.reverse ? T : -1) * S.y_t)[lo_y] = v;
     }
     __syncthreads();
+    if (y_tile && S.pad) store_h(hs[0], S.reverse ? T : -1);
     const float bhn = S.bhn[col0 + li];
     const float4* __restrict__ wp = reinterpret_cast<const float4*>(S.wp) + (int64_t)w * KC * 3 * 64 + lane;
     float4* stash = S.stash ? reinterpret_cast<float4*>(S.stash) : nullptr;
@@ -149,14 +164,26 @@ __global__ __launch_bounds__(H / 32 * 64) void gru_seq_fwd_kernel(GruFwdParams P
     f32x16 gr, gu, gn;
     auto load_gi = [&](int t) {
         const float* gt = gi_base + (int64_t)t * S.gi_t;
+        if (!(ABL & 2) && full) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const float* g = gt + (int64_t)CR(r) * S.gi_row;
-            if (full || CR(r) + lrow < nvalid) { gr[r] = g[lo_gi]; gu[r] = g[lo_gi + H]; gn[r] = g[lo_gi + 2 * H]; }
-            else { gr[r] = 0.f; gu[r] = 0.f; gn[r] = 0.f; }
+            for (int r = 0; r < 16; ++r) {
+                const float* g = gt + (int64_t)CR(r) * S.gi_row;
+                gr[r] = g[lo_gi]; gu[r] = g[lo_gi + H]; gn[r] = g[lo_gi + 2 * H];
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float* g = gt + (int64_t)CR(r) * S.gi_row;
+                if (!(ABL & 2) && CR(r) + lrow < nvalid) { gr[r] = g[lo_gi]; gu[r] = g[lo_gi + H]; gn[r] = g[lo_gi + 2 * H]; }
+                else { gr[r] = 0.f; gu[r] = 0.f; gn[r] = 0.f; }
+            }
         }
     };
     load_gi(S.reverse ? T - 1 : 0);
+    constexpr int PD = 4;                       // KC % PD == 0 for every supported H
+    float4 wq[PD][3];
+#pragma unroll
+    for (int c = 0; c < PD; ++c) { wq[c][0] = wp[(c * 3 + 0) * 64]; wq[c][1] = wp[(c * 3 + 1) * 64]; wq[c][2] = wp[(c * 3 + 2) * 64]; }
     for (int step = 0; step < T; ++step) {
         const int t = S.reverse ? T - 1 - step : step;
         f32x16 ar = gr, au = gu, ani = gn, anh;
@@ -164,45 +191,55 @@ __global__ __launch_bounds__(H / 32 * 64) void gru_seq_fwd_kernel(GruFwdParams P
         for (int r = 0; r < 16; ++r) anh[r] = bhn;
         if (step + 1 < T && S.gi_t != 0) load_gi(S.reverse ? t - 1 : t + 1);     // in flight during the k-loop
         const float* hrow = &hs[cur][li * LDH + 4 * hh];
-        // software pipeline: fragments of chunk c+1 are requested before the 12 MFMAs of chunk c
-        float4 a = *reinterpret_cast<const float4*>(hrow);
-        float4 b0 = wp[0], b1 = wp[64], b2 = wp[128];
-#pragma unroll 2
-        for (int c = 0; c < KC; ++c) {
-            const int cn = c + 1 < KC ? c + 1 : c;
-            const float4 an = *reinterpret_cast<const float4*>(hrow + 8 * cn);
-            const float4 b0n = wp[(cn * 3 + 0) * 64], b1n = wp[(cn * 3 + 1) * 64], b2n = wp[(cn * 3 + 2) * 64];
+        // software pipeline, distance PD chunks: W_hh fragments (L2) are requested PD x 12 MFMAs ahead of use; the
+        // first PD chunks of a step were requested before the previous step's epilogue (they do not depend on h)
+#pragma unroll 1
+        for (int c0 = 0; c0 < KC; c0 += PD)
+#pragma unroll
+        for (int j = 0; j < PD; ++j) {
+            const int c = c0 + j;
+            const float4 a = *reinterpret_cast<const float4*>(hrow + 8 * c);
+            const float4 b0 = wq[j][0], b1 = wq[j][1], b2 = wq[j][2];
+            {
+                const int cn = (ABL & 16) ? 0 : (c + PD == KC + j ? j : c + PD);      // wraps into the next step's first chunks
+                wq[j][0] = wp[(cn * 3 + 0) * 64]; wq[j][1] = wp[(cn * 3 + 1) * 64]; wq[j][2] = wp[(cn * 3 + 2) * 64];
+            }
             ar = MFMA_32x32x2(a.x, b0.x, ar); au = MFMA_32x32x2(a.x, b1.x, au); anh = MFMA_32x32x2(a.x, b2.x, anh);
             ar = MFMA_32x32x2(a.y, b0.y, ar); au = MFMA_32x32x2(a.y, b1.y, au); anh = MFMA_32x32x2(a.y, b2.y, anh);
             ar = MFMA_32x32x2(a.z, b0.z, ar); au = MFMA_32x32x2(a.z, b1.z, au); anh = MFMA_32x32x2(a.z, b2.z, anh);
             ar = MFMA_32x32x2(a.w, b0.w, ar); au = MFMA_32x32x2(a.w, b1.w, au); anh = MFMA_32x32x2(a.w, b2.w, anh);
-            a = an; b0 = b0n; b1 = b1n; b2 = b2n;
         }
         float* hnext = &hs[cur ^ 1][lrow * LDH + col0 + li];
-        float* yt = y_base ? y_base + (int64_t)t * S.y_t : nullptr;
+        f32x16 ust;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const float rr = fast_sigmoid(ar[r]);
-            const float uu = fast_sigmoid(au[r]);
-            const float nn = fast_tanh(ani[r] + rr * anh[r]);
-            const float hv = nn + uu * (hprev[r] - nn);
-            ar[r] = rr; au[r] = uu; ani[r] = nn;
+            const float rr = (ABL & 8) ? ar[r] * 0.01f : fast_sigmoid(ar[r]);
+            const float uu = (ABL & 8) ? au[r] * 0.01f : fast_sigmoid(au[r]);
+            const float nn = (ABL & 8) ? (ani[r] + rr * anh[r]) * 0.01f : fast_tanh(ani[r] + rr * anh[r]);
+            const float hp = hprev[r];
+            const float hv = nn + uu * (hp - nn);
+            const float omu = 1.0f - uu;
+            ani[r] = omu * (1.0f - nn * nn);          // cA
+            au[r] = (hp - nn) * uu * omu;             // cB
+            ar[r] = rr;
+            ust[r] = uu;
             hprev[r] = hv;
             hnext[CR(r) * LDH] = hv;
-            if (yt && (full || CR(r) + lrow < nvalid)) (yt + (int64_t)CR(r) * S.y_row)[lo_y] = hv;
         }
-        if (stash) {
-            float4* sp = stash + ((((int64_t)tile * T + t) * NW + w) * 16) * 64 + lane;
+        if (!(ABL & 1) && stash) {
+            float4* sp = stash + ((((int64_t)tile * T + t) * NW + w) * 20) * 64 + lane;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                sp[(0 * 4 + q) * 64] = make_float4(ar[4 * q], ar[4 * q + 1], ar[4 * q + 2], ar[4 * q + 3]);
+                sp[(0 * 4 + q) * 64] = make_float4(ani[4 * q], ani[4 * q + 1], ani[4 * q + 2], ani[4 * q + 3]);
                 sp[(1 * 4 + q) * 64] = make_float4(au[4 * q], au[4 * q + 1], au[4 * q + 2], au[4 * q + 3]);
-                sp[(2 * 4 + q) * 64] = make_float4(ani[4 * q], ani[4 * q + 1], ani[4 * q + 2], ani[4 * q + 3]);
-                sp[(3 * 4 + q) * 64] = make_float4(anh[4 * q], anh[4 * q + 1], anh[4 * q + 2], anh[4 * q + 3]);
+                sp[(2 * 4 + q) * 64] = make_float4(ust[4 * q], ust[4 * q + 1], ust[4 * q + 2], ust[4 * q + 3]);
+                sp[(3 * 4 + q) * 64] = make_float4(ar[4 * q], ar[4 * q + 1], ar[4 * q + 2], ar[4 * q + 3]);
+                sp[(4 * 4 + q) * 64] = make_float4(anh[4 * q], anh[4 * q + 1], anh[4 * q + 2], anh[4 * q + 3]);
             }
         }
-        __syncthreads();
+        if (!(ABL & 32)) __syncthreads();
         cur ^= 1;
+        if (!(ABL & 4) && y_tile) store_h(hs[cur], t);
     }
     if (S.hn) {
 #pragma unroll
@@ -214,10 +251,11 @@ __global__ __launch_bounds__(H / 32 * 64) void gru_seq_fwd_kernel(GruFwdParams P
 }
 
 // ------------------------------------------------------------------------------------------- backward
-template <int H>
+// ABL: 1 no dG stores, 2 no stash/dy loads (first step's reused), 16 W fragments not re-streamed, 32 no barriers
+template <int H, int ABL = 0>
 __global__ __launch_bounds__(H / 32 * 64) void gru_seq_bwd_kernel(GruBwdParams P) {
-    constexpr int NW = H / 32, K3 = 3 * H, LDG = K3 + 4, KC = K3 / 8;
-    __shared__ float gs[32 * LDG];
+    constexpr int NW = H / 32, K3 = 3 * H, LDG = 4 * H + 4, KC = K3 / 8;
+    __shared__ float gs[32 * LDG];      // per row [da_r | da_z | dgh_n | dgi_n]: first 3H = MFMA A operand
     int sidx, tile;
     if (!map_block(P.nstreams, P.ntiles, sidx, tile)) return;
     const GruBwdStream& S = P.s[sidx];
@@ -227,10 +265,12 @@ __global__ __launch_bounds__(H / 32 * 64) void gru_seq_bwd_kernel(GruBwdParams P
     const int row0 = tile * 32, col0 = 32 * w, lrow = 4 * hh;
     const int nvalid = B - row0;
     const bool full = nvalid >= 32;
-    const int lo_y = lrow * (int)S.y_row + li, lo_dy = lrow * (int)S.dy_row + li, lo_dg = lrow * T * 4 * H + li;
-    const float* y_base = S.y + (int64_t)row0 * S.y_row + col0;
+    const int lo_dy = lrow * (int)S.dy_row + li;
     const float* dy_base = S.dy ? S.dy + (int64_t)row0 * S.dy_row + col0 : nullptr;
-    float* dg_base = S.dg + (int64_t)row0 * T * 4 * H + col0;
+    // dG copy pass: thread -> (row = tid / H + 2*i, float4 column tid % H), i = 0..15; LDS blocks (r,z,gh_n,gi_n) -> global (r,z,gi_n,gh_n)
+    const int crow = tid / H, cc = 4 * (tid % H), cblk = cc / H;
+    float* dg_copy = S.dg + ((int64_t)(row0 + crow) * T) * 4 * H + (cblk == 2 ? 3 * H : cblk == 3 ? 2 * H : cblk * H) + cc % H;
+    const float* gs_copy = &gs[crow * LDG + cc];
 
     f32x16 dh;
 #pragma unroll
@@ -242,87 +282,102 @@ __global__ __launch_bounds__(H / 32 * 64) void gru_seq_bwd_kernel(GruBwdParams P
     const float4* __restrict__ wpt = reinterpret_cast<const float4*>(S.wpt) + (int64_t)w * KC * 64 + lane;
     const float4* stash = reinterpret_cast<const float4*>(S.stash);
     const float* grow_a = &gs[li * LDG + 4 * hh];
-    float* gs_w = &gs[lrow * LDG + col0 + li];
+    // LDS is > 64 KiB: two lane bases keep every ds_write inside the 16-bit immediate offset range
+    float* gw_lo = &gs[lrow * LDG + col0 + li];
+    float* gw_hi = gw_lo + 16 * LDG;
 
-    // per-step operands (forward stash r,u,n,gh_n; h_{t-1}; dy_t), loaded one step ahead: the loads for
-    // step s+1 are issued right before the MFMA loop of step s into registers that are dead during it
-    float4 sr[4], su[4], sn[4], sg[4];
-    f32x16 hpv, dyv;
+    // per-step operands (coefficient stash cA,cB,u,r,gh_n and dy_t), loaded one step ahead: the loads for step
+    // s+1 are issued right before the MFMA loop of step s into registers that are dead during it
+    float4 sa[4], sb[4], su[4], sr[4], sg[4];
+    f32x16 dyv;
     auto load_step = [&](int step) {
         const int fstep = T - 1 - step;
         const int t = S.reverse ? T - 1 - fstep : fstep;
-        const int tprev = S.reverse ? t + 1 : t - 1;
-        const float4* sp = stash + ((((int64_t)tile * T + t) * NW + w) * 16) * 64 + lane;
+        const float4* sp = stash + ((((int64_t)tile * T + t) * NW + w) * 20) * 64 + lane;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            sr[q] = sp[(0 * 4 + q) * 64]; su[q] = sp[(1 * 4 + q) * 64]; sn[q] = sp[(2 * 4 + q) * 64]; sg[q] = sp[(3 * 4 + q) * 64];
+            sa[q] = sp[(0 * 4 + q) * 64]; sb[q] = sp[(1 * 4 + q) * 64]; su[q] = sp[(2 * 4 + q) * 64];
+            sr[q] = sp[(3 * 4 + q) * 64]; sg[q] = sp[(4 * 4 + q) * 64];
         }
-        const bool have_prev = fstep > 0 || S.pad;
-        const float* yp = y_base + (int64_t)tprev * S.y_t;
         const float* dyt = dy_base ? dy_base + (int64_t)t * S.dy_t : nullptr;
+        if (dyt && full) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            float hp = 0.f, dv = 0.f;
-            if (full || CR(r) + lrow < nvalid) {
-                if (have_prev) hp = (yp + (int64_t)CR(r) * S.y_row)[lo_y];
-                else if (S.h0) hp = S.h0[(int64_t)(row0 + CR(r) + lrow) * S.h0_row + col0 + li];
-                if (dyt) dv = (dyt + (int64_t)CR(r) * S.dy_row)[lo_dy];
-            }
-            hpv[r] = hp; dyv[r] = dv;
+            for (int r = 0; r < 16; ++r) dyv[r] = (dyt + (int64_t)CR(r) * S.dy_row)[lo_dy];
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                dyv[r] = (dyt && CR(r) + lrow < nvalid) ? (dyt + (int64_t)CR(r) * S.dy_row)[lo_dy] : 0.f;
         }
     };
     load_step(0);
+    constexpr int PD = 3;                       // W_hh fragment prefetch distance in chunk pairs ((KC/2) % PD == 0 for H = 32..256)
+    float4 wq[PD][2];
+#pragma unroll
+    for (int c = 0; c < PD; ++c) { wq[c][0] = wpt[(2 * c) * 64]; wq[c][1] = wpt[(2 * c + 1) * 64]; }
     for (int step = 0; step < T; ++step) {
         const int fstep = T - 1 - step;
         const int t = S.reverse ? T - 1 - fstep : fstep;
-        float* dgt = dg_base + (int64_t)t * 4 * H;
-        f32x16 dhp;
+        f32x16 acc0;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const float rv[4] = {sr[q].x, sr[q].y, sr[q].z, sr[q].w}, uv[4] = {su[q].x, su[q].y, su[q].z, su[q].w},
-                        nv[4] = {sn[q].x, sn[q].y, sn[q].z, sn[q].w}, gv[4] = {sg[q].x, sg[q].y, sg[q].z, sg[q].w};
+            const float av[4] = {sa[q].x, sa[q].y, sa[q].z, sa[q].w}, bv[4] = {sb[q].x, sb[q].y, sb[q].z, sb[q].w},
+                        uv[4] = {su[q].x, su[q].y, su[q].z, su[q].w}, rv[4] = {sr[q].x, sr[q].y, sr[q].z, sr[q].w},
+                        gv[4] = {sg[q].x, sg[q].y, sg[q].z, sg[q].w};
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int r = 4 * q + j;
-                const float hp = hpv[r], d = dh[r] + dyv[r];
-                const float rr = rv[j], uu = uv[j], nn = nv[j], gh = gv[j];
-                const float dn = d * (1.0f - uu);
-                const float du = d * (hp - nn);
-                dhp[r] = d * uu;
-                const float dan = dn * (1.0f - nn * nn);
-                const float dau = du * uu * (1.0f - uu);
-                const float dar = dan * gh * rr * (1.0f - rr);
-                const float dgh = dan * rr;
-                float* gw = gs_w + CR(r) * LDG;
-                gw[0] = dar; gw[H] = dau; gw[2 * H] = dgh;
-                if (full || CR(r) + lrow < nvalid) {
-                    float* o = dgt + (int64_t)CR(r) * T * 4 * H;
-                    o[lo_dg] = dar; o[lo_dg + H] = dau; o[lo_dg + 2 * H] = dan; o[lo_dg + 3 * H] = dgh;
-                }
+                const float d = dh[r] + dyv[r];
+                const float dan = d * av[j];
+                const float dau = d * bv[j];
+                const float dgh = dan * rv[j];
+                const float dar = dgh * gv[j] * (1.0f - rv[j]);
+                acc0[r] = d * uv[j];                               // dh carried through the update gate
+                float* gw = (r < 8 ? gw_lo : gw_hi) + (CR(r) & 15) * LDG;
+                gw[0] = dar; gw[H] = dau; gw[2 * H] = dgh; gw[3 * H] = dan;
                 dbs0 += dar; dbs1 += dau; dbs2 += dan; dbs3 += dgh;
             }
         }
-        __syncthreads();
-        if (step + 1 < T) load_step(step + 1);
-        f32x16 acc0, acc1;
+        if (!(ABL & 32)) __syncthreads();
+        if (!(ABL & 1)) {
+            // dG[b][t][da_r | da_z | dgi_n | dgh_n] leaves through LDS: 16 coalesced 16-byte stores per thread
+            float* dgt = dg_copy + (int64_t)t * 4 * H;
+            if (full) {
+#pragma unroll 4
+                for (int i = 0; i < 16; ++i)
+                    *reinterpret_cast<float4*>(dgt + (int64_t)(2 * i) * T * 4 * H) =
+                        *reinterpret_cast<const float4*>((i < 8 ? gs_copy : gs_copy + 16 * LDG) + 2 * (i & 7) * LDG);
+            } else {
+#pragma unroll 4
+                for (int i = 0; i < 16; ++i)
+                    if (crow + 2 * i < nvalid)
+                        *reinterpret_cast<float4*>(dgt + (int64_t)(2 * i) * T * 4 * H) =
+                            *reinterpret_cast<const float4*>((i < 8 ? gs_copy : gs_copy + 16 * LDG) + 2 * (i & 7) * LDG);
+            }
+        }
+        if (!(ABL & 2) && step + 1 < T) load_step(step + 1);
+        f32x16 acc1;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { acc0[r] = dhp[r]; acc1[r] = 0.f; }
-        float4 b0 = wpt[0], b1 = wpt[64];
-#pragma unroll 2
-        for (int c = 0; c < KC; c += 2) {
-            const int cn = c + 2 < KC ? c + 2 : c;
+        for (int r = 0; r < 16; ++r) acc1[r] = 0.f;
+#pragma unroll 1
+        for (int c0 = 0; c0 < KC / 2; c0 += PD)
+#pragma unroll
+        for (int j = 0; j < PD; ++j) {
+            const int c = 2 * (c0 + j);
             const float4 a0 = *reinterpret_cast<const float4*>(grow_a + 8 * c);
             const float4 a1 = *reinterpret_cast<const float4*>(grow_a + 8 * c + 8);
-            const float4 b0n = wpt[cn * 64], b1n = wpt[(cn + 1) * 64];      // weights of the next chunk pair (L2) in flight
+            const float4 b0 = wq[j][0], b1 = wq[j][1];
+            {
+                const int cn = (ABL & 16) ? 0 : (c0 + j + PD == KC / 2 + j ? 2 * j : c + 2 * PD);   // wraps into the next step
+                wq[j][0] = wpt[cn * 64]; wq[j][1] = wpt[(cn + 1) * 64];
+            }
             acc0 = MFMA_32x32x2(a0.x, b0.x, acc0); acc1 = MFMA_32x32x2(a1.x, b1.x, acc1);
             acc0 = MFMA_32x32x2(a0.y, b0.y, acc0); acc1 = MFMA_32x32x2(a1.y, b1.y, acc1);
             acc0 = MFMA_32x32x2(a0.z, b0.z, acc0); acc1 = MFMA_32x32x2(a1.z, b1.z, acc1);
             acc0 = MFMA_32x32x2(a0.w, b0.w, acc0); acc1 = MFMA_32x32x2(a1.w, b1.w, acc1);
-            b0 = b0n; b1 = b1n;
         }
 #pragma unroll
         for (int r = 0; r < 16; ++r) dh[r] = acc0[r] + acc1[r];
-        __syncthreads();
+        if (!(ABL & 32)) __syncthreads();
     }
     if (S.dh0) {
 #pragma unroll
@@ -342,13 +397,32 @@ __global__ __launch_bounds__(H / 32 * 64) void gru_seq_bwd_kernel(GruBwdParams P
 }
 
 // ------------------------------------------------------------------------------------------- host
+#include <stdlib.h>
+static int abl_env(const char* name) { const char* e = getenv(name); return e ? atoi(e) : 0; }
+#define ABL_CASE(K, H, A, P, st) case A: hipLaunchKernelGGL((K<H, A>), dim3(grid_blocks(P.nstreams, P.ntiles)), dim3(H / 32 * 64), 0, st, P); return;
+
 template <int H>
 static void launch_fwd(const GruFwdParams& P, hipStream_t st) {
-    hipLaunchKernelGGL(gru_seq_fwd_kernel<H>, dim3(grid_blocks(P.nstreams, P.ntiles)), dim3(H / 32 * 64), 0, st, P);
+#ifndef VAME_EMU
+    if (H == 256) switch (abl_env("VAME_ABL_FWD")) {      // profiling-only ablations (tools/microbench.py)
+        ABL_CASE(gru_seq_fwd_kernel, 256, 1, P, st) ABL_CASE(gru_seq_fwd_kernel, 256, 2, P, st) ABL_CASE(gru_seq_fwd_kernel, 256, 4, P, st)
+        ABL_CASE(gru_seq_fwd_kernel, 256, 8, P, st) ABL_CASE(gru_seq_fwd_kernel, 256, 16, P, st) ABL_CASE(gru_seq_fwd_kernel, 256, 32, P, st)
+        ABL_CASE(gru_seq_fwd_kernel, 256, 7, P, st) ABL_CASE(gru_seq_fwd_kernel, 256, 63, P, st)
+        default: break;
+    }
+#endif
+    hipLaunchKernelGGL((gru_seq_fwd_kernel<H, 0>), dim3(grid_blocks(P.nstreams, P.ntiles)), dim3(H / 32 * 64), 0, st, P);
 }
 template <int H>
 static void launch_bwd(const GruBwdParams& P, hipStream_t st) {
-    hipLaunchKernelGGL(gru_seq_bwd_kernel<H>, dim3(grid_blocks(P.nstreams, P.ntiles)), dim3(H / 32 * 64), 0, st, P);
+#ifndef VAME_EMU
+    if (H == 256) switch (abl_env("VAME_ABL_BWD")) {
+        ABL_CASE(gru_seq_bwd_kernel, 256, 1, P, st) ABL_CASE(gru_seq_bwd_kernel, 256, 2, P, st) ABL_CASE(gru_seq_bwd_kernel, 256, 3, P, st)
+        ABL_CASE(gru_seq_bwd_kernel, 256, 16, P, st) ABL_CASE(gru_seq_bwd_kernel, 256, 32, P, st) ABL_CASE(gru_seq_bwd_kernel, 256, 51, P, st)
+        default: break;
+    }
+#endif
+    hipLaunchKernelGGL((gru_seq_bwd_kernel<H, 0>), dim3(grid_blocks(P.nstreams, P.ntiles)), dim3(H / 32 * 64), 0, st, P);
 }
 
 extern "C" int vame_gru_seq_fwd_f32(const int64_t* desc, int nstreams, int B, int H, void* stream) {

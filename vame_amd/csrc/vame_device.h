@@ -10,6 +10,7 @@ typedef f32x4_emu f32x4;
 #define MFMA_16x16x4(a, b, c) emu_mfma_16x16x4((a), (b), (c))
 #define VAME_DYN_SMEM(name) char* name = emu::dyn_smem()
 #define SETPRIO(n)
+#define SCHED_FENCE()
 #define VAME_EXPF(x) expf(x)
 #define VAME_RCP(x) (1.0f / (x))
 #else
@@ -21,6 +22,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define MFMA_16x16x4(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
 #define VAME_DYN_SMEM(name) extern __shared__ __attribute__((aligned(16))) char name[]
 #define SETPRIO(n) __builtin_amdgcn_s_setprio(n)
+#define SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)   /* keep the scheduler from merging phases (register pressure) */
 #define VAME_EXPF(x) __expf(x)
 #define VAME_RCP(x) __builtin_amdgcn_rcpf(x)   /* v_rcp_f32, 1 ulp */
 #endif
