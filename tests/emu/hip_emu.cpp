@@ -1,5 +1,6 @@
 // Fiber scheduler for tests/emu/hip_emu.h (test infrastructure).
 #include "hip_emu.h"
+#include <memory>
 
 thread_local uint3 threadIdx, blockIdx;
 thread_local dim3 blockDim, gridDim;
@@ -28,7 +29,7 @@ emu_switch:
 )");
 
 namespace emu {
-static constexpr size_t STACK = 256 * 1024;
+static constexpr size_t STACK = 96 * 1024;
 
 static void fiber_entry() {
     BlockCtx* b = g_blk;
@@ -82,8 +83,8 @@ void launch_impl(dim3 grid, dim3 block, size_t shmem, std::function<void()> body
         b.fibers.resize(nthreads);
         b.waves.resize(nthreads / WAVE);
         b.dyn_smem.assign(shmem + 64, 0);
-        std::vector<char> stacks((size_t)nthreads * STACK);
-        for (int t = 0; t < nthreads; ++t) b.fibers[t].stack = stacks.data() + (size_t)t * STACK;
+        std::unique_ptr<char[]> stacks(new char[(size_t)nthreads * STACK]);      // not zeroed: only touched pages get committed
+        for (int t = 0; t < nthreads; ++t) b.fibers[t].stack = stacks.get() + (size_t)t * STACK;
         for (;;) {
             long i = next.fetch_add(1);
             if (i >= nblocks) break;

@@ -1,0 +1,72 @@
+"""The C-ABI shared library loads without a GPU and exports every symbol include/vame_hip.h declares
+(no compute calls here); the argument validation / error-code path is exercised through the emulator build."""
+import ctypes
+import os
+import re
+import subprocess
+
+import pytest
+import torch
+
+from conftest import ROOT
+
+
+def header_symbols():
+    txt = open(os.path.join(ROOT, "include", "vame_hip.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(vame_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_header_matches_python_binding():
+    from vame_amd import _lib
+    assert sorted(_lib.EXPORTS) == header_symbols()
+
+
+def test_product_library_exports_declared_abi():
+    subprocess.run(["make", "-s", "vame_amd/libvame_hip.so"], cwd=ROOT, check=True)
+    lib = ctypes.CDLL(os.path.join(ROOT, "vame_amd", "libvame_hip.so"))
+    for name in header_symbols():
+        assert hasattr(lib, name), name
+    assert lib.vame_version() >= 100
+
+
+def test_error_codes_and_messages(emu):
+    L = emu.lib()
+    x = torch.zeros(16)
+    rc = L.vame_gemm_f32(0, 4, 4, x.data_ptr(), 4, 0, 0, 0, x.data_ptr(), 4, 0, 0, 0, None, x.data_ptr(), 4, 0, 1, None, None)
+    assert rc == -2 and b"empty problem" in L.vame_last_error()
+    rc = L.vame_gemm_f32(4, 4, 4, x.data_ptr(), 4, 1, 0, 0, x.data_ptr(), 4, 0, 0, 0, None, x.data_ptr(), 4, 0, 1, None, None)
+    assert rc == -4                                            # A k-major with B n-major: unsupported layout
+    rc = L.vame_gru_seq_fwd_f32(None, 1, 4, 32, None)
+    assert rc == -1
+    d = torch.zeros(16, dtype=torch.int64)
+    rc = L.vame_gru_seq_fwd_f32(d.data_ptr(), 1, 4, 48, None)
+    assert rc in (-1, -4)
+    rc = L.vame_window_gather_f32(x.data_ptr(), 4, 2, None, 0, 1, 8, x.data_ptr(), None)
+    assert rc == -2 and b"bad shape" in L.vame_last_error()
+    with pytest.raises(emu.VameHipError):
+        emu.check(rc, "vame_window_gather_f32")
+
+
+def test_no_cpu_fallback_without_library(monkeypatch):
+    """The product binding refuses to run without libvame_hip.so instead of falling back."""
+    from vame_amd import _lib
+    saved = (_lib._lib, _lib._emulated)
+    _lib._lib, _lib._emulated = None, False
+    monkeypatch.setattr(_lib, "LIB_PATH", os.path.join(ROOT, "vame_amd", "does_not_exist.so"))
+    try:
+        with pytest.raises(_lib.VameHipError):
+            _lib.lib()
+    finally:
+        _lib._lib, _lib._emulated = saved
+
+
+def test_cpu_tensors_rejected_by_product_path():
+    from vame_amd import _lib, ops
+    saved = (_lib._lib, _lib._emulated)
+    _lib._lib, _lib._emulated = None, False
+    try:
+        with pytest.raises(_lib.VameHipError):
+            ops.axpy(torch.zeros(4), 1.0, torch.zeros(4), 4)
+    finally:
+        _lib._lib, _lib._emulated = saved

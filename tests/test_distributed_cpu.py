@@ -1,0 +1,88 @@
+"""Data-parallel path on CPU: 2 gloo ranks run the emulated kernels on disjoint window shards, all-reduce the flat
+gradient bucket once, and must hold identical weights equal to a single process that averages the two shard gradients."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import ROOT, golden_weights, load_golden
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), VAME_EMU_THREADS="2")
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from vame_amd import _lib
+    _lib._load_for_tests(os.path.join(ROOT, "tests", "emu", "libvame_emu.so"))
+    from model_cases import build_model
+    from vame_amd.model.rnn_vae import FusedAdamAMSGrad, allreduce_gradients
+    from vame_amd.analysis.pose_segmentation import embed_series
+    g = load_golden("step_tiny")
+    model, (T, F, Z, H, FS, fut, sp) = build_model(g, "cpu")
+    model.train()
+    opt = FusedAdamAMSGrad(model, lr=5e-4)
+    win = torch.cat([torch.from_numpy(g["x"]), torch.from_numpy(g["xfut"])], 1)
+    eps = torch.from_numpy(g["eps"])
+    sl = slice(rank * 4, rank * 4 + 4)                           # rank-local batch of 4 windows
+    model.loss_step(win[sl].contiguous(), 1.0, beta=1.0, kloss=Z, klmbda=0.1, bsize=4, eps=eps[sl].contiguous())
+    gscale = allreduce_gradients(model)
+    opt.step(gscale=gscale)
+    flat_p, flat_g = model.flat_parameters()
+    np.save(os.path.join(out_dir, f"p{rank}.npy"), flat_p.numpy())
+    np.save(os.path.join(out_dir, f"g{rank}.npy"), flat_g.numpy() * gscale)
+    model.eval()
+    emb = load_golden("embed_tiny")
+    m2, _ = build_model(emb, "cpu")
+    m2.eval()
+    shard, (lo, hi) = embed_series(m2, emb["data"][:, :70], batch=16, rank=rank, world=world)   # sharded by window index
+    np.save(os.path.join(out_dir, f"e{rank}.npy"), np.concatenate([[lo, hi], shard.numpy().ravel()]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_gradient_allreduce_and_sharded_embedding(emu, tmp_path):
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    p0, p1 = np.load(tmp_path / "p0.npy"), np.load(tmp_path / "p1.npy")
+    np.testing.assert_array_equal(p0, p1)                                    # replicas stay in lock-step
+    # single-process reference: average of the two shard gradients, same Adam step
+    from model_cases import build_model
+    from vame_amd.model.rnn_vae import FusedAdamAMSGrad
+    g = load_golden("step_tiny")
+    model, (T, F, Z, H, FS, fut, sp) = build_model(g, "cpu")
+    model.train()
+    win = torch.cat([torch.from_numpy(g["x"]), torch.from_numpy(g["xfut"])], 1)
+    eps = torch.from_numpy(g["eps"])
+    acc = None
+    for r in range(world):
+        sl = slice(r * 4, r * 4 + 4)
+        model.loss_step(win[sl].contiguous(), 1.0, beta=1.0, kloss=Z, klmbda=0.1, bsize=4, eps=eps[sl].contiguous())
+        gr = model.flat_parameters()[1].clone()
+        acc = gr if acc is None else acc + gr
+    np.testing.assert_allclose(np.load(tmp_path / "g0.npy"), (acc / world).numpy(), rtol=1e-6, atol=1e-7)
+    model.flat_parameters()[1].copy_(acc)
+    opt = FusedAdamAMSGrad(model, lr=5e-4)
+    opt.step(gscale=1.0 / world)
+    np.testing.assert_allclose(p0, model.flat_parameters()[0].numpy(), rtol=1e-6, atol=1e-7)
+    # sharded embedding: the two shards tile [0, N-T) and equal the reference loop's rows
+    emb = load_golden("embed_tiny")
+    rows = []
+    for r in range(world):
+        e = np.load(tmp_path / f"e{r}.npy")
+        lo, hi = int(e[0]), int(e[1])
+        rows.append((lo, hi, e[2:].reshape(hi - lo, -1)))
+    assert rows[0][0] == 0 and rows[0][1] == rows[1][0] and rows[1][1] == 70 - 30
+    np.testing.assert_allclose(np.concatenate([rows[0][2], rows[1][2]]), emb["latent"][:40], atol=1e-5)

@@ -1,0 +1,88 @@
+"""End-to-end plumbing of vame.train_model() / vame.pose_segmentation() on a synthetic project (config 1 shape of
+BASELINE.json, tiny hidden size) through the emulator build: file layout, loss arrays, checkpoint format, the
+embedding output contract -- compared with the run of the REFERENCE driver captured in tests/golden/train_model_run.npz."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+import yaml
+
+from conftest import load_golden
+
+
+@pytest.fixture(scope="module")
+def project(tmp_path_factory, emu):
+    g = load_golden("train_model_run")
+    cfg = json.loads(str(g["cfg_json"]))
+    root = tmp_path_factory.mktemp("proj")
+    os.makedirs(root / "data" / "train")
+    os.makedirs(root / "model")
+    np.save(root / "data" / "train" / "train_seq.npy", g["train_seq"])
+    np.save(root / "data" / "train" / "test_seq.npy", g["test_seq"])
+    cfg.update(project_path=str(root), n_cluster=4, parameterization="kmeans", individual_parameterization=False,
+               video_sets=["vid1"], all_data="yes", hmm_trained=False, random_state_kmeans=42, n_init_kmeans=3)
+    os.makedirs(root / "data" / "vid1")
+    np.save(root / "data" / "vid1" / "vid1-PE-seq-clean.npy", g["train_seq"][:, :120])
+    os.makedirs(root / "results" / "vid1")
+    with open(root / "config.yaml", "w") as f:
+        yaml.safe_dump(cfg, f)
+    return root, cfg, g
+
+
+def test_train_model_files_and_losses(project):
+    import vame_amd as vame
+    root, cfg, g = project
+    np.random.seed(0)
+    vame.train_model(str(root / "config.yaml"))
+    ld = root / "model" / "model_losses"
+    names = sorted(os.listdir(ld))
+    assert names == sorted(k + ".npy" for k in g if k.endswith("_VAME"))
+    for n in names:
+        mine, ref = np.load(ld / n), g[n[:-4]]
+        assert mine.shape == ref.shape, n
+    # same annealing schedule; first-epoch losses are the untrained model on statistically identical batches
+    np.testing.assert_allclose(np.load(ld / "weight_values_VAME.npy"), g["weight_values_VAME"])
+    mine, ref = np.load(ld / "mse_train_losses_VAME.npy"), g["mse_train_losses_VAME"]
+    assert abs(mine[0] - ref[0]) / ref[0] < 0.1
+    assert mine[-1] < mine[0]                                   # it learns
+    assert sorted(os.listdir(root / "model" / "best_model")) == list(g["files_best"])
+    assert sorted(os.listdir(root / "model" / "best_model" / "snapshots")) == list(g["files_snap"])
+    sd = torch.load(root / "model" / "best_model" / "VAME_demo.pkl")
+    assert list(sd.keys()) == list(g["sd_keys"])
+    assert [str(tuple(v.shape)) for v in sd.values()] == list(g["sd_shapes"])
+    assert os.path.exists(root / "data" / "train" / "seq_mean.npy")
+
+
+def test_pose_segmentation_outputs(project):
+    import vame_amd as vame
+    root, cfg, g = project
+    vame.pose_segmentation(str(root / "config.yaml"))
+    out = root / "results" / "vid1" / "VAME" / "kmeans-4"
+    lat = np.load(out / "latent_vector_vid1.npy")
+    assert lat.shape == (120 - cfg["time_window"], cfg["zdims"]) and lat.dtype == np.float32     # N-T windows
+    lab = np.load(out / "4_km_label_vid1.npy")
+    assert lab.shape == (lat.shape[0],) and set(np.unique(lab)) <= set(range(4))
+    assert np.load(out / "cluster_center_vid1.npy").shape == (4, cfg["zdims"])
+    assert np.load(out / "motif_usage_vid1.npy").sum() == lat.shape[0]
+    # the embedding is the eval-mode mean of the trained model on un-normalised windows (pose_segmentation.py:84-96)
+    from oracle import vame_oracle as vo
+    sd = torch.load(root / "model" / "best_model" / "VAME_demo.pkl")
+    p = {k: v.numpy() for k, v in sd.items()}
+    H = cfg["hidden_size_layer_1"]
+    ref = vo.embed_series(p, np.load(root / "data" / "vid1" / "vid1-PE-seq-clean.npy"),
+                          vo.Spec(T=30, F=24, Z=30, H=H, FS=15), batch=64)
+    np.testing.assert_allclose(lat, ref, atol=2e-5)
+
+
+def test_read_config_contract(tmp_path):
+    from vame_amd.util.auxiliary import read_config
+    with pytest.raises(FileNotFoundError):
+        read_config(tmp_path / "missing.yaml")
+    p = tmp_path / "config.yaml"
+    with open(p, "w") as f:
+        yaml.safe_dump(dict(project_path="/somewhere/else", Project="x"), f)
+    cfg = read_config(str(p))
+    assert cfg["project_path"] == str(tmp_path)                 # rewritten when the folder moved (auxiliary.py:139-142)
+    assert yaml.safe_load(open(p))["project_path"] == str(tmp_path)
