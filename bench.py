@@ -133,6 +133,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--batch", type=int, default=B_LOCAL)
+    ap.add_argument("--dump-kernels", action="store_true", help="per-launch-group table on stderr")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -196,6 +197,9 @@ def main():
         value = B_LOCAL * world * args.steps / dt
         agg = profile_kernels(model, loader)
         total_ms = sum(d["ms"] for d in agg.values())
+        if args.dump_kernels:
+            for k, d in sorted(agg.items(), key=lambda kv: -kv[1]["ms"]):
+                print(f"{k:60s} x{d['launches']:4.0f} {d['ms']*1e3:9.1f} us/step {d['flops']/max(d['ms'],1e-9)/1e9:7.1f} TF", file=sys.stderr)
         dom_key = max(agg, key=lambda k: agg[k]["ms"])
         dom = agg[dom_key]
         per_launch_ms = dom["ms"] / dom["launches"]

@@ -39,12 +39,14 @@ int vame_window_gather_f32(const float* X, int64_t N, int F, const int64_t* star
  *   Row i of an operand lives at (seg ? (i/seg)*seg_stride + (i%seg)*ld : i*ld): two-level
  *   addressing for (batch,time) rows of padded sequences and (ld = 0) time-constant GRU inputs.
  *   accumulate != 0: C += result.  splitk > 1 needs ws of splitk*M*N floats (reduced internally).
+ *   a_gap != 0 (k-major A only): column m >= a_gap_at of A is read at m + a_gap, i.e. a block of a wider
+ *   row is skipped -- dW_hh reads [da_r|da_z|dgh_n] out of dG = [da_r|da_z|dgi_n|dgh_n] in one call.
  * Replaces the nn.Linear / nn.GRU input-projection and all weight-gradient contractions that
  * torch autograd performs for vame/model/rnn_model.py:34-35,56-57,91-97,125-131. */
 int vame_gemm_f32(int M, int N, int K, const float* A, int64_t lda, int a_kmajor, int64_t a_seg,
                   int64_t a_seg_stride, const float* B, int64_t ldb, int b_kmajor, int64_t b_seg,
                   int64_t b_seg_stride, const float* bias, float* C, int64_t ldc, int accumulate,
-                  int splitk, float* ws, void* stream);
+                  int splitk, float* ws, int a_gap_at, int a_gap, void* stream);
 
 /* Pack one GRU layer-direction's recurrent weights for the sequence kernels.
  *   W_hh (3H,H), b_ih/b_hh (3H) -> wp_fwd (3H*H, MFMA B-fragment order for h W_hh^T),

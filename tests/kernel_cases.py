@@ -53,6 +53,10 @@ def check_gemm_cases(dev, small=True):
     C = torch.zeros(16, 10, device=dev)
     ops.gemm(16, 10, Bq * Tq, Operand(T_(dG, dev), 16), 1, Operand(T_(z, dev), 0, seg=Tq, seg_stride=10), 1, C, 10)
     np.testing.assert_allclose(N_(C), dG.T @ np.repeat(z, Tq, 0), atol=1e-4)
+    # column gap on the k-major A operand: rows of C come from columns [0,8) and [12,16) of dG
+    C = torch.zeros(12, 10, device=dev)
+    ops.gemm(12, 10, Bq * Tq, Operand(T_(dG, dev), 16), 1, Operand(T_(z, dev), 0, seg=Tq, seg_stride=10), 1, C, 10, a_gap_at=8, a_gap=4)
+    np.testing.assert_allclose(N_(C), np.concatenate([dG[:, :8], dG[:, 12:]], 1).T @ np.repeat(z, Tq, 0), atol=1e-4)
 
 
 def _gru_weights(rng, I, H):

@@ -33,9 +33,9 @@ def test_product_library_exports_declared_abi():
 def test_error_codes_and_messages(emu):
     L = emu.lib()
     x = torch.zeros(16)
-    rc = L.vame_gemm_f32(0, 4, 4, x.data_ptr(), 4, 0, 0, 0, x.data_ptr(), 4, 0, 0, 0, None, x.data_ptr(), 4, 0, 1, None, None)
+    rc = L.vame_gemm_f32(0, 4, 4, x.data_ptr(), 4, 0, 0, 0, x.data_ptr(), 4, 0, 0, 0, None, x.data_ptr(), 4, 0, 1, None, 0, 0, None)
     assert rc == -2 and b"empty problem" in L.vame_last_error()
-    rc = L.vame_gemm_f32(4, 4, 4, x.data_ptr(), 4, 1, 0, 0, x.data_ptr(), 4, 0, 0, 0, None, x.data_ptr(), 4, 0, 1, None, None)
+    rc = L.vame_gemm_f32(4, 4, 4, x.data_ptr(), 4, 1, 0, 0, x.data_ptr(), 4, 0, 0, 0, None, x.data_ptr(), 4, 0, 1, None, 0, 0, None)
     assert rc == -4                                            # A k-major with B n-major: unsupported layout
     rc = L.vame_gru_seq_fwd_f32(None, 1, 4, 32, None)
     assert rc == -1

@@ -10,6 +10,7 @@ struct GemmOperand {
     const float* p;
     int64_t ld, seg, seg_stride;   // row i -> (seg ? (i/seg)*seg_stride + (i%seg)*ld : i*ld)
     int vec;                       // 16-byte loads legal
+    int gap_at, gap;               // k-major operands: column x >= gap_at is read at x + gap (skips a block of a wider row)
 };
 struct GemmParams {
     GemmOperand A, B;
@@ -84,13 +85,14 @@ struct TileIO {
             }
         } else {
             const int gx = x0 + 4 * (tid % XQ);
+            const int gxs = gx + (gx >= o.gap_at ? o.gap : 0);       // source column (gap_at, gap multiples of 4)
             int b = seg_b, t = seg_t;
 #pragma unroll
             for (int it = 0; it < PER; ++it) {
                 const int gk = k0 + tid / XQ + it * kstep;
                 float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
                 if ((ITEMS % NT == 0 || tid + it * NT < ITEMS) && gk < ke && gx < X) {
-                    const float* src = o.p + (o.seg ? (int64_t)b * o.seg_stride + (int64_t)t * o.ld : (int64_t)t * o.ld) + gx;
+                    const float* src = o.p + (o.seg ? (int64_t)b * o.seg_stride + (int64_t)t * o.ld : (int64_t)t * o.ld) + gxs;
                     if (o.vec && gx + 3 < X) r = *reinterpret_cast<const float4*>(src);
                     else { r.x = src[0]; if (gx + 1 < X) r.y = src[1]; if (gx + 2 < X) r.z = src[2]; if (gx + 3 < X) r.w = src[3]; }
                 }
@@ -229,14 +231,16 @@ static int operand_vec(const float* p, int64_t ld, int64_t seg, int64_t seg_stri
 extern "C" int vame_gemm_f32(int M, int N, int K, const float* A, int64_t lda, int a_kmajor, int64_t a_seg,
                              int64_t a_seg_stride, const float* B, int64_t ldb, int b_kmajor, int64_t b_seg,
                              int64_t b_seg_stride, const float* bias, float* C, int64_t ldc, int accumulate, int splitk,
-                             float* ws, void* stream) {
+                             float* ws, int a_gap_at, int a_gap, void* stream) {
     VAME_CHECK_ARG(M >= 1 && N >= 1 && K >= 1, VAME_E_SHAPE, "gemm: empty problem M=%d N=%d K=%d", M, N, K);
     VAME_CHECK_ARG(A && B && C, VAME_E_BADARG, "gemm: null operand");
     VAME_CHECK_ARG(!(a_kmajor && !b_kmajor), VAME_E_UNSUPPORTED, "gemm: A k-major with B n-major is not provided");
     VAME_CHECK_ARG(splitk >= 1 && (splitk == 1 || ws), VAME_E_BADARG, "gemm: splitk=%d needs a workspace", splitk);
     GemmParams p;
-    p.A = {A, lda, a_seg, a_seg_stride, operand_vec(A, lda, a_seg, a_seg_stride)};
-    p.B = {B, ldb, b_seg, b_seg_stride, operand_vec(B, ldb, b_seg, b_seg_stride)};
+    VAME_CHECK_ARG(a_gap == 0 || (a_kmajor && a_gap_at % 4 == 0 && a_gap % 4 == 0), VAME_E_BADARG,
+                   "gemm: a column gap needs a k-major A and multiples of 4");
+    p.A = {A, lda, a_seg, a_seg_stride, operand_vec(A, lda, a_seg, a_seg_stride), a_gap ? a_gap_at : 0x7fffffff, a_gap};
+    p.B = {B, ldb, b_seg, b_seg_stride, operand_vec(B, ldb, b_seg, b_seg_stride), 0x7fffffff, 0};
     p.bias = bias; p.C = C; p.ldc = ldc; p.ws = ws;
     p.M = M; p.N = N; p.K = K; p.accumulate = accumulate;
     int kper = (int)(cdiv64(cdiv64(K, splitk), 32) * 32);

@@ -37,22 +37,25 @@ struct GruBwdStream {
 };
 struct GruBwdParams { GruBwdStream s[8]; int nstreams; int B; int ntiles; };
 
-// blockIdx -> (stream, tile).  Workgroup b is dispatched to XCD b%8 (observed, speed only): when the
-// stream count divides 8 each XCD serves a single stream so its 4 MiB L2 keeps that stream's W_hh.
+// blockIdx -> (stream, tile).  Workgroup b is dispatched to XCD b%8 (observed, speed only).  Streams are dealt to
+// XCD parity classes so that one XCD's 4 MiB L2 keeps at most two streams' W_hh, and -- for 4 streams ordered
+// (long, long, short, short), i.e. decoder f/b + future-decoder f/b -- every XCD gets the same amount of work:
+// XCD x serves stream x&1 first (its tiles x>>1, x>>1 + 4, ...) and then stream 2 + (x&1).
 __device__ __forceinline__ bool map_block(int nstreams, int ntiles, int& s, int& tile) {
-    const int bid = blockIdx.x;
-    if (8 % nstreams == 0) {
-        const int xcd = bid & 7, q = bid >> 3, per = 8 / nstreams;
-        s = xcd % nstreams;
-        tile = q * per + xcd / nstreams;
-    } else {
-        s = bid % nstreams;
-        tile = bid / nstreams;
-    }
+    const int bid = blockIdx.x, xcd = bid & 7, q = bid >> 3;
+    if (nstreams == 1) { s = 0; tile = q * 8 + xcd; }
+    else if (nstreams == 2) { s = xcd & 1; tile = q * 4 + (xcd >> 1); }
+    else if (nstreams == 4) {
+        const int per = (ntiles + 3) >> 2;
+        if (q < per) { s = xcd & 1; tile = q * 4 + (xcd >> 1); }
+        else { s = 2 + (xcd & 1); tile = (q - per) * 4 + (xcd >> 1); }
+    } else { s = bid % nstreams; tile = bid / nstreams; }
     return tile < ntiles;
 }
 static int grid_blocks(int nstreams, int ntiles) {
-    if (8 % nstreams == 0) { const int per = 8 / nstreams; return (int)cdiv64(ntiles, per) * 8; }
+    if (nstreams == 1) return (int)cdiv64(ntiles, 8) * 8;
+    if (nstreams == 2) return (int)cdiv64(ntiles, 4) * 8;
+    if (nstreams == 4) return 2 * (int)cdiv64(ntiles, 4) * 8;
     return nstreams * ntiles;
 }
 

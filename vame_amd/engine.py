@@ -132,11 +132,12 @@ class VAEEngine:
             sk = sk // 8 * 8
         return sk
 
-    def _gemm_wgrad(self, M, N, K, A, B, gname, row_off=0):
+    def _gemm_wgrad(self, M, N, K, A, B, gname, row_off=0, gap_at=0, gap=0):
         """flat_g[gname][row_off:row_off+M, :N] = A^T B with split-K over K = batch x time."""
         sk = self._splitk(M, N, K)
         ws = self.ws.get("splitk", max(sk * M * N, 1), self.dev) if sk > 1 else None
-        ops.gemm(M, N, K, A, 1, B, 1, self.g, N, c_off=self.table.off(gname) + row_off * N, splitk=sk, ws=ws)
+        ops.gemm(M, N, K, A, 1, B, 1, self.g, N, c_off=self.table.off(gname) + row_off * N, splitk=sk, ws=ws,
+                 a_gap_at=gap_at, a_gap=gap)
 
     # ------------------------------------------------------------------ forward
     def _gru_fwd_stream(self, d: GruDir, gi, gi_row, gi_t, h0, h0_off, Y, y_cols, y_T, dirn, hn, hn_off, hn_row, stash, T,
@@ -275,8 +276,8 @@ class VAEEngine:
             self._gemm_wgrad(3 * H, x_K, B, Operand(dgsum, 3 * H), Operand(z, x_K), d.w_ih)
         # h_{t-1} rows: padded slot t (forward dir) / t+2 (reverse dir) of the (B,T+2,2H) sequence
         hp = Operand(Yseq, 2 * H, off=(2 * 2 * H if dirn else 0) + dirn * H, seg=T, seg_stride=(T + 2) * 2 * H)
-        self._gemm_wgrad(2 * H, H, K, dG_i, hp, d.w_hh, row_off=0)
-        self._gemm_wgrad(H, H, K, Operand(dG, 4 * H, off=3 * H), hp, d.w_hh, row_off=2 * H)
+        # dW_hh = [da_r | da_z | dgh_n]^T h_{t-1}: columns 0..2H and 3H..4H of dG in one call (skip the dgi_n block)
+        self._gemm_wgrad(3 * H, H, K, dG_i, hp, d.w_hh, gap_at=2 * H, gap=H)
         ob_i, ob_h = t.off(d.b_ih), t.off(d.b_hh)
         ops.colsum(dbias, 0, ntiles, 3 * H, 4 * H, g, ob_i)
         ops.colsum(dbias, 0, ntiles, 2 * H, 4 * H, g, ob_h)

@@ -38,13 +38,14 @@ class Operand:
         self.t, self.off, self.ld, self.seg, self.seg_stride = t, off, ld, seg, seg_stride
 
 
-def gemm(M, N, K, A, a_kmajor, B, b_kmajor, C, ldc, c_off=0, bias=None, accumulate=False, splitk=1, ws=None):
+def gemm(M, N, K, A, a_kmajor, B, b_kmajor, C, ldc, c_off=0, bias=None, accumulate=False, splitk=1, ws=None, a_gap_at=0,
+         a_gap=0):
     L = _lib.lib()
     if splitk > 1:
         assert ws is not None and ws.numel() >= splitk * M * N, "split-K workspace too small"
     rc = L.vame_gemm_f32(M, N, K, _ptr(A.t, A.off), A.ld, int(a_kmajor), A.seg, A.seg_stride, _ptr(B.t, B.off), B.ld,
                          int(b_kmajor), B.seg, B.seg_stride, _ptr(bias), _ptr(C, c_off), ldc, int(accumulate), splitk,
-                         _ptr(ws), _stream())
+                         _ptr(ws), a_gap_at, a_gap, _stream())
     _lib.check(rc, "vame_gemm_f32")
 
 
