@@ -13,5 +13,9 @@ tests/emu/libvame_emu.so: $(SRC) $(HDR) tests/emu/hip_emu.h tests/emu/hip_emu.cp
 	$(HOSTCXX) -DVAME_EMU -O2 -std=c++17 -fPIC -shared -pthread -Itests/emu -Wno-unknown-attributes \
 	    -o $@ $(foreach f,$(SRC),-x c++ $(f)) -x c++ tests/emu/hip_emu.cpp
 
+# tuning build with all GEMM variants selectable through VAME_GEMM_VAR (tools/microbench.py ab)
+ab: $(SRC) $(HDR)
+	$(HIPCC) --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -DVAME_GEMM_AB -o vame_amd/libvame_hip.so $(SRC)
+
 clean:
 	rm -f vame_amd/libvame_hip.so tests/emu/libvame_emu.so

@@ -91,6 +91,9 @@ class VAEEngine:
         self.fut = ([GruDir("decoder_future.rnn_pred", "_l0", H, Z, self.dev),
                      GruDir("decoder_future.rnn_pred", "_l0_reverse", H, Z, self.dev)] if spec.future else [])
         self.ws = Workspace()
+        # the single-workgroup Jacobi solve of the nuclear-norm loss (~0.27 ms) runs on a side stream beside the decoder
+        self.side = torch.cuda.Stream(device=self.dev) if self.dev.type == "cuda" else None
+        self._ev_z = self._ev_nuc = None
         self.packed_version = -1
         self.version = 0          # bumped by the owner whenever flat_p changes
         self._B = None
@@ -182,9 +185,9 @@ class VAEEngine:
         logvar, z = self.buf("logvar", B, Z), self.buf("z", B, Z)
         hn_op = Operand(hn, 4 * H)
         ops.gemm(B, Z, 4 * H, hn_op, 0, self.P("lmbda.hidden_to_mean.weight", 4 * H), 0, mu, Z,
-                 bias=self._pv("lmbda.hidden_to_mean.bias"))
+                 bias=self._pv("lmbda.hidden_to_mean.bias"), splitk=0)
         ops.gemm(B, Z, 4 * H, hn_op, 0, self.P("lmbda.hidden_to_logvar.weight", 4 * H), 0, lvr, Z,
-                 bias=self._pv("lmbda.hidden_to_logvar.bias"))
+                 bias=self._pv("lmbda.hidden_to_logvar.bias"), splitk=0)
         losses = self.buf("losses", 8)
         losses.zero_()
         ops.latent_fwd(mu, lvr, eps, B, Z, s.softplus, training, logvar, z, losses[LOSS_KLSUM:] if want_kl else None)
@@ -222,11 +225,34 @@ class VAEEngine:
                      bias=self._pv("decoder_future.hidden_to_output.bias"))
         return pred, fut
 
-    def forward(self, win, win_row, B, eps, training):
-        """Full RNN_VAE.forward (rnn_model.py:162-179).  Returns workspace views pred, fut, z, mu, logvar."""
+    def cluster_terms(self, B, kl_weight, kloss, klmbda, bsize):
+        """cluster_loss (rnn_vae.py:45-50) from the (Z,Z) Gram: losses[KMEANS] and Minv with d loss/dz = z Minv."""
+        Z = self.spec.Z
+        z, G = self.buf("z", B, Z), self.buf("gram", Z, Z)
+        sk = max(1, min(64, B // 256))
+        ws = self.ws.get("splitk_gram", sk * Z * Z, self.dev) if sk > 1 else None
+        ops.gemm(Z, Z, B, Operand(z, Z), 1, Operand(z, Z), 1, G, Z, splitk=sk, ws=ws)
+        ops.nuclear(G, Z, kloss, B, klmbda, bsize, self.buf("losses", 8), LOSS_KMEANS, self.buf("Minv", Z, Z), gscale=kl_weight)
+
+    def forward(self, win, win_row, B, eps, training, cluster=None):
+        """Full RNN_VAE.forward (rnn_model.py:162-179).  Returns workspace views pred, fut, z, mu, logvar.
+        cluster = (kl_weight, kloss, klmbda, bsize) starts the nuclear-norm loss as soon as z exists."""
         s = self.spec
         hn = self.encode(win, win_row, B, training)
         z, mu, logvar = self.latent(hn, B, eps, training)
+        self._ev_nuc = None
+        if cluster is not None:
+            if self.side is not None:
+                ev = torch.cuda.Event()
+                ev.record()
+                with torch.cuda.stream(self.side):
+                    self.side.wait_event(ev)
+                    self.cluster_terms(B, *cluster)
+                    self._ev_nuc = torch.cuda.Event()
+                    self._ev_nuc.record()
+            else:
+                self.cluster_terms(B, *cluster)
+        self._cluster_done = cluster is not None
         pred, fut = self.decode(z, B, training)
         self._B = B
         self._win, self._win_row, self._eps = win, win_row, eps
@@ -246,12 +272,12 @@ class VAEEngine:
             dfut = self.buf("dfut", B, FS, F)
             sc = 2.0 if mse_pred == "sum" else 2.0 / (B * FS * F)
             ops.mse_fwd_bwd(self.buf("futp", B, FS, F), tgt, fut_tgt_off, tgt_row, B, FS * F, sc, dfut, losses, LOSS_FUT)
-        z = self.buf("z", B, Z)
-        G = self.buf("gram", Z, Z)
-        sk = max(1, min(64, B // 256))
-        ws = self.ws.get("splitk", sk * Z * Z, self.dev) if sk > 1 else None
-        ops.gemm(Z, Z, B, Operand(z, Z), 1, Operand(z, Z), 1, G, Z, splitk=sk, ws=ws)
-        ops.nuclear(G, Z, kloss, B, klmbda, bsize, losses, LOSS_KMEANS, self.buf("Minv", Z, Z), gscale=kl_weight)
+        if not getattr(self, "_cluster_done", False):
+            self.cluster_terms(B, kl_weight, kloss, klmbda, bsize)
+        if self._ev_nuc is not None:
+            torch.cuda.current_stream().wait_event(self._ev_nuc)
+            self._ev_nuc = None
+        self._cluster_done = False
         return losses
 
     # ------------------------------------------------------------------ backward
@@ -323,12 +349,12 @@ class VAEEngine:
             for dirn, (d, dG, dbias, dgsum) in enumerate(per):
                 ops.timesum(dG, B, steps, 3 * H, 4 * H, dgsum)       # z is constant in time: sum_t dG first
                 self._gru_param_grads(d, dG, dbias, ntiles, B, steps, Y, dirn, None, Z, const_in=(dgsum, z))
-                ops.gemm(B, Z, 3 * H, Operand(dgsum, 3 * H), 0, self.P(d.w_ih, Z), 1, dz, Z, accumulate=not first)
+                ops.gemm(B, Z, 3 * H, Operand(dgsum, 3 * H), 0, self.P(d.w_ih, Z), 1, dz, Z, accumulate=not first, splitk=0)
                 first = False
             wl = f"{name}.latent_to_hidden.weight"
             self._gemm_wgrad(2 * H, Z, B, Operand(dhid, 2 * H), Operand(z, Z), wl)
             ops.colsum(dhid, 0, B, 2 * H, 2 * H, self.g, t.off(f"{name}.latent_to_hidden.bias"))
-            ops.gemm(B, Z, 2 * H, Operand(dhid, 2 * H), 0, self.P(wl, Z), 1, dz, Z, accumulate=True)
+            ops.gemm(B, Z, 2 * H, Operand(dhid, 2 * H), 0, self.P(wl, Z), 1, dz, Z, accumulate=True, splitk=0)
         if use_minv and kl_weight != 0:
             ops.gemm(B, Z, Z, Operand(z, Z), 0, Operand(self.buf("Minv", Z, Z), Z), 1, dz, Z, accumulate=True)
         if dz_ext is not None:

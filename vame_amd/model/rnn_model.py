@@ -271,7 +271,7 @@ class RNN_VAE(nn.Module):
         if training and eps is None:
             eps = torch.randn(B, s.Z, device=eng.dev)
         with torch.no_grad():
-            eng.forward(win, L * F, B, eps, training)
+            eng.forward(win, L * F, B, eps, training, cluster=(kl_weight, kloss, klmbda, bsize))
             # test(): no future term (rnn_vae.py:183-198)
             losses = eng.loss(B, win, L * F, s.T * F, kl_weight, kloss, klmbda, bsize, mse_red, mse_pred,
                               with_future=training and s.future)

@@ -38,9 +38,25 @@ class Operand:
         self.t, self.off, self.ld, self.seg, self.seg_stride = t, off, ld, seg, seg_stride
 
 
+_ws_cache = {}
+
+
+def _auto_ws(dev, n):
+    t = _ws_cache.get(dev)
+    if t is None or t.numel() < n:
+        t = _ws_cache[dev] = torch.empty(max(n, 1 << 20), device=dev)
+    return t
+
+
 def gemm(M, N, K, A, a_kmajor, B, b_kmajor, C, ldc, c_off=0, bias=None, accumulate=False, splitk=1, ws=None, a_gap_at=0,
          a_gap=0):
     L = _lib.lib()
+    if splitk == 0:
+        # auto: few output tiles but a long K (Lambda / latent_to_hidden / dz GEMMs, M = batch): spread K over more workgroups
+        tiles = ((M + 127) // 128) * ((N + 127) // 128 if N > 64 else 1)
+        splitk = max(1, min(7, 192 // tiles, K // 128)) if tiles <= 64 else 1
+        if splitk > 1:
+            ws = _auto_ws(C.device, splitk * M * N)
     if splitk > 1:
         assert ws is not None and ws.numel() >= splitk * M * N, "split-K workspace too small"
     rc = L.vame_gemm_f32(M, N, K, _ptr(A.t, A.off), A.ld, int(a_kmajor), A.seg, A.seg_stride, _ptr(B.t, B.off), B.ld,
