@@ -120,6 +120,8 @@ int vame_timesum_f32(const float* in, int B, int T, int C, int64_t ld, float* ou
  * two-pass reduction; ws must hold vame_colsum_ws_floats(R, C) floats. */
 int64_t vame_colsum_ws_floats(int64_t R, int C);
 int vame_colsum_f32(const float* in, int64_t R, int C, int64_t ld, float* out, int accumulate, float* ws, void* stream);
+/* njobs (<= 32) independent column sums out_i[c] = sum_r in_i[r*ld_i + c] in one launch; desc = njobs x {in, R, C, ld, out}. */
+int vame_colsum_batch_f32(const int64_t* desc, int njobs, void* stream);
 
 /* Fused Adam with AMSGrad over a flat parameter buffer (torch.optim.Adam(amsgrad=True), rnn_vae.py:332,143).
  * gscale multiplies the gradient first (1/world_size after an all-reduce SUM). */

@@ -210,6 +210,20 @@ def check_colsum(dev):
     np.testing.assert_allclose(N_(out), 1 + a[:, 5:265].sum(0), atol=1e-5)
 
 
+def check_colsum_batch(dev):
+    rng = np.random.default_rng(16)
+    a = rng.standard_normal((128, 1024)).astype(np.float32)
+    b = rng.standard_normal((37, 30)).astype(np.float32)
+    at, bt = T_(a, dev), T_(b, dev)
+    out = torch.zeros(2000, device=dev)
+    ops.colsum_batch([(at, 0, 128, 768, 1024, out, 0), (at, 768, 128, 256, 1024, out, 800), (bt, 0, 37, 30, 30, out, 1100)])
+    o = N_(out)
+    np.testing.assert_allclose(o[:768], a[:, :768].sum(0), atol=1e-4)
+    np.testing.assert_allclose(o[800:1056], a[:, 768:].sum(0), atol=1e-4)
+    np.testing.assert_allclose(o[1100:1130], b.sum(0), atol=1e-5)
+    assert (o[768:800] == 0).all() and (o[1130:] == 0).all()
+
+
 def check_adam(dev):
     rng = np.random.default_rng(7)
     n = 1000

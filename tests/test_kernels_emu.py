@@ -9,7 +9,7 @@ import torch
 
 from oracle import vame_oracle as vo
 from vame_amd import ops
-from kernel_cases import (check_adam, check_colsum, check_gather, check_gemm_cases, check_gru_bwd, check_gru_fwd,
+from kernel_cases import (check_adam, check_colsum, check_colsum_batch, check_gather, check_gemm_cases, check_gru_bwd, check_gru_fwd,
                           check_latent, check_mse, check_nuclear)
 
 DEV = "cpu"
@@ -34,6 +34,7 @@ def test_elementwise(emu):
     check_latent(DEV)
     check_mse(DEV)
     check_colsum(DEV)
+    check_colsum_batch(DEV)
     check_adam(DEV)
 
 

@@ -1,7 +1,7 @@
 """The kernel checks of test_kernels_emu.py on the real MI355X through libvame_hip.so (C ABI)."""
 import pytest
 
-from kernel_cases import (check_adam, check_colsum, check_gather, check_gemm_cases, check_gru_bwd, check_gru_fwd,
+from kernel_cases import (check_adam, check_colsum, check_colsum_batch, check_gather, check_gemm_cases, check_gru_bwd, check_gru_fwd,
                           check_latent, check_mse, check_nuclear)
 
 pytestmark = pytest.mark.gpu
@@ -27,6 +27,7 @@ def test_elementwise(hip):
     check_latent(DEV)
     check_mse(DEV)
     check_colsum(DEV)
+    check_colsum_batch(DEV)
     check_adam(DEV)
 
 

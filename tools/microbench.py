@@ -8,7 +8,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
 import torch  # noqa: E402
 
-from vame_amd import ops  # noqa: E402
+from vame_amd import _lib, ops  # noqa: E402
+if os.environ.get("VAME_LIB"):          # A/B against another build of the library
+    _lib._lib = _lib._bind(os.environ["VAME_LIB"])
 from vame_amd.ops import GB, GF, Operand  # noqa: E402
 
 dev = "cuda"

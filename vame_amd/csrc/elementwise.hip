@@ -200,6 +200,38 @@ extern "C" int vame_colsum_f32(const float* in, int64_t R, int C, int64_t ld, fl
     return VAME_OK;
 }
 
+// Batched single-pass column sums for many small jobs (the 24 bias-gradient reductions of a train step) in ONE launch.
+struct ColsumJob { const float* in; int64_t R; int64_t C; int64_t ld; float* out; };
+struct ColsumBatch { ColsumJob j[32]; };
+__global__ __launch_bounds__(256) void colsum_batch_kernel(ColsumBatch P) {
+    __shared__ float red[4][64];
+    const ColsumJob& J = P.j[blockIdx.y];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + tx;
+    if ((int64_t)blockIdx.x * 64 >= J.C) return;
+    float s = 0.f;
+    if (c < J.C)
+        for (int64_t r = ty; r < J.R; r += 4) s += J.in[r * J.ld + c];
+    red[ty][tx] = s;
+    __syncthreads();
+    if (ty == 0 && c < J.C) J.out[c] = red[0][tx] + red[1][tx] + red[2][tx] + red[3][tx];
+}
+
+extern "C" int vame_colsum_batch_f32(const int64_t* desc, int njobs, void* stream) {
+    VAME_CHECK_ARG(desc && njobs >= 1 && njobs <= 32, VAME_E_BADARG, "colsum_batch: njobs=%d not in 1..32", njobs);
+    ColsumBatch P;
+    int64_t maxc = 0;
+    for (int i = 0; i < njobs; ++i) {
+        const int64_t* d = desc + 5 * (int64_t)i;
+        P.j[i] = {(const float*)d[0], d[1], d[2], d[3], (float*)d[4]};
+        VAME_CHECK_ARG(P.j[i].in && P.j[i].out && d[1] >= 1 && d[2] >= 1, VAME_E_BADARG, "colsum_batch: job %d invalid", i);
+        if (d[2] > maxc) maxc = d[2];
+    }
+    hipLaunchKernelGGL(colsum_batch_kernel, dim3((unsigned)cdiv64(maxc, 64), (unsigned)njobs), dim3(256), 0, (hipStream_t)stream, P);
+    VAME_LAUNCH_CHECK("colsum_batch");
+    return VAME_OK;
+}
+
 // --------------------------------------------------------------------------------- sum over time
 __global__ __launch_bounds__(256) void timesum_kernel(const float* __restrict__ in, int B, int T, int C4, int64_t ld,
                                                       float* __restrict__ out) {

@@ -45,7 +45,7 @@ __device__ __forceinline__ bool map_tile(const GemmParams& p, int& tm, int& tn, 
 //        (two-level) row offsets are resolved once; 8 lanes cover one 128-byte line of a row.
 //    KM (stored K x X, X contiguous): item = (k, x-quad); rows advance by BK per k-tile, the (segment,
 //        index) pair of the two-level addressing is advanced incrementally (no division in the loop).
-template <int BK, int BX, int NT, bool KM>
+template <int BK, int BX, int NT, bool KM, bool XM>
 struct TileIO {
     static constexpr int ITEMS = BK * BX / 4;
     static constexpr int PER = (ITEMS + NT - 1) / NT;
@@ -126,7 +126,14 @@ struct TileIO {
             if (o.seg) while (seg_t >= (int)o.seg) { seg_t -= (int)o.seg; ++seg_b; }
         }
     }
-    __device__ __forceinline__ void store(float* lds, int LD, int tid) const {
+    // LDS image.  k-major [BK][BX+4] (default; fragment = ds_read_b32 of row k; a row-major (!KM) operand is transposed by
+    // four ds_write_b32 per global float4), or for !KM operands with XM: x-major [BX][BK+4] -- the global float4 is stored
+    // as-is with one ds_write_b128 and a lane reads float4 [x][8c + 4*(lane>>5)] = its operand for 4 MFMA steps (row
+    // stride 36 floats = 9 x 16 B: conflict-free b128).  Measured: XM wins for the NN form's A operand only.
+    static constexpr bool XMAJ = !KM && XM;
+    static constexpr int LD = XMAJ ? BK + 4 : BX + 4;
+    static constexpr int LDS_FLOATS = XMAJ ? BX * (BK + 4) : BK * (BX + 4);
+    __device__ __forceinline__ void store(float* lds, int tid) const {
 #pragma unroll
         for (int it = 0; it < PER; ++it) {
             const int idx = tid + it * NT;
@@ -134,6 +141,9 @@ struct TileIO {
                 if (KM) {
                     const int k = idx / XQ, xq = idx % XQ;
                     *reinterpret_cast<float4*>(&lds[k * LD + 4 * xq]) = v[it];
+                } else if (XMAJ) {
+                    const int x = idx / KQ, kq = idx % KQ;
+                    *reinterpret_cast<float4*>(&lds[x * LD + 4 * kq]) = v[it];
                 } else {
                     const int x = idx / KQ, kq = idx % KQ;
                     lds[(4 * kq + 0) * LD + x] = v[it].x;
@@ -144,14 +154,26 @@ struct TileIO {
             }
         }
     }
+    // fragment values of the 4 MFMA steps e = 0..3 of chunk c (k = 8c + 4*hh + e) for operand column block at xw
+    __device__ __forceinline__ static void frag(const float* lds, int xw, int li, int hh, int c, float (&f)[4]) {
+        if (!XMAJ) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) f[e] = lds[(8 * c + 4 * hh + e) * LD + xw + li];
+        } else {
+            const float4 q = *reinterpret_cast<const float4*>(&lds[(xw + li) * LD + 8 * c + 4 * hh]);
+            f[0] = q.x; f[1] = q.y; f[2] = q.z; f[3] = q.w;
+        }
+    }
 };
 
-// VAR (tuning variants, tools/microbench.py A/B): 1 unpredicated interior fetch, 2 LDS fragments read one k-pair ahead, 4 s_setprio around the MFMAs
+// VAR (tuning variants, tools/microbench.py A/B): 1 unpredicated interior fetch, 4 s_setprio around the MFMAs
 template <int BM, int BN, int WM, int WN, bool AKM, bool BKM, int VAR>
 __global__ __launch_bounds__(WM * WN * 64, 3) void gemm_kernel(GemmParams p) {
-    constexpr int BK = 32, NT = WM * WN * 64, TM = BM / WM / 32, TN = BN / WN / 32, LDA = BM + 4, LDB = BN + 4;
-    __shared__ __attribute__((aligned(16))) float As[BK * LDA];
-    __shared__ __attribute__((aligned(16))) float Bs[BK * LDB];
+    constexpr int BK = 32, NT = WM * WN * 64, TM = BM / WM / 32, TN = BN / WN / 32;
+    typedef TileIO<BK, BM, NT, AKM, BKM> TA;      // x-major image only for the A operand of the NN form
+    typedef TileIO<BK, BN, NT, BKM, false> TB;
+    __shared__ __attribute__((aligned(16))) float As[TA::LDS_FLOATS];
+    __shared__ __attribute__((aligned(16))) float Bs[TB::LDS_FLOATS];
     int tm_, tn_, z;
     if (!map_tile(p, tm_, tn_, z)) return;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, li = lane & 31, hh = lane >> 5;
@@ -167,52 +189,31 @@ __global__ __launch_bounds__(WM * WN * 64, 3) void gemm_kernel(GemmParams p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    TileIO<BK, BM, NT, AKM> ta;
-    TileIO<BK, BN, NT, BKM> tb;
+    TA ta;
+    TB tb;
     ta.init(p.A, m0, p.M, kb, tid);
     tb.init(p.B, n0, p.N, kb, tid);
     if (kb < ke) { ta.template fetch<(VAR & 1) != 0>(p.A, m0, p.M, kb, ke, tid); tb.template fetch<(VAR & 1) != 0>(p.B, n0, p.N, kb, ke, tid); }
-    const float* ap = &As[hh * LDA + wm * (BM / WM) + li];
-    const float* bp = &Bs[hh * LDB + wn * (BN / WN) + li];
     for (int k0 = kb; k0 < ke; k0 += BK) {
-        ta.store(As, LDA, tid);
-        tb.store(Bs, LDB, tid);
+        ta.store(As, tid);
+        tb.store(Bs, tid);
         __syncthreads();
         if (k0 + BK < ke) { ta.template fetch<(VAR & 1) != 0>(p.A, m0, p.M, k0 + BK, ke, tid); tb.template fetch<(VAR & 1) != 0>(p.B, n0, p.N, k0 + BK, ke, tid); }   // in flight during the MFMAs
         if (VAR & 4) SETPRIO(1);
-        if (VAR & 2) {
-            // fragments of k-pair kk+1 are read from LDS before the MFMAs of k-pair kk
-            float a[2][TM], b[2][TN];
+        // MFMA step (c, e) contracts k = {8c + e, 8c + 4 + e}: any k order is valid as long as A and B agree
 #pragma unroll
-            for (int i = 0; i < TM; ++i) a[0][i] = ap[i * 32];
+        for (int c = 0; c < BK / 8; ++c) {
+            float a[TM][4], b[TN][4];
 #pragma unroll
-            for (int j = 0; j < TN; ++j) b[0][j] = bp[j * 32];
+            for (int i = 0; i < TM; ++i) TA::frag(As, wm * (BM / WM) + i * 32, li, hh, c, a[i]);
 #pragma unroll
-            for (int kk = 0; kk < BK / 2; ++kk) {
-                if (kk + 1 < BK / 2) {
+            for (int j = 0; j < TN; ++j) TB::frag(Bs, wn * (BN / WN) + j * 32, li, hh, c, b[j]);
 #pragma unroll
-                    for (int i = 0; i < TM; ++i) a[(kk + 1) & 1][i] = ap[2 * (kk + 1) * LDA + i * 32];
-#pragma unroll
-                    for (int j = 0; j < TN; ++j) b[(kk + 1) & 1][j] = bp[2 * (kk + 1) * LDB + j * 32];
-                }
+            for (int e = 0; e < 4; ++e)
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
-                    for (int j = 0; j < TN; ++j) acc[i][j] = MFMA_32x32x2(a[kk & 1][i], b[kk & 1][j], acc[i][j]);
-            }
-        } else {
-#pragma unroll
-            for (int kk = 0; kk < BK / 2; ++kk) {
-                float a[TM], b[TN];
-#pragma unroll
-                for (int i = 0; i < TM; ++i) a[i] = ap[2 * kk * LDA + i * 32];
-#pragma unroll
-                for (int j = 0; j < TN; ++j) b[j] = bp[2 * kk * LDB + j * 32];
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int j = 0; j < TN; ++j) acc[i][j] = MFMA_32x32x2(a[i], b[j], acc[i][j]);
-            }
+                    for (int j = 0; j < TN; ++j) acc[i][j] = MFMA_32x32x2(a[i][e], b[j][e], acc[i][j]);
         }
         if (VAR & 4) SETPRIO(0);
         __syncthreads();
@@ -278,10 +279,8 @@ static int launch_gemm(GemmParams p, int akm, int bkm, hipStream_t st) {
         switch (e ? atoi(e) : -1) {
             case 0: return launch_gemm_var<BM, BN, WM, WN, 0>(p, akm, bkm, grid, block, st);
             case 1: return launch_gemm_var<BM, BN, WM, WN, 1>(p, akm, bkm, grid, block, st);
-            case 2: return launch_gemm_var<BM, BN, WM, WN, 2>(p, akm, bkm, grid, block, st);
-            case 3: return launch_gemm_var<BM, BN, WM, WN, 3>(p, akm, bkm, grid, block, st);
+            case 4: return launch_gemm_var<BM, BN, WM, WN, 4>(p, akm, bkm, grid, block, st);
             case 5: return launch_gemm_var<BM, BN, WM, WN, 5>(p, akm, bkm, grid, block, st);
-            case 7: return launch_gemm_var<BM, BN, WM, WN, 7>(p, akm, bkm, grid, block, st);
             default: break;
         }
     }
@@ -289,7 +288,8 @@ static int launch_gemm(GemmParams p, int akm, int bkm, hipStream_t st) {
     // measured on MI355X (interleaved A/B, tools/microbench.py gemm_ab): the unpredicated interior fetch + s_setprio
     // variant wins +6..10 % on split-K weight-gradient GEMMs and +2 % on the data-gradient (NN) form, and loses on the
     // NT form and on un-split TN, which keep the baseline variant
-    if (bkm && (!akm || p.splitk >= 8)) return launch_gemm_var<BM, BN, WM, WN, 5>(p, akm, bkm, grid, block, st);
+    if (akm && bkm && p.splitk >= 8) return launch_gemm_var<BM, BN, WM, WN, 5>(p, akm, bkm, grid, block, st);
+    if (!akm && bkm) return launch_gemm_var<BM, BN, WM, WN, 1>(p, akm, bkm, grid, block, st);
     return launch_gemm_var<BM, BN, WM, WN, 0>(p, akm, bkm, grid, block, st);
 }
 
@@ -317,7 +317,8 @@ extern "C" int vame_gemm_f32(int M, int N, int K, const float* A, int64_t lda, i
     p.splitk = (int)cdiv64(K, kper);
     hipStream_t st = (hipStream_t)stream;
     int rc;
-    if (N > 64) rc = launch_gemm<128, 128, 2, 2>(p, a_kmajor, b_kmajor, st);
+    if (M <= 32 && N > 64) rc = launch_gemm<32, 128, 1, 4>(p, a_kmajor, b_kmajor, st);      // skinny outputs (dW of the 24/30-row heads)
+    else if (N > 64) rc = launch_gemm<128, 128, 2, 2>(p, a_kmajor, b_kmajor, st);
     else if (N > 32) rc = launch_gemm<128, 64, 4, 1>(p, a_kmajor, b_kmajor, st);
     else rc = launch_gemm<128, 32, 4, 1>(p, a_kmajor, b_kmajor, st);
     VAME_CHECK_ARG(rc == VAME_OK, rc, "gemm: unsupported layout");

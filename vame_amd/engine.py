@@ -305,9 +305,9 @@ class VAEEngine:
         # dW_hh = [da_r | da_z | dgh_n]^T h_{t-1}: columns 0..2H and 3H..4H of dG in one call (skip the dgi_n block)
         self._gemm_wgrad(3 * H, H, K, dG_i, hp, d.w_hh, gap_at=2 * H, gap=H)
         ob_i, ob_h = t.off(d.b_ih), t.off(d.b_hh)
-        ops.colsum(dbias, 0, ntiles, 3 * H, 4 * H, g, ob_i)
-        ops.colsum(dbias, 0, ntiles, 2 * H, 4 * H, g, ob_h)
-        ops.colsum(dbias, 3 * H, ntiles, H, 4 * H, g, ob_h + 2 * H)
+        # bias gradients = column sums of the per-tile partials; queued and reduced in one batched launch per backward
+        self._colsum_jobs += [(dbias, 0, ntiles, 3 * H, 4 * H, g, ob_i), (dbias, 0, ntiles, 2 * H, 4 * H, g, ob_h),
+                              (dbias, 3 * H, ntiles, H, 4 * H, g, ob_h + 2 * H)]
 
     def _decoder_backward(self, tag, name, dirs, steps, dpred, B, dz, first):
         H, F, Z, t = self.spec.H, self.spec.F, self.spec.Z, self.table
@@ -334,6 +334,7 @@ class VAEEngine:
         """Backward of the whole model given the seeds left by loss() (or external ones).  Fills flat_g."""
         s, H, F, Z, T, FS, t = self.spec, self.spec.H, self.spec.F, self.spec.Z, self.spec.T, self.spec.FS, self.table
         ntiles = (B + 31) // 32
+        self._colsum_jobs = []
         z = self.buf("z", B, Z)
         dz = self.buf("dz", B, Z)
         # ---- decoders (one BPTT launch for all 2 or 4 streams)
@@ -353,7 +354,7 @@ class VAEEngine:
                 first = False
             wl = f"{name}.latent_to_hidden.weight"
             self._gemm_wgrad(2 * H, Z, B, Operand(dhid, 2 * H), Operand(z, Z), wl)
-            ops.colsum(dhid, 0, B, 2 * H, 2 * H, self.g, t.off(f"{name}.latent_to_hidden.bias"))
+            self._colsum_jobs.append((dhid, 0, B, 2 * H, 2 * H, self.g, t.off(f"{name}.latent_to_hidden.bias")))
             ops.gemm(B, Z, 2 * H, Operand(dhid, 2 * H), 0, self.P(wl, Z), 1, dz, Z, accumulate=True, splitk=0)
         if use_minv and kl_weight != 0:
             ops.gemm(B, Z, Z, Operand(z, Z), 0, Operand(self.buf("Minv", Z, Z), Z), 1, dz, Z, accumulate=True)
@@ -372,7 +373,7 @@ class VAEEngine:
         dhn = self.buf("dhn", B, 4 * H)
         for nm, dv, first in (("lmbda.hidden_to_mean", dmu, True), ("lmbda.hidden_to_logvar", dlv, False)):
             self._gemm_wgrad(Z, 4 * H, B, Operand(dv, Z), Operand(hn, 4 * H), nm + ".weight")
-            ops.colsum(dv, 0, B, Z, Z, self.g, t.off(nm + ".bias"))
+            self._colsum_jobs.append((dv, 0, B, Z, Z, self.g, t.off(nm + ".bias")))
             ops.gemm(B, 4 * H, Z, Operand(dv, Z), 0, self.P(nm + ".weight", 4 * H), 1, dhn, 4 * H, accumulate=not first)
         # ---- encoder layer 1
         Y0, Y1 = self.buf("Y0", B, T + 2, 2 * H), self.buf("Y1", B, T + 2, 2 * H)
@@ -401,6 +402,8 @@ class VAEEngine:
         xrows = Operand(self._win, F, seg=T, seg_stride=self._win_row)
         for dirn, (d, dG, dbias) in enumerate(per):
             self._gru_param_grads(d, dG, dbias, ntiles, B, T, Y0, dirn, xrows, F)
+        ops.colsum_batch(self._colsum_jobs)
+        self._colsum_jobs = []
 
 
 def _numel(shape):

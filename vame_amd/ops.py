@@ -142,6 +142,15 @@ def colsum(inp, in_off, R, C, ld, out, out_off=0, accumulate=False):
     _lib.check(rc, "vame_colsum_f32")
 
 
+def colsum_batch(jobs):
+    """jobs: list of (in_tensor, in_off, R, C, ld, out_tensor, out_off); up to 32 per launch."""
+    for i in range(0, len(jobs), 32):
+        chunk = jobs[i:i + 32]
+        d = torch.tensor([[_ptr(a, ao), R, C, ld, _ptr(o, oo)] for (a, ao, R, C, ld, o, oo) in chunk], dtype=torch.int64)
+        rc = _lib.lib().vame_colsum_batch_f32(d.data_ptr(), len(chunk), _stream())
+        _lib.check(rc, "vame_colsum_batch_f32")
+
+
 def adam_amsgrad(p, g, m, v, vmax, n, lr, step, gscale=1.0, beta1=0.9, beta2=0.999, eps=1e-8):
     rc = _lib.lib().vame_adam_amsgrad_f32(_ptr(p), _ptr(g), _ptr(m), _ptr(v), _ptr(vmax), n, lr, beta1, beta2, eps, step,
                                           gscale, _stream())
