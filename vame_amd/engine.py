@@ -91,9 +91,7 @@ class VAEEngine:
         self.fut = ([GruDir("decoder_future.rnn_pred", "_l0", H, Z, self.dev),
                      GruDir("decoder_future.rnn_pred", "_l0_reverse", H, Z, self.dev)] if spec.future else [])
         self.ws = Workspace()
-        # the single-workgroup Jacobi solve of the nuclear-norm loss (~0.27 ms) runs on a side stream beside the decoder
-        self.side = torch.cuda.Stream(device=self.dev) if self.dev.type == "cuda" else None
-        self._ev_z = self._ev_nuc = None
+        self._nuc_state = None
         self.packed_version = -1
         self.version = 0          # bumped by the owner whenever flat_p changes
         self._B = None
@@ -232,26 +230,19 @@ class VAEEngine:
         sk = max(1, min(64, B // 256))
         ws = self.ws.get("splitk_gram", sk * Z * Z, self.dev) if sk > 1 else None
         ops.gemm(Z, Z, B, Operand(z, Z), 1, Operand(z, Z), 1, G, Z, splitk=sk, ws=ws)
-        ops.nuclear(G, Z, kloss, B, klmbda, bsize, self.buf("losses", 8), LOSS_KMEANS, self.buf("Minv", Z, Z), gscale=kl_weight)
+        if self._nuc_state is None:
+            self._nuc_state = torch.zeros(((Z + 1) // 2 * 2) ** 2, device=self.dev, dtype=torch.float64)
+        ops.nuclear(G, Z, kloss, B, klmbda, bsize, self.buf("losses", 8), LOSS_KMEANS, self.buf("Minv", Z, Z), gscale=kl_weight,
+                    vstate=self._nuc_state)
 
     def forward(self, win, win_row, B, eps, training, cluster=None):
         """Full RNN_VAE.forward (rnn_model.py:162-179).  Returns workspace views pred, fut, z, mu, logvar.
-        cluster = (kl_weight, kloss, klmbda, bsize) starts the nuclear-norm loss as soon as z exists."""
+        cluster = (kl_weight, kloss, klmbda, bsize) also evaluates the nuclear-norm loss as soon as z exists."""
         s = self.spec
         hn = self.encode(win, win_row, B, training)
         z, mu, logvar = self.latent(hn, B, eps, training)
-        self._ev_nuc = None
         if cluster is not None:
-            if self.side is not None:
-                ev = torch.cuda.Event()
-                ev.record()
-                with torch.cuda.stream(self.side):
-                    self.side.wait_event(ev)
-                    self.cluster_terms(B, *cluster)
-                    self._ev_nuc = torch.cuda.Event()
-                    self._ev_nuc.record()
-            else:
-                self.cluster_terms(B, *cluster)
+            self.cluster_terms(B, *cluster)
         self._cluster_done = cluster is not None
         pred, fut = self.decode(z, B, training)
         self._B = B
@@ -274,9 +265,6 @@ class VAEEngine:
             ops.mse_fwd_bwd(self.buf("futp", B, FS, F), tgt, fut_tgt_off, tgt_row, B, FS * F, sc, dfut, losses, LOSS_FUT)
         if not getattr(self, "_cluster_done", False):
             self.cluster_terms(B, kl_weight, kloss, klmbda, bsize)
-        if self._ev_nuc is not None:
-            torch.cuda.current_stream().wait_event(self._ev_nuc)
-            self._ev_nuc = None
         self._cluster_done = False
         return losses
 

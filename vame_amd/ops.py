@@ -119,9 +119,12 @@ def mse_fwd_bwd(pred, target, tgt_off, tgt_row, B, TF, gscale, dpred, loss_out, 
     _lib.check(rc, "vame_mse_fwd_bwd_f32")
 
 
-def nuclear(G, Z, kloss, nrows, lmbda, bsize, loss_out, loss_off, Minv, gscale=1.0):
+def nuclear(G, Z, kloss, nrows, lmbda, bsize, loss_out, loss_off, Minv, gscale=1.0, vstate=None):
+    if vstate is not None:
+        assert vstate.dtype == torch.float64 and vstate.numel() >= ((Z + 1) // 2 * 2) ** 2
     rc = _lib.lib().vame_nuclear_f32(_ptr(G), Z, kloss, nrows, float(lmbda), float(bsize), float(gscale),
-                                     _ptr(loss_out, loss_off), _ptr(Minv), _stream())
+                                     _ptr(loss_out, loss_off), _ptr(Minv), vstate.data_ptr() if vstate is not None else None,
+                                     _stream())
     _lib.check(rc, "vame_nuclear_f32")
 
 
