@@ -103,6 +103,43 @@ def profile_kernels(model, loader, steps=3):
     return agg
 
 
+def bench_embed(args, dev, rank, world):
+    """Encoder-only latent embedding of a synthetic series, window index range sharded over ranks (no collective)."""
+    from vame_amd.analysis.pose_segmentation import embed_series
+    from vame_amd.model.rnn_model import RNN_VAE
+    model = RNN_VAE(2 * T, Z, F, 1, FS, H, H, H, H, 0, 0, 0, False).to(dev).eval()
+    n_win = args.embed_windows * world
+    data = synth_series(n_win + T)
+    embed_series(model, data[:, :70000], batch=16384)                      # warm-up (allocations, clocks)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    out, (lo, hi) = embed_series(model, data, batch=16384, rank=rank, world=world)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    assert torch.isfinite(out).all()
+    if rank == 0:
+        value = n_win / dt
+        print(json.dumps(dict(metric="latent-embedding windows/sec (encoder + Lambda mean) T=30,F=24,h=256", value=round(value, 1),
+                              unit="windows/s", n_gpus=world, higher_is_better=True, scaling="weak", dtype="f32", data="synthetic",
+                              seconds=round(dt, 3), includes="host->device upload of the series + window gather + encoder + mean",
+                              config=dict(workload=f"BASELINE.json configs[4] shape: {args.embed_windows} stride-1 windows per GPU, batch 16384",
+                                          parallelism=f"shard{world}"),
+                              roofline=dict(bound="mfma", unit="TFLOP/s", peak=PEAK_F32_MFMA_TFLOPS,
+                                            achieved=round(value / world * 96.707e6 / 1e12, 2),
+                                            frac=round(value / world * 96.707e6 / 1e12 / PEAK_F32_MFMA_TFLOPS, 4), traffic=None))))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def cpu_baseline():
     """Reference-equivalent torch-CPU train step (oracle/torch_ref.py) on this box's host cores, in a
     subprocess with a hard time limit (a bounded sample: <= 12 steps of B=256 or 25 s)."""
@@ -134,6 +171,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--batch", type=int, default=B_LOCAL)
     ap.add_argument("--dump-kernels", action="store_true", help="per-launch-group table on stderr")
+    ap.add_argument("--mode", choices=["train", "embed"], default="train",
+                    help="train = the headline metric; embed = encoder-only embedd_latent_vectors sweep (BASELINE config 5)")
+    ap.add_argument("--embed-windows", type=int, default=2_000_000)
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -154,6 +194,8 @@ def main():
 
     B_LOCAL = args.batch
     torch.manual_seed(19)
+    if args.mode == "embed":
+        return bench_embed(args, dev, rank, world)
     model = RNN_VAE(2 * T, Z, F, 1, FS, H, H, H, H, 0, 0, 0, False).to(dev).train()
     opt = FusedAdamAMSGrad(model, lr=5e-4)
 

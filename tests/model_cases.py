@@ -82,3 +82,28 @@ def check_h0_view(dev):
         z = torch.from_numpy(g[f"B{B}/z"]).to(dev)
         pred = model.decoder(None, z)
         np.testing.assert_allclose(pred.cpu().numpy(), g[f"B{B}/pred"], atol=2e-5)
+
+
+def check_noise_input(dev):
+    """cfg['noise']: the encoder sees a perturbed input while the reconstruction target stays clean (rnn_vae.py:116-124)."""
+    from oracle import vame_oracle as vo
+    g = load_golden("step_tiny")
+    model, (T, F, Z, H, FS, fut, sp) = build_model(g, dev)
+    model.train()
+    x, xfut, eps = g["x"], g["xfut"], g["eps"]
+    rng = np.random.default_rng(3)
+    xin = (x + 0.3 * rng.standard_normal(x.shape)).astype(np.float32)
+    win = torch.cat([torch.from_numpy(x), torch.from_numpy(xfut)], 1).contiguous().to(dev)
+    out = model.loss_step(win, 1.0, beta=1.0, kloss=Z, klmbda=0.1, bsize=x.shape[0], eps=torch.from_numpy(eps).to(dev),
+                          enc_in=torch.from_numpy(xin).to(dev)).cpu().numpy()
+    p = golden_weights(g)
+    spec = vo.Spec(T=T, F=F, Z=Z, H=H, FS=FS, future=bool(fut), softplus=bool(sp))
+    cache = vo.FwdCache()
+    res = vo.model_forward(p, xin, eps, spec, True, cache)
+    L = vo.total_loss(*res, x, xfut, spec, 1.0)
+    for i, k in enumerate(["rec", "fut", "kl", "kmeans"]):
+        assert abs(out[i] - L[k]) <= 1e-4 * max(1.0, abs(L[k])), (k, out[i], L[k])
+    grads = vo.model_backward(p, cache, spec, x, xfut, 1.0)
+    for k, prm in model.named_parameters():
+        r = grads[k]
+        np.testing.assert_allclose(prm.grad.cpu().numpy(), r, atol=3e-4 * max(1.0, np.abs(r).max()), err_msg=k)

@@ -2,7 +2,7 @@
 reference's golden vectors (tiny model).  The same bodies run on the GPU in test_model_gpu.py."""
 import pytest
 
-from model_cases import check_eval_and_submodules, check_h0_view, check_step
+from model_cases import check_eval_and_submodules, check_h0_view, check_noise_input, check_step
 
 
 @pytest.mark.parametrize("name,kw,mse", [("step_tiny", 1.0, "sum"), ("step_tiny", 0.25, "sum"), ("step_tiny_oddB", 1.0, "sum"),
@@ -22,3 +22,7 @@ def test_eval_and_submodules(emu):
 
 def test_decoder_h0_view(emu):
     check_h0_view("cpu")
+
+
+def test_noise_option_separate_encoder_input(emu):
+    check_noise_input("cpu")

@@ -5,7 +5,7 @@ import pytest
 import torch
 
 from conftest import load_golden
-from model_cases import check_eval_and_submodules, check_h0_view, check_step
+from model_cases import check_eval_and_submodules, check_h0_view, check_noise_input, check_step
 from oracle import vame_oracle as vo
 from vame_amd.model.rnn_model import RNN_VAE
 
@@ -89,3 +89,7 @@ def test_embedding_matches_reference_loop(hip):
     assert np.abs(lat - g["latent"]).max() < 1e-5
     lat2, (lo, hi) = embed_series(model, g["data"], batch=50, rank=1, world=3)     # sharded by window index
     np.testing.assert_allclose(lat2.cpu().numpy(), g["latent"][lo:hi], atol=1e-5)
+
+
+def test_noise_option_separate_encoder_input(hip):
+    check_noise_input("cuda")

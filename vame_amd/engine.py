@@ -235,18 +235,20 @@ class VAEEngine:
         ops.nuclear(G, Z, kloss, B, klmbda, bsize, self.buf("losses", 8), LOSS_KMEANS, self.buf("Minv", Z, Z), gscale=kl_weight,
                     vstate=self._nuc_state)
 
-    def forward(self, win, win_row, B, eps, training, cluster=None):
+    def forward(self, win, win_row, B, eps, training, cluster=None, enc_in=None):
         """Full RNN_VAE.forward (rnn_model.py:162-179).  Returns workspace views pred, fut, z, mu, logvar.
-        cluster = (kl_weight, kloss, klmbda, bsize) also evaluates the nuclear-norm loss as soon as z exists."""
+        cluster = (kl_weight, kloss, klmbda, bsize) also evaluates the nuclear-norm loss as soon as z exists.
+        enc_in (B,T,F contiguous) replaces the first T steps of `win` as the encoder input (input-noise option)."""
         s = self.spec
-        hn = self.encode(win, win_row, B, training)
+        xin, xin_row = (win, win_row) if enc_in is None else (enc_in, s.T * s.F)
+        hn = self.encode(xin, xin_row, B, training)
         z, mu, logvar = self.latent(hn, B, eps, training)
         if cluster is not None:
             self.cluster_terms(B, *cluster)
         self._cluster_done = cluster is not None
         pred, fut = self.decode(z, B, training)
         self._B = B
-        self._win, self._win_row, self._eps = win, win_row, eps
+        self._win, self._win_row, self._eps = xin, xin_row, eps
         sh = lambda t, *shape: t[:_numel(shape)].view(*shape)
         return (sh(pred, B, s.T, s.F), sh(fut, B, s.FS, s.F) if fut is not None else None, sh(z, B, s.Z), sh(mu, B, s.Z),
                 sh(logvar, B, s.Z))

@@ -52,8 +52,9 @@ class DeviceWindowLoader:
 
     Window starts come from the global numpy RNG, `np.random.randint(0, N - 2T, size=B)`, which is
     stream-equivalent to the B scalar `np.random.choice(N - 2T)` calls the reference's DataLoader
-    makes per batch (dataloader.py:49; tests/golden/batcher.npz).  With several ranks each rank
-    draws its own disjoint slice of the same stream.
+    makes per batch (dataloader.py:49; tests/golden/batcher.npz).  With several ranks each rank keeps
+    its own slice [rank*B, (rank+1)*B) of a B*world draw (disjoint slices of one stream when the ranks
+    seed numpy identically, independent draws otherwise -- the reference never seeds numpy).
     """
 
     def __init__(self, dataset: SEQUENCE_DATASET, batch_size, keep, device, rank=0, world=1):

@@ -256,11 +256,13 @@ class RNN_VAE(nn.Module):
         return pred, z, mu, lv
 
     # ---------------------------------------------------------------- fused training / evaluation step
-    def loss_step(self, win, kl_weight, *, beta, kloss, klmbda, bsize, mse_red="sum", mse_pred="sum", eps=None, backward=True):
+    def loss_step(self, win, kl_weight, *, beta, kloss, klmbda, bsize, mse_red="sum", mse_pred="sum", eps=None, backward=True,
+                  enc_in=None):
         """One fused forward + loss (+ backward) over a batch of windows, entirely on device.
 
         win: (B, L, F) fp32 device tensor, L >= T (+FS): steps [0,T) are the encoder input and
         reconstruction target, steps [T, T+FS) the future target (rnn_vae.py:111-112).
+        `enc_in` (B,T,F) optionally replaces the encoder input (cfg['noise'], rnn_vae.py:116-119); targets stay `win`.
         Gradients land in the flat bucket (p.grad views).  Returns a device tensor
         [rec, fut, kl, kmeans] in the reference's units (no host sync)."""
         eng = self._ensure_engine()
@@ -271,7 +273,10 @@ class RNN_VAE(nn.Module):
         if training and eps is None:
             eps = torch.randn(B, s.Z, device=eng.dev)
         with torch.no_grad():
-            eng.forward(win, L * F, B, eps, training, cluster=(kl_weight, kloss, klmbda, bsize))
+            if enc_in is not None:
+                enc_in = enc_in.to(device=eng.dev, dtype=torch.float32).contiguous()
+                _check(tuple(enc_in.shape) == (B, s.T, F), f"enc_in {tuple(enc_in.shape)} != {(B, s.T, F)}")
+            eng.forward(win, L * F, B, eps, training, cluster=(kl_weight, kloss, klmbda, bsize), enc_in=enc_in)
             # test(): no future term (rnn_vae.py:183-198)
             losses = eng.loss(B, win, L * F, s.T * F, kl_weight, kloss, klmbda, bsize, mse_red, mse_pred,
                               with_future=training and s.future)

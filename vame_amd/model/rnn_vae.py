@@ -83,7 +83,7 @@ def kl_annealing(epoch, kl_start, annealtime, function):
 def gaussian(ins, is_training, seq_len, std_n=0.8):
     """Optional input noise (cfg['noise'], off by default): ins + N(0,1) * 0.8 * std over time."""
     if is_training:
-        emp_std = ins.std(1, keepdim=True) * std_n
+        emp_std = ins.std(1, keepdim=True) * std_n          # unbiased std over time per (sample, feature), rnn_vae.py:86
         return ins + torch.randn_like(ins) * emp_std
     return ins
 
@@ -122,6 +122,15 @@ def _world():
     return 0, 1
 
 
+def _rank_mean(t):
+    """Average a small statistics tensor over ranks so every rank takes the same scheduler / checkpoint decisions."""
+    _, world = _world()
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        t = t / world
+    return t
+
+
 def allreduce_gradients(model):
     """One RCCL all-reduce (SUM) of the flat fp32 gradient bucket over xGMI; the 1/world factor is folded
     into the Adam kernel.  2,618,476 floats = 10.5 MB at the default model size."""
@@ -151,11 +160,9 @@ def train(train_loader, epoch, model, optimizer, anneal_function, BETA, kl_start
     idx = -1
     for idx, data_item in enumerate(train_loader):
         win = _to_windows(data_item, keep, dev)
-        if noise == True:  # noqa: E712
-            enc_in = gaussian(win[:, :seq_len_half, :], True, seq_len_half)
-            raise NotImplementedError("vame_amd: cfg['noise']=True needs separate encoder input and target buffers")
+        enc_in = gaussian(win[:, :seq_len_half, :], True, seq_len_half) if noise == True else None  # noqa: E712
         terms = model.loss_step(win, kl_weight, beta=BETA, kloss=kloss, klmbda=klmbda, bsize=bsize, mse_red=mse_red,
-                                mse_pred=mse_pred)
+                                mse_pred=mse_pred, enc_in=enc_in)
         gscale = allreduce_gradients(model)
         optimizer.step(gscale=gscale) if isinstance(optimizer, FusedAdamAMSGrad) else optimizer.step()
         total = terms[0] + terms[1] + BETA * kl_weight * terms[2] + kl_weight * terms[3]
@@ -164,8 +171,9 @@ def train(train_loader, epoch, model, optimizer, anneal_function, BETA, kl_start
     if idx < 1:
         raise ValueError("train(): need at least 2 batches per epoch (the reference divides by the last batch index, "
                          "rnn_vae.py:158,164); lower batch_size or provide more data")
-    scheduler.step(last.item())
-    train_loss, mse_loss, fut_loss, kullback_loss, kmeans_losses = [float(v) for v in acc.cpu()]
+    acc = _rank_mean(torch.cat([acc, last.to(torch.float64).reshape(1)]))      # identical statistics (and decisions) on all ranks
+    scheduler.step(float(acc[5]))
+    train_loss, mse_loss, fut_loss, kullback_loss, kmeans_losses = [float(v) for v in acc[:5].cpu()]
     if future_decoder:
         print('Train loss: {:.3f}, MSE-Loss: {:.3f}, MSE-Future-Loss {:.3f}, KL-Loss: {:.3f}, Kmeans-Loss: {:.3f}, weight: {:.2f}'.format(
             train_loss / idx, mse_loss / idx, fut_loss / idx, BETA * kl_weight * kullback_loss / idx, kl_weight * kmeans_losses / idx, kl_weight))
@@ -190,7 +198,7 @@ def test(test_loader, epoch, model, optimizer, BETA, kl_weight, seq_len, mse_red
             acc += torch.stack([total, terms[0], terms[2], terms[3]]).to(torch.float64)
     if idx < 1:
         raise ValueError("test(): need at least 2 test batches of batch_size/4 (rnn_vae.py:207-210 divides by the last index)")
-    test_loss, mse_loss, kullback_loss, kmeans_losses = [float(v) for v in acc.cpu()]
+    test_loss, mse_loss, kullback_loss, kmeans_losses = [float(v) for v in _rank_mean(acc).cpu()]
     print('Test loss: {:.3f}, MSE-Loss: {:.3f}, KL-Loss: {:.3f}, Kmeans-Loss: {:.3f}'.format(
         test_loss / idx, mse_loss / idx, BETA * kl_weight * kullback_loss / idx, kl_weight * kmeans_losses / idx))
     return mse_loss / idx, test_loss / idx, kl_weight * kmeans_losses
