@@ -67,9 +67,15 @@ enum vame_gru_fwd_field {
     GF_HN, GF_HN_ROW,                       /* final state (0 = not written) */
     GF_STASH,                               /* r,u,n,gh_n stash for backward (0 = inference) */
     GF_T, GF_REVERSE, GF_PAD,
+    GF_WPX, GF_BGI, GF_XF,                  /* fused input projection: packed W_ih (vame_gru_pack_x_f32), bias_gi (3H), F (0 = off);
+                                               GF_GI/_ROW/_T then describe x (B,T,F) instead of gi */
+    GF_RESERVED,
     VAME_GRU_FWD_FIELDS
 };
 int64_t vame_gru_stash_floats(int B, int T, int H);
+/* W_ih (3H,F), F <= 32 -> wpx (3H*32): zero-padded K = 32 input projection in MFMA B-fragment order (encoder layer 0:
+ * the projection x_t W_ih^T is then computed inside the sequence kernel instead of by vame_gemm_f32). */
+int vame_gru_pack_x_f32(const float* W_ih, int F, int H, float* wpx, void* stream);
 int vame_gru_seq_fwd_f32(const int64_t* desc, int nstreams, int B, int H, void* stream);
 
 /* GRU sequence backward (BPTT) for the same streams.  Writes dG (B,T,4H) = [da_r|da_z|dgi_n|dgh_n]

@@ -111,6 +111,35 @@ def check_gru_fwd(dev, H, B, T):
         np.testing.assert_allclose(pad, s["h0"] if s["h0"] is not None else 0 * pad, atol=0)
 
 
+def check_gru_fwd_fused(dev, H, B, T, I=24):
+    """Fused input projection (encoder layer 0 mode): x (B,L,F) windows are read directly, no gi tensor."""
+    rng = np.random.default_rng(11)
+    L = T + 3
+    win = rng.standard_normal((B, L, I)).astype(np.float32)
+    wint = T_(win, dev)
+    Y = torch.zeros(B, T + 2, 2 * H, device=dev)
+    hN = torch.zeros(B, 2 * H, device=dev)
+    rows, st, keep = [], [], []
+    for d in range(2):
+        W_ih, W_hh, b_ih, b_hh = _gru_weights(rng, I, H)
+        wpf, wpb, bgi, bhn = _pack(dev, W_hh, b_ih, b_hh, H)
+        wpx = torch.zeros(3 * H * 32, device=dev)
+        ops.gru_pack_x(T_(W_ih, dev), I, H, wpx)
+        stash = torch.zeros(ops.gru_stash_floats(B, T, H), device=dev)
+        rows.append({GF["GI"]: ops.addr(wint), GF["GI_ROW"]: L * I, GF["GI_T"]: I, GF["WP"]: ops.addr(wpf), GF["BHN"]: ops.addr(bhn),
+                     GF["Y"]: ops.addr(Y, 2 * H + d * H), GF["Y_ROW"]: (T + 2) * 2 * H, GF["Y_T"]: 2 * H, GF["HN"]: ops.addr(hN, d * H),
+                     GF["HN_ROW"]: 2 * H, GF["STASH"]: ops.addr(stash), GF["T"]: T, GF["REVERSE"]: d, GF["PAD"]: 1,
+                     GF["WPX"]: ops.addr(wpx), GF["BGI"]: ops.addr(bgi), GF["XF"]: I})
+        st.append((W_ih, W_hh, b_ih, b_hh))
+        keep.append((wpf, wpb, bgi, bhn, wpx, stash))
+    ops.gru_seq_fwd(rows, B, H)
+    Yn, hNn = N_(Y), N_(hN)
+    for d, (W_ih, W_hh, b_ih, b_hh) in enumerate(st):
+        out, hn, _ = vo.gru_dir_forward(win[:, :T], None, W_ih, W_hh, b_ih, b_hh, reverse=bool(d))
+        np.testing.assert_allclose(Yn[:, 1:T + 1, d * H:(d + 1) * H], out, atol=2e-5)
+        np.testing.assert_allclose(hNn[:, d * H:(d + 1) * H], hn, atol=2e-5)
+
+
 def check_gru_bwd(dev, H, B, T):
     x, st, Y, hN = run_gru_fwd(dev, H, B, T, seed=1)
     rng = np.random.default_rng(5)

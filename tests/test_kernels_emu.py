@@ -9,7 +9,7 @@ import torch
 
 from oracle import vame_oracle as vo
 from vame_amd import ops
-from kernel_cases import (check_adam, check_colsum, check_colsum_batch, check_gather, check_gemm_cases, check_gru_bwd, check_gru_fwd,
+from kernel_cases import (check_adam, check_colsum, check_colsum_batch, check_gather, check_gemm_cases, check_gru_bwd, check_gru_fwd, check_gru_fwd_fused,
                           check_latent, check_mse, check_nuclear)
 
 DEV = "cpu"
@@ -41,3 +41,8 @@ def test_elementwise(emu):
 @pytest.mark.parametrize("B,Z,k", [(64, 30, 30), (8, 30, 30), (50, 7, 4)])
 def test_nuclear(emu, B, Z, k):
     check_nuclear(DEV, B, Z, k)
+
+
+@pytest.mark.parametrize("H,B,T,I", [(32, 5, 4, 24), (64, 40, 3, 8)])
+def test_gru_fwd_fused_input(emu, H, B, T, I):
+    check_gru_fwd_fused(DEV, H, B, T, I)

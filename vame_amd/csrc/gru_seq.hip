@@ -21,6 +21,7 @@ struct GruFwdStream {
     float* hn; int64_t hn_row;
     float* stash;
     int64_t T, reverse, pad;
+    const float* wpx; const float* bgi; int64_t xf;      // fused input projection (xf = features, 0 = gi is precomputed)
 };
 struct GruFwdParams { GruFwdStream s[8]; int nstreams; int B; int ntiles; };
 
@@ -98,6 +99,28 @@ extern "C" int vame_gru_pack_f32(const float* W_hh, const float* b_ih, const flo
     return VAME_OK;
 }
 
+// wpx[(((w*4+c)*3+g)*64+l)*4+e] = W_ih[(g*H+32w+(l&31))*F + k], k = 8c+4(l>>5)+e (< F, else 0): the K = 32 (zero padded)
+// input projection of a layer whose input has F <= 32 features, in the same B-fragment order as wp_fwd
+__global__ __launch_bounds__(256) void gru_pack_x_kernel(const float* __restrict__ W, int F, int H, float* __restrict__ wpx) {
+    const int64_t n = (int64_t)3 * H * 32;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int e = i & 3, l = (i >> 2) & 63;
+        int64_t r = i >> 8;
+        const int g = r % 3; r /= 3;
+        const int c = r % 4, w = r / 4;
+        const int k = 8 * c + 4 * (l >> 5) + e;
+        wpx[i] = k < F ? W[(int64_t)(g * H + 32 * w + (l & 31)) * F + k] : 0.0f;
+    }
+}
+
+extern "C" int vame_gru_pack_x_f32(const float* W_ih, int F, int H, float* wpx, void* stream) {
+    VAME_CHECK_ARG(H >= 32 && H % 32 == 0 && F >= 1 && F <= 32, VAME_E_SHAPE, "gru_pack_x: H=%d F=%d (need F <= 32)", H, F);
+    VAME_CHECK_ARG(W_ih && wpx, VAME_E_BADARG, "gru_pack_x: null pointer");
+    hipLaunchKernelGGL(gru_pack_x_kernel, dim3((unsigned)cdiv64(3 * H * 32, 256)), dim3(256), 0, (hipStream_t)stream, W_ih, F, H, wpx);
+    VAME_LAUNCH_CHECK("gru_pack_x");
+    return VAME_OK;
+}
+
 extern "C" int64_t vame_gru_stash_floats(int B, int T, int H) {
     return cdiv64(B, 32) * 32 * (int64_t)T * 5 * H;
 }
@@ -120,10 +143,13 @@ extern "C" int64_t vame_gru_stash_floats(int B, int T, int H) {
 //   d * {cA, cB, u} or a product with r / gh_n, so the backward kernel needs neither n nor h_prev.
 // ABL (ablation mask, 0 in production; tools/microbench.py VAME_ABL_FWD): 1 no stash stores, 2 no gi loads,
 // 4 no y stores, 8 no gate transcendental math, 16 W fragments not re-streamed, 32 no per-step barrier
-template <int H, int ABL = 0>
+// XIN: the input projection x_t W_ih^T (F <= 32 features, zero padded to K = 32) is computed in-kernel as four extra
+// MFMA chunks per step from an LDS-staged (32 x F) tile of x_t; no gi tensor exists (encoder layer 0).
+template <int H, int ABL = 0, bool XIN = false>
 __global__ __launch_bounds__(H / 32 * 64) void gru_seq_fwd_kernel(GruFwdParams P) {
-    constexpr int NW = H / 32, LDH = H + 4, KC = H / 8;
+    constexpr int NW = H / 32, LDH = H + 4, KC = H / 8, LDX = 36;
     __shared__ float hs[2][32 * LDH];
+    __shared__ float xs[XIN ? 2 : 1][XIN ? 32 * LDX : 4];
     int sidx, tile;
     if (!map_block(P.nstreams, P.ntiles, sidx, tile)) return;
     const GruFwdStream& S = P.s[sidx];
@@ -157,9 +183,36 @@ __global__ __launch_bounds__(H / 32 * 64) void gru_seq_fwd_kernel(GruFwdParams P
         hprev[r] = v;
         hs[0][row * LDH + col0 + li] = v;
     }
+    // fused input: thread -> (row, float4 column) of the (32 x F) x_t tile; columns F..31 of the LDS tile stay zero
+    constexpr int XI = XIN ? (32 * 8 + NW * 64 - 1) / (NW * 64) : 1;      // x-tile items per thread (1 for H >= 128)
+    const int nq = XIN ? (int)S.xf / 4 : 1;
+    float4 xv[XI];
+    auto load_x = [&](int t) {
+#pragma unroll
+        for (int i = 0; i < XI; ++i) {
+            const int idx = tid + i * NW * 64, xr = idx / nq, xq = idx % nq;
+            xv[i] = (idx < 32 * nq && xr < nvalid)
+                        ? *reinterpret_cast<const float4*>(S.gi + (int64_t)(row0 + xr) * S.gi_row + (int64_t)t * S.gi_t + 4 * xq)
+                        : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    auto store_x = [&](float* buf) {
+#pragma unroll
+        for (int i = 0; i < XI; ++i) {
+            const int idx = tid + i * NW * 64, xr = idx / nq, xq = idx % nq;
+            if (idx < 32 * nq) *reinterpret_cast<float4*>(&buf[xr * LDX + 4 * xq]) = xv[i];
+        }
+    };
+    if (XIN) {
+        for (int i = tid; i < 2 * 32 * LDX; i += NW * 64) (&xs[0][0])[i] = 0.f;
+        load_x(S.reverse ? T - 1 : 0);
+    }
     __syncthreads();
+    if (XIN) store_x(xs[0]);
     if (y_tile && S.pad) store_h(hs[0], S.reverse ? T : -1);
     const float bhn = S.bhn[col0 + li];
+    const float bgr = XIN ? S.bgi[col0 + li] : 0.f, bgu = XIN ? S.bgi[H + col0 + li] : 0.f, bgn = XIN ? S.bgi[2 * H + col0 + li] : 0.f;
+    const float4* __restrict__ wpx = XIN ? reinterpret_cast<const float4*>(S.wpx) + (int64_t)w * 4 * 3 * 64 + lane : nullptr;
     const float4* __restrict__ wp = reinterpret_cast<const float4*>(S.wp) + (int64_t)w * KC * 3 * 64 + lane;
     float4* stash = S.stash ? reinterpret_cast<float4*>(S.stash) : nullptr;
     int cur = 0;
@@ -182,17 +235,40 @@ __global__ __launch_bounds__(H / 32 * 64) void gru_seq_fwd_kernel(GruFwdParams P
             }
         }
     };
-    load_gi(S.reverse ? T - 1 : 0);
-    constexpr int PD = 4;                       // KC % PD == 0 for every supported H
+    if (!XIN) load_gi(S.reverse ? T - 1 : 0);
+    constexpr int PD = 4;                       // KC % PD == 0 for every supported H; the fused input has exactly PD chunks
     float4 wq[PD][3];
+    {
+        const float4* w0 = XIN ? wpx : wp;
 #pragma unroll
-    for (int c = 0; c < PD; ++c) { wq[c][0] = wp[(c * 3 + 0) * 64]; wq[c][1] = wp[(c * 3 + 1) * 64]; wq[c][2] = wp[(c * 3 + 2) * 64]; }
+        for (int c = 0; c < PD; ++c) { wq[c][0] = w0[(c * 3 + 0) * 64]; wq[c][1] = w0[(c * 3 + 1) * 64]; wq[c][2] = w0[(c * 3 + 2) * 64]; }
+    }
+    if (XIN) __syncthreads();
     for (int step = 0; step < T; ++step) {
         const int t = S.reverse ? T - 1 - step : step;
-        f32x16 ar = gr, au = gu, ani = gn, anh;
+        f32x16 ar, au, ani, anh;
+        if (XIN) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) anh[r] = bhn;
-        if (step + 1 < T && S.gi_t != 0) load_gi(S.reverse ? t - 1 : t + 1);     // in flight during the k-loop
+            for (int r = 0; r < 16; ++r) { ar[r] = bgr; au[r] = bgu; ani[r] = bgn; anh[r] = bhn; }
+            if (step + 1 < T) load_x(S.reverse ? t - 1 : t + 1);
+            // input projection: K = 32 from the LDS x tile; the ring is refilled with the first W_hh chunks
+            const float* xrow = &xs[cur][li * LDX + 4 * hh];
+#pragma unroll
+            for (int j = 0; j < PD; ++j) {
+                const float4 a = *reinterpret_cast<const float4*>(xrow + 8 * j);
+                const float4 b0 = wq[j][0], b1 = wq[j][1], b2 = wq[j][2];
+                wq[j][0] = wp[(j * 3 + 0) * 64]; wq[j][1] = wp[(j * 3 + 1) * 64]; wq[j][2] = wp[(j * 3 + 2) * 64];
+                ar = MFMA_32x32x2(a.x, b0.x, ar); au = MFMA_32x32x2(a.x, b1.x, au); ani = MFMA_32x32x2(a.x, b2.x, ani);
+                ar = MFMA_32x32x2(a.y, b0.y, ar); au = MFMA_32x32x2(a.y, b1.y, au); ani = MFMA_32x32x2(a.y, b2.y, ani);
+                ar = MFMA_32x32x2(a.z, b0.z, ar); au = MFMA_32x32x2(a.z, b1.z, au); ani = MFMA_32x32x2(a.z, b2.z, ani);
+                ar = MFMA_32x32x2(a.w, b0.w, ar); au = MFMA_32x32x2(a.w, b1.w, au); ani = MFMA_32x32x2(a.w, b2.w, ani);
+            }
+        } else {
+            ar = gr; au = gu; ani = gn;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) anh[r] = bhn;
+            if (step + 1 < T && S.gi_t != 0) load_gi(S.reverse ? t - 1 : t + 1);     // in flight during the k-loop
+        }
         const float* hrow = &hs[cur][li * LDH + 4 * hh];
         // software pipeline, distance PD chunks: W_hh fragments (L2) are requested PD x 12 MFMAs ahead of use; the
         // first PD chunks of a step were requested before the previous step's epilogue (they do not depend on h)
@@ -203,7 +279,9 @@ __global__ __launch_bounds__(H / 32 * 64) void gru_seq_fwd_kernel(GruFwdParams P
             const int c = c0 + j;
             const float4 a = *reinterpret_cast<const float4*>(hrow + 8 * c);
             const float4 b0 = wq[j][0], b1 = wq[j][1], b2 = wq[j][2];
-            {
+            if (XIN && c0 + PD == KC) {        // last group: the ring wraps into the next step's input-projection chunks
+                wq[j][0] = wpx[(j * 3 + 0) * 64]; wq[j][1] = wpx[(j * 3 + 1) * 64]; wq[j][2] = wpx[(j * 3 + 2) * 64];
+            } else {
                 const int cn = (ABL & 16) ? 0 : (c + PD == KC + j ? j : c + PD);      // wraps into the next step's first chunks
                 wq[j][0] = wp[(cn * 3 + 0) * 64]; wq[j][1] = wp[(cn * 3 + 1) * 64]; wq[j][2] = wp[(cn * 3 + 2) * 64];
             }
@@ -240,6 +318,7 @@ __global__ __launch_bounds__(H / 32 * 64) void gru_seq_fwd_kernel(GruFwdParams P
                 sp[(4 * 4 + q) * 64] = make_float4(anh[4 * q], anh[4 * q + 1], anh[4 * q + 2], anh[4 * q + 3]);
             }
         }
+        if (XIN) store_x(xs[cur ^ 1]);
         if (!(ABL & 32)) __syncthreads();
         cur ^= 1;
         if (!(ABL & 4) && y_tile) store_h(hs[cur], t);
@@ -414,7 +493,8 @@ static void launch_fwd(const GruFwdParams& P, hipStream_t st) {
         default: break;
     }
 #endif
-    hipLaunchKernelGGL((gru_seq_fwd_kernel<H, 0>), dim3(grid_blocks(P.nstreams, P.ntiles)), dim3(H / 32 * 64), 0, st, P);
+    if (P.s[0].xf > 0) hipLaunchKernelGGL((gru_seq_fwd_kernel<H, 0, true>), dim3(grid_blocks(P.nstreams, P.ntiles)), dim3(H / 32 * 64), 0, st, P);
+    else hipLaunchKernelGGL((gru_seq_fwd_kernel<H, 0, false>), dim3(grid_blocks(P.nstreams, P.ntiles)), dim3(H / 32 * 64), 0, st, P);
 }
 template <int H>
 static void launch_bwd(const GruBwdParams& P, hipStream_t st) {
@@ -443,7 +523,12 @@ extern "C" int vame_gru_seq_fwd_f32(const int64_t* desc, int nstreams, int B, in
         s.hn = (float*)d[GF_HN]; s.hn_row = d[GF_HN_ROW];
         s.stash = (float*)d[GF_STASH];
         s.T = d[GF_T]; s.reverse = d[GF_REVERSE]; s.pad = d[GF_PAD];
+        s.wpx = (const float*)d[GF_WPX]; s.bgi = (const float*)d[GF_BGI]; s.xf = d[GF_XF];
         VAME_CHECK_ARG(s.gi && s.wp && s.bhn, VAME_E_BADARG, "gru_seq_fwd: stream %d: gi/wp/bhn null", i);
+        VAME_CHECK_ARG((s.xf > 0) == (P.s[0].xf > 0), VAME_E_BADARG, "gru_seq_fwd: fused-input and gi streams cannot share a launch");
+        VAME_CHECK_ARG(s.xf == 0 || (s.wpx && s.bgi && s.xf <= 32 && s.xf % 4 == 0 && s.gi_row % 4 == 0 && s.gi_t % 4 == 0 &&
+                                     (uintptr_t)s.gi % 16 == 0), VAME_E_SHAPE,
+                       "gru_seq_fwd: stream %d: fused input needs F <= 32, F %% 4 == 0 and 16-byte aligned rows", i);
         VAME_CHECK_ARG(s.T >= 1, VAME_E_SHAPE, "gru_seq_fwd: stream %d: T=%lld", i, (long long)s.T);
     }
     hipStream_t st = (hipStream_t)stream;

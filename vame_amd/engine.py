@@ -59,6 +59,7 @@ class GruDir:
         self.w_ih, self.w_hh = f"{prefix}.weight_ih{sfx}", f"{prefix}.weight_hh{sfx}"
         self.b_ih, self.b_hh = f"{prefix}.bias_ih{sfx}", f"{prefix}.bias_hh{sfx}"
         self.H, self.I = H, I
+        self.wp_x = torch.empty(3 * H * 32, device=dev) if (I <= 32 and I % 4 == 0) else None    # fused input projection
         self.wp_fwd = torch.empty(3 * H * H, device=dev)
         self.wp_bwd = torch.empty(3 * H * H, device=dev)
         self.bias_gi = torch.empty(3 * H, device=dev)
@@ -106,6 +107,9 @@ class VAEEngine:
         t = self.table
         for d in self._all_dirs():
             ops.gru_pack(self._pv(d.w_hh), self._pv(d.b_ih), self._pv(d.b_hh), d.H, d.wp_fwd, d.wp_bwd, d.bias_gi, d.b_hn)
+        for d in self.enc[0]:
+            if d.wp_x is not None:
+                ops.gru_pack_x(self._pv(d.w_ih), d.I, d.H, d.wp_x)
         self.packed_version = self.version
 
     def _pv(self, name):
@@ -159,11 +163,18 @@ class VAEEngine:
         Y0 = self.buf("Y0", B, T + 2, 2 * H)
         hn = self.buf("hn", B, 4 * H)
         rows = []
+        # layer 0: F <= 32 features -> the input projection runs inside the sequence kernel on the window tile itself
+        fused = self.enc[0][0].wp_x is not None and win_row % 4 == 0 and win.data_ptr() % 16 == 0
         for dirn, d in enumerate(self.enc[0]):
-            gi = self.buf(f"gi_e0_{dirn}", B, T, 3 * H)
-            ops.gemm(B * T, 3 * H, F, x_op, 0, self.P(d.w_ih, F), 0, gi, 3 * H, bias=d.bias_gi)
             st = self.buf(f"st_e0_{dirn}", ops.gru_stash_floats(B, T, H)) if training else None
-            rows.append(self._gru_fwd_stream(d, gi, T * 3 * H, 3 * H, None, 0, Y0, 2 * H, T, dirn, hn, dirn * H, 4 * H, st, T))
+            if fused:
+                row = self._gru_fwd_stream(d, win, win_row, F, None, 0, Y0, 2 * H, T, dirn, hn, dirn * H, 4 * H, st, T)
+                row.update({GF["WPX"]: ops.addr(d.wp_x), GF["BGI"]: ops.addr(d.bias_gi), GF["XF"]: F})
+            else:
+                gi = self.buf(f"gi_e0_{dirn}", B, T, 3 * H)
+                ops.gemm(B * T, 3 * H, F, x_op, 0, self.P(d.w_ih, F), 0, gi, 3 * H, bias=d.bias_gi)
+                row = self._gru_fwd_stream(d, gi, T * 3 * H, 3 * H, None, 0, Y0, 2 * H, T, dirn, hn, dirn * H, 4 * H, st, T)
+            rows.append(row)
         ops.gru_seq_fwd(rows, B, H)
         y_op = Operand(Y0, 2 * H, off=2 * H, seg=T, seg_stride=(T + 2) * 2 * H)
         Y1 = self.buf("Y1", B, T + 2, 2 * H) if training else None

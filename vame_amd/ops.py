@@ -5,7 +5,7 @@ import torch
 from . import _lib
 
 GF = dict(GI=0, GI_ROW=1, GI_T=2, WP=3, BHN=4, H0=5, H0_ROW=6, Y=7, Y_ROW=8, Y_T=9, HN=10, HN_ROW=11, STASH=12, T=13,
-          REVERSE=14, PAD=15, N=16)
+          REVERSE=14, PAD=15, WPX=16, BGI=17, XF=18, N=20)
 GB = dict(STASH=0, Y=1, Y_ROW=2, Y_T=3, H0=4, H0_ROW=5, WPT=6, DY=7, DY_ROW=8, DY_T=9, DHN=10, DHN_ROW=11, DG=12, DH0=13,
           DH0_ROW=14, DBIAS=15, RESERVED=16, T=17, REVERSE=18, PAD=19, N=20)
 
@@ -74,6 +74,11 @@ def gru_pack(W_hh, b_ih, b_hh, H, wp_fwd, wp_bwd, bias_gi, b_hn):
     rc = _lib.lib().vame_gru_pack_f32(_ptr(W_hh), _ptr(b_ih), _ptr(b_hh), H, _ptr(wp_fwd), _ptr(wp_bwd), _ptr(bias_gi),
                                       _ptr(b_hn), _stream())
     _lib.check(rc, "vame_gru_pack_f32")
+
+
+def gru_pack_x(W_ih, F, H, wpx):
+    rc = _lib.lib().vame_gru_pack_x_f32(_ptr(W_ih), F, H, _ptr(wpx), _stream())
+    _lib.check(rc, "vame_gru_pack_x_f32")
 
 
 def gru_stash_floats(B, T, H):
