@@ -64,6 +64,11 @@ class DeviceWindowLoader:
         self.rank, self.world = rank, world
         self.Xn = torch.from_numpy(dataset.normalised_f32()).to(device).contiguous()
         self.n_batches = self.N // (self.B * world)
+        # window starts travel through two pinned staging buffers so the 8*B-byte upload never blocks the host
+        pin = device.type == "cuda"
+        self._stage = [torch.empty(self.B, dtype=torch.int64, pin_memory=pin) for _ in range(2)]
+        self._ev = [None, None]
+        self._k = 0
 
     def __len__(self):
         return self.n_batches
@@ -73,7 +78,14 @@ class DeviceWindowLoader:
         return s[self.rank * self.B:(self.rank + 1) * self.B]
 
     def gather(self, starts):
-        st = torch.from_numpy(np.ascontiguousarray(starts, dtype=np.int64)).to(self.dev, non_blocking=True)
+        k = self._k = self._k ^ 1
+        if self._ev[k] is not None:
+            self._ev[k].synchronize()                   # the copy that last used this staging buffer has finished
+        self._stage[k].copy_(torch.from_numpy(np.ascontiguousarray(starts, dtype=np.int64)))
+        st = self._stage[k].to(self.dev, non_blocking=True)
+        if self.dev.type == "cuda":
+            self._ev[k] = torch.cuda.Event()
+            self._ev[k].record()
         out = torch.empty(self.B, self.L, self.F, device=self.dev)
         ops.window_gather(self.Xn, self.N, self.F, st, 0, self.B, self.L, out)
         return out
