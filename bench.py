@@ -188,7 +188,7 @@ def cpu_baseline():
 
 
 def main():
-    global B_LOCAL
+    global B_LOCAL, H, T, MFLOP_PER_WINDOW_TRAIN
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
@@ -199,6 +199,8 @@ def main():
     ap.add_argument("--mode", choices=["train", "embed"], default="train",
                     help="train = the headline metric; embed = encoder-only embedd_latent_vectors sweep (BASELINE config 5)")
     ap.add_argument("--embed-windows", type=int, default=2_000_000)
+    ap.add_argument("--hidden", type=int, default=H, help="exploration only (BASELINE config 4 uses 512)")
+    ap.add_argument("--time-window", type=int, default=T, help="exploration only (BASELINE config 4 uses 60)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -218,6 +220,12 @@ def main():
     from vame_amd.model.rnn_vae import FusedAdamAMSGrad, allreduce_gradients
 
     B_LOCAL = args.batch
+    if (args.hidden, args.time_window) != (H, T):          # non-headline shape: recompute the algorithmic flops per window
+        H, T = args.hidden, args.time_window
+        fwd = 2 * T * 2 * 3 * H * (F + H) + 2 * T * 2 * 3 * H * (2 * H + H) + 2 * 2 * 4 * H * Z     # encoder L0 + L1, Lambda
+        for st in (T, FS):                                                                         # decoder, future decoder
+            fwd += 2 * Z * 2 * H + 2 * 2 * 3 * H * Z + 2 * st * 2 * 3 * H * H + 2 * st * 2 * H * F
+        MFLOP_PER_WINDOW_TRAIN = 3 * fwd / 1e6
     torch.manual_seed(19)
     if args.mode == "embed":
         return bench_embed(args, dev, rank, world)
@@ -284,11 +292,11 @@ def main():
                     by_class={c: dict(ms_per_step=round(e["ms"], 3), tflops=round(e["flops"] / (e["ms"] * 1e-3) / 1e12, 2))
                               for c, e in classes.items()},
                     timed_kernel_ms_per_step=round(total_ms, 3))
-        out = dict(metric="temporal windows/sec (train) T=30,F=24,h=256", value=round(value, 1), unit="windows/s", n_gpus=world,
+        out = dict(metric=f"temporal windows/sec (train) T={T},F={F},h={H}", value=round(value, 1), unit="windows/s", n_gpus=world,
                    steps=args.steps, warmup=args.warmup, ms_per_step=round(dt / args.steps * 1e3, 3), higher_is_better=True,
                    scaling="weak", vs_baseline=None, dtype="f32", data="synthetic",
-                   config=dict(workload="BASELINE.json configs[1]: T=30,F=24,zdims=30,hidden=256,FS=15, batch=4096/GPU fp32 train step "
-                                        "(gather+fwd+loss+bwd+allreduce+Adam-amsgrad)", global_batch=B_LOCAL * world,
+                   config=dict(workload=(f"BASELINE.json configs[1]: T={T},F={F},zdims={Z},hidden={H},FS={FS}, batch={B_LOCAL}/GPU fp32 train step "
+                                         "(gather+fwd+loss+bwd+allreduce+Adam-amsgrad)"), global_batch=B_LOCAL * world,
                                parallelism=f"dp{world}", last_loss_terms=last),
                    roofline=roof)
         if not args.no_cpu_baseline and world == 1:

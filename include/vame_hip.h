@@ -95,6 +95,15 @@ enum vame_gru_bwd_field {
 };
 int vame_gru_seq_bwd_f32(const int64_t* desc, int nstreams, int B, int H, void* stream);
 
+/* Per-step GRU cell for hidden sizes beyond the persistent sequence kernels (H > 256, BASELINE config 4): the gate GEMM
+ * gh = h_{t-1} W_hh^T is a vame_gemm_f32 call (a real dense contraction at batch x hidden = 8192 x 512) and these
+ * kernels apply the gate math of torch.nn.GRU (vame/model/rnn_model.py:34-35).  gi includes b_ih + [b_hr,b_hz,0];
+ * stash row = [cA|cB|u|r|gh_n] (5H); backward: dh in/out (B,H), dG row = [da_r|da_z|dgi_n|dgh_n], dgh = [da_r|da_z|dgh_n]. */
+int vame_gru_cell_fwd_f32(const float* gi, int64_t gi_row, const float* gh, const float* bhn, const float* hprev, int64_t hp_row,
+                          float* hout, int64_t ho_row, float* stash, int64_t st_row, int B, int H, void* stream);
+int vame_gru_cell_bwd_f32(const float* stash, int64_t st_row, float* dh, const float* dy, int64_t dy_row, float* dG,
+                          int64_t dg_row, float* dgh, int B, int H, void* stream);
+
 /* Lambda reparameterisation + KL partials (vame/model/rnn_model.py:63-76, vame/model/rnn_vae.py:53-60).
  *   mu, lv_raw (B,Z) -> logvar (softplus optional), z = eps*exp(0.5*logvar)+mu (training) or mu;
  *   kl_out[0] += sum(1 + logvar - mu^2 - exp(logvar))   (caller zeroes kl_out). */

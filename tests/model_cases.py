@@ -15,10 +15,12 @@ def build_model(g, dev):
     return model.to(dev), (T, F, Z, H, FS, fut, sp)
 
 
-def check_step(dev, name, kw, mse="sum", tol_grad=3e-4, via_autograd=False):
+def check_step(dev, name, kw, mse="sum", tol_grad=3e-4, via_autograd=False, stepwise=False):
     g = load_golden(name)
     model, (T, F, Z, H, FS, fut, sp) = build_model(g, dev)
     model.train()
+    if stepwise:                                  # force the large-H per-step path on a small model
+        model._ensure_engine().stepwise = True
     x, xfut, eps = [torch.from_numpy(g[k]).to(dev) for k in ("x", "xfut", "eps")]
     B = x.shape[0]
     tag = f"kw{kw:g}/"

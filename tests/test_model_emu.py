@@ -26,3 +26,9 @@ def test_decoder_h0_view(emu):
 
 def test_noise_option_separate_encoder_input(emu):
     check_noise_input("cpu")
+
+
+@pytest.mark.parametrize("name,kw", [("step_tiny", 1.0), ("step_tiny_oddB", 1.0), ("step_h64", 0.5)])
+def test_stepwise_large_h_path_matches_reference(emu, name, kw):
+    """The per-step GEMM + gate-kernel path used for H > 256, forced on small models."""
+    check_step("cpu", name, kw, stepwise=True)

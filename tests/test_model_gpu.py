@@ -93,3 +93,36 @@ def test_embedding_matches_reference_loop(hip):
 
 def test_noise_option_separate_encoder_input(hip):
     check_noise_input("cuda")
+
+
+def test_stepwise_path_small_models(hip):
+    from model_cases import check_step
+    check_step("cuda", "step_tiny", 1.0, stepwise=True)
+    check_step("cuda", "step_h64", 0.5, stepwise=True)
+
+
+def test_cfg4_shape_h512_t60_vs_oracle(hip):
+    """BASELINE config 4 shape (hidden=512, T=60, 2-layer bi-GRU encoder): per-step MFMA gate-GEMM path vs the numpy oracle."""
+    T, F, Z, H, FS, B = 60, 24, 30, 512, 15, 48
+    torch.manual_seed(19)
+    model = RNN_VAE(2 * T, Z, F, 1, FS, H, H, H, H, 0, 0, 0, False)
+    p = {k: v.numpy().copy() for k, v in model.state_dict().items()}
+    model = model.cuda().train()
+    assert model._ensure_engine().stepwise
+    rng = np.random.default_rng(4)
+    win = rng.standard_normal((B, T + FS, F)).astype(np.float32)
+    eps = rng.standard_normal((B, Z)).astype(np.float32)
+    out = model.loss_step(torch.from_numpy(win).cuda(), 1.0, beta=1.0, kloss=Z, klmbda=0.1, bsize=B, eps=torch.from_numpy(eps).cuda()).cpu().numpy()
+    spec = vo.Spec(T=T, F=F, Z=Z, H=H, FS=FS)
+    cache = vo.FwdCache()
+    x, xf = win[:, :T], win[:, T:]
+    res = vo.model_forward(p, x, eps, spec, True, cache)
+    L = vo.total_loss(*res, x, xf, spec, 1.0)
+    for i, k in enumerate(["rec", "fut", "kl", "kmeans"]):
+        assert abs(out[i] - L[k]) <= 1e-4 * max(1.0, abs(L[k])), (k, out[i], L[k])
+    eng = model._engine
+    assert np.abs(eng.buf("mu", B, Z)[:B * Z].view(B, Z).cpu().numpy() - res[3]).max() < 1e-4
+    grads = vo.model_backward(p, cache, spec, x, xf, 1.0)
+    for k, prm in model.named_parameters():
+        r = grads[k]
+        np.testing.assert_allclose(prm.grad.cpu().numpy(), r, atol=5e-4 * max(1.0, np.abs(r).max()), err_msg=k)

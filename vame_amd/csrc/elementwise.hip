@@ -295,6 +295,74 @@ extern "C" int vame_axpy_f32(const float* x, float a, float* y, int64_t n, void*
     return VAME_OK;
 }
 
+// --------------------------------------------------------------------------------- per-step GRU cell (large-H path)
+// For hidden sizes beyond the persistent sequence kernels (H > 256) the recurrence runs step by step: the gate GEMM
+// h_{t-1} W_hh^T (M = batch, a real dense contraction at those sizes) goes through vame_gemm_f32 and these two kernels
+// do the gate math.  Same stash contents (cA, cB, u, r, gh_n) as the sequence kernels, row-major (B, 5H) per step.
+__global__ __launch_bounds__(256) void gru_cell_fwd_kernel(const float* __restrict__ gi, int64_t gi_row, const float* __restrict__ gh,
+                                                           const float* __restrict__ bhn, const float* __restrict__ hprev,
+                                                           int64_t hp_row, float* __restrict__ hout, int64_t ho_row,
+                                                           float* __restrict__ stash, int64_t st_row, int B, int H) {
+    const int64_t n = (int64_t)B * H;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t b = i / H;
+        const int j = (int)(i % H);
+        const float* g = gi + b * gi_row + j;
+        const float* q = gh + b * 3 * H + j;
+        const float ghn = q[2 * H] + bhn[j];
+        const float r = fast_sigmoid(g[0] + q[0]);
+        const float u = fast_sigmoid(g[H] + q[H]);
+        const float nn = fast_tanh(g[2 * H] + r * ghn);
+        const float hp = hprev ? hprev[b * hp_row + j] : 0.f;
+        hout[b * ho_row + j] = nn + u * (hp - nn);
+        if (stash) {
+            float* s = stash + b * st_row + j;
+            const float omu = 1.0f - u;
+            s[0] = omu * (1.0f - nn * nn); s[H] = (hp - nn) * u * omu; s[2 * H] = u; s[3 * H] = r; s[4 * H] = ghn;
+        }
+    }
+}
+
+extern "C" int vame_gru_cell_fwd_f32(const float* gi, int64_t gi_row, const float* gh, const float* bhn, const float* hprev,
+                                     int64_t hp_row, float* hout, int64_t ho_row, float* stash, int64_t st_row, int B, int H,
+                                     void* stream) {
+    VAME_CHECK_ARG(gi && gh && bhn && hout && B >= 1 && H >= 1, VAME_E_BADARG, "gru_cell_fwd: bad argument");
+    hipLaunchKernelGGL(gru_cell_fwd_kernel, dim3(ew_blocks((int64_t)B * H)), dim3(256), 0, (hipStream_t)stream, gi, gi_row, gh, bhn,
+                       hprev, hp_row, hout, ho_row, stash, st_row, B, H);
+    VAME_LAUNCH_CHECK("gru_cell_fwd");
+    return VAME_OK;
+}
+
+// dh (B,H): in = gradient wrt h_t carried from the later steps, out = d*u (the part flowing through the update gate;
+// the caller adds dgh W_hh with an accumulating GEMM).  dG row = [da_r | da_z | dgi_n | dgh_n], dgh (B,3H) = [da_r|da_z|dgh_n].
+__global__ __launch_bounds__(256) void gru_cell_bwd_kernel(const float* __restrict__ stash, int64_t st_row, float* __restrict__ dh,
+                                                           const float* __restrict__ dy, int64_t dy_row, float* __restrict__ dG,
+                                                           int64_t dg_row, float* __restrict__ dgh, int B, int H) {
+    const int64_t n = (int64_t)B * H;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t b = i / H;
+        const int j = (int)(i % H);
+        const float* s = stash + b * st_row + j;
+        const float d = dh[i] + (dy ? dy[b * dy_row + j] : 0.f);
+        const float r = s[3 * H];
+        const float dan = d * s[0], dau = d * s[H], dghn = dan * r, dar = dghn * s[4 * H] * (1.0f - r);
+        dh[i] = d * s[2 * H];
+        float* o = dG + b * dg_row + j;
+        o[0] = dar; o[H] = dau; o[2 * H] = dan; o[3 * H] = dghn;
+        float* q = dgh + b * 3 * H + j;
+        q[0] = dar; q[H] = dau; q[2 * H] = dghn;
+    }
+}
+
+extern "C" int vame_gru_cell_bwd_f32(const float* stash, int64_t st_row, float* dh, const float* dy, int64_t dy_row, float* dG,
+                                     int64_t dg_row, float* dgh, int B, int H, void* stream) {
+    VAME_CHECK_ARG(stash && dh && dG && dgh && B >= 1 && H >= 1, VAME_E_BADARG, "gru_cell_bwd: bad argument");
+    hipLaunchKernelGGL(gru_cell_bwd_kernel, dim3(ew_blocks((int64_t)B * H)), dim3(256), 0, (hipStream_t)stream, stash, st_row, dh, dy,
+                       dy_row, dG, dg_row, dgh, B, H);
+    VAME_LAUNCH_CHECK("gru_cell_bwd");
+    return VAME_OK;
+}
+
 // --------------------------------------------------------------------------------- nuclear norm
 // Symmetric eigen-decomposition of G/bsize (Z<=64) by parallel-ordered cyclic Jacobi in fp64: a
 // round-robin schedule gives Z/2 disjoint rotations per round, applied as a column pass and a row

@@ -15,6 +15,7 @@ Sequences are stored as (B, T+2, 2H): slot 0 / T+1 hold the initial state of the
 reverse direction so h_{t-1} is a plain strided view for the BPTT kernels and the dW_hh GEMMs.
 """
 from dataclasses import dataclass
+from types import SimpleNamespace
 
 import torch
 
@@ -83,8 +84,11 @@ class VAEEngine:
         self.spec, self.table, self.p, self.g = spec, table, flat_p, flat_g
         self.dev = flat_p.device
         H, F, Z = spec.H, spec.F, spec.Z
-        if H % 32 or H > 256:
-            raise ValueError(f"hidden size {H}: the gfx950 GRU kernels support multiples of 32 up to 256")
+        if H % 32 or H > 1024:
+            raise ValueError(f"hidden size {H}: the gfx950 GRU kernels support multiples of 32 up to 1024")
+        # H <= 256: persistent sequence kernels (h and the gate tiles stay on chip for all T steps).  Larger H: the gate
+        # GEMM per step is a real dense contraction (M = batch) -> per-step vame_gemm_f32 + gate-math kernels
+        self.stepwise = H > 256
         e = "encoder.encoder_rnn"
         self.enc = [[GruDir(e, "_l0", H, F, self.dev), GruDir(e, "_l0_reverse", H, F, self.dev)],
                     [GruDir(e, "_l1", H, 2 * H, self.dev), GruDir(e, "_l1_reverse", H, 2 * H, self.dev)]]
@@ -144,11 +148,71 @@ class VAEEngine:
         ops.gemm(M, N, K, A, 1, B, 1, self.g, N, c_off=self.table.off(gname) + row_off * N, splitk=sk, ws=ws,
                  a_gap_at=gap_at, a_gap=gap)
 
+    # ------------------------------------------------------------------ GRU sequence dispatch
+    def _gru_fwd(self, rows, B):
+        if not self.stepwise:
+            return ops.gru_seq_fwd(rows, B, self.spec.H)
+        for r in rows:
+            self._stepwise_fwd(r["_s"], B)
+
+    def _gru_bwd(self, rows, B):
+        if not self.stepwise:
+            return ops.gru_seq_bwd(rows, B, self.spec.H)
+        for r in rows:
+            self._stepwise_bwd(r["_s"], B)
+
+    def _stepwise_fwd(self, s, B):
+        """One (layer,direction) stream step by step: gh = h_{t-1} W_hh^T (GEMM) then the gate kernel."""
+        H, d, T = self.spec.H, s.d, s.T
+        Yrow, col = (s.y_T + 2) * 2 * H, s.dirn * H
+        Y = s.Y if (s.Y is not None and s.write_y) else self.buf("Y_step", B, s.y_T + 2, 2 * H)
+        yv = Y[:B * Yrow].view(B, s.y_T + 2, 2 * H)
+        slot0 = T + 1 if s.dirn else 0                            # padded slot holding the initial state
+        if s.h0 is not None:
+            yv[:, slot0, col:col + H].copy_(s.h0[s.h0_off:s.h0_off + B * H].view(B, H))
+        else:
+            yv[:, slot0, col:col + H].zero_()
+        gh = self.buf("gh_step", B, 3 * H)
+        for step in range(T):
+            t = T - 1 - step if s.dirn else step
+            hp_off = ((t + 2) if s.dirn else t) * 2 * H + col     # previous state: time t-1 (fwd) / t+1 (reverse)
+            ops.gemm(B, 3 * H, H, Operand(Y, Yrow, off=hp_off), 0, self.P(d.w_hh, H), 0, gh, 3 * H)
+            ops.gru_cell_fwd(s.gi, t * s.gi_t, s.gi_row, gh, d.b_hn, Y, hp_off, Yrow, Y, (t + 1) * 2 * H + col, Yrow,
+                             s.stash, t * 5 * H if s.stash is not None else 0, T * 5 * H, B, H)
+        if s.hn is not None:
+            last = 1 if s.dirn else T
+            rows = s.hn.numel() // s.hn_row
+            s.hn[:rows * s.hn_row].view(rows, s.hn_row)[:B, s.hn_off:s.hn_off + H].copy_(yv[:, last, col:col + H])
+
+    def _stepwise_bwd(self, s, B):
+        H, d, T = self.spec.H, s.d, s.T
+        dh, dgh = self.buf("dh_step", B, H), self.buf("dgh_step", B, 3 * H)
+        dhv = dh[:B * H].view(B, H)
+        if s.dhn is not None:
+            rows = s.dhn.numel() // s.dhn_row
+            dhv.copy_(s.dhn[:rows * s.dhn_row].view(rows, s.dhn_row)[:B, s.dhn_off:s.dhn_off + H])
+        else:
+            dhv.zero_()
+        for step in range(T):
+            fstep = T - 1 - step
+            t = T - 1 - fstep if s.dirn else fstep
+            ops.gru_cell_bwd(s.stash, t * 5 * H, T * 5 * H, dh, s.dY, (t * 2 * H + s.dirn * H) if s.dY is not None else 0,
+                             s.dy_T * 2 * H, s.dG, t * 4 * H, T * 4 * H, dgh, B, H)
+            ops.gemm(B, H, 3 * H, Operand(dgh, 3 * H), 0, self.P(d.w_hh, H), 1, dh, H, accumulate=True)
+        if s.dh0 is not None:
+            s.dh0[s.dh0_off:s.dh0_off + B * H].view(B, H).copy_(dhv)
+        ntiles = (B + 31) // 32                                   # bias partials: everything in row 0 of the (ntiles,4H) buffer
+        s.dbias[:ntiles * 4 * H].zero_()
+        ops.colsum(s.dG, 0, B * T, 4 * H, 4 * H, s.dbias, 0)
+
     # ------------------------------------------------------------------ forward
     def _gru_fwd_stream(self, d: GruDir, gi, gi_row, gi_t, h0, h0_off, Y, y_cols, y_T, dirn, hn, hn_off, hn_row, stash, T,
                         write_y=True):
         H = self.spec.H
-        return {GF["GI"]: ops.addr(gi), GF["GI_ROW"]: gi_row, GF["GI_T"]: gi_t, GF["WP"]: ops.addr(d.wp_fwd),
+        spec = SimpleNamespace(d=d, gi=gi, gi_row=gi_row, gi_t=gi_t, h0=h0, h0_off=h0_off, Y=Y, y_T=y_T, dirn=dirn, hn=hn,
+                               hn_off=hn_off, hn_row=hn_row, stash=stash, T=T, write_y=write_y)
+        return {"_s": spec,
+                GF["GI"]: ops.addr(gi), GF["GI_ROW"]: gi_row, GF["GI_T"]: gi_t, GF["WP"]: ops.addr(d.wp_fwd),
                 GF["BHN"]: ops.addr(d.b_hn), GF["H0"]: ops.addr(h0, h0_off) if h0 is not None else 0, GF["H0_ROW"]: H,
                 GF["Y"]: ops.addr(Y, y_cols + dirn * H) if (write_y and Y is not None) else 0,
                 GF["Y_ROW"]: (y_T + 2) * 2 * H, GF["Y_T"]: 2 * H,
@@ -164,7 +228,7 @@ class VAEEngine:
         hn = self.buf("hn", B, 4 * H)
         rows = []
         # layer 0: F <= 32 features -> the input projection runs inside the sequence kernel on the window tile itself
-        fused = self.enc[0][0].wp_x is not None and win_row % 4 == 0 and win.data_ptr() % 16 == 0
+        fused = (not self.stepwise) and self.enc[0][0].wp_x is not None and win_row % 4 == 0 and win.data_ptr() % 16 == 0
         for dirn, d in enumerate(self.enc[0]):
             st = self.buf(f"st_e0_{dirn}", ops.gru_stash_floats(B, T, H)) if training else None
             if fused:
@@ -175,7 +239,7 @@ class VAEEngine:
                 ops.gemm(B * T, 3 * H, F, x_op, 0, self.P(d.w_ih, F), 0, gi, 3 * H, bias=d.bias_gi)
                 row = self._gru_fwd_stream(d, gi, T * 3 * H, 3 * H, None, 0, Y0, 2 * H, T, dirn, hn, dirn * H, 4 * H, st, T)
             rows.append(row)
-        ops.gru_seq_fwd(rows, B, H)
+        self._gru_fwd(rows, B)
         y_op = Operand(Y0, 2 * H, off=2 * H, seg=T, seg_stride=(T + 2) * 2 * H)
         Y1 = self.buf("Y1", B, T + 2, 2 * H) if training else None
         rows = []
@@ -185,7 +249,7 @@ class VAEEngine:
             st = self.buf(f"st_e1_{dirn}", ops.gru_stash_floats(B, T, H)) if training else None
             rows.append(self._gru_fwd_stream(d, gi, T * 3 * H, 3 * H, None, 0, Y1, 2 * H, T, dirn, hn, (2 + dirn) * H, 4 * H, st, T,
                                              write_y=training))
-        ops.gru_seq_fwd(rows, B, H)
+        self._gru_fwd(rows, B)
         return hn
 
     def latent(self, hn, B, eps, training, want_kl=True):
@@ -222,7 +286,7 @@ class VAEEngine:
         rows = []
         Yd = self._decode_one("dec", "decoder", self.dec, T, z, B, training, rows)
         Yf = self._decode_one("fut", "decoder_future", self.fut, FS, z, B, training, rows) if s.future else None
-        ops.gru_seq_fwd(rows, B, H)
+        self._gru_fwd(rows, B)
         pred = self.buf("pred", B, T, F)
         ops.gemm(B * T, F, 2 * H, Operand(Yd, 2 * H, off=2 * H, seg=T, seg_stride=(T + 2) * 2 * H), 0,
                  self.P("decoder.hidden_to_output.weight", 2 * H), 0, pred, F, bias=self._pv("decoder.hidden_to_output.bias"))
@@ -284,7 +348,10 @@ class VAEEngine:
     # ------------------------------------------------------------------ backward
     def _gru_bwd_stream(self, d, stash, Y, y_T, dirn, dY, dy_T, dhn, dhn_off, dhn_row, dG, dh0, dh0_off, dbias, T):
         H = self.spec.H
-        return {GB["STASH"]: ops.addr(stash), GB["Y"]: ops.addr(Y, 2 * H + dirn * H), GB["Y_ROW"]: (y_T + 2) * 2 * H,
+        spec = SimpleNamespace(d=d, stash=stash, Y=Y, y_T=y_T, dirn=dirn, dY=dY, dy_T=dy_T, dhn=dhn, dhn_off=dhn_off, dhn_row=dhn_row,
+                               dG=dG, dh0=dh0, dh0_off=dh0_off, dbias=dbias, T=T)
+        return {"_s": spec,
+                GB["STASH"]: ops.addr(stash), GB["Y"]: ops.addr(Y, 2 * H + dirn * H), GB["Y_ROW"]: (y_T + 2) * 2 * H,
                 GB["Y_T"]: 2 * H, GB["WPT"]: ops.addr(d.wp_bwd),
                 GB["DY"]: ops.addr(dY, dirn * H) if dY is not None else 0, GB["DY_ROW"]: dy_T * 2 * H, GB["DY_T"]: 2 * H,
                 GB["DHN"]: ops.addr(dhn, dhn_off) if dhn is not None else 0, GB["DHN_ROW"]: dhn_row, GB["DG"]: ops.addr(dG),
@@ -345,7 +412,7 @@ class VAEEngine:
             rows_f, per_f, Yf, dhid_f = self._decoder_backward("fut", "decoder_future", self.fut, FS, self.buf("dfut", B, FS, F), B, dz, False)
             rows += rows_f
             groups.append(("decoder_future", per_f, Yf, dhid_f, FS))
-        ops.gru_seq_bwd(rows, B, H)
+        self._gru_bwd(rows, B)
         first = True
         for name, per, Y, dhid, steps in groups:
             for dirn, (d, dG, dbias, dgsum) in enumerate(per):
@@ -385,7 +452,7 @@ class VAEEngine:
             st = self.buf(f"st_e1_{dirn}", ops.gru_stash_floats(B, T, H))
             rows.append(self._gru_bwd_stream(d, st, Y1, T, dirn, None, T, dhn, (2 + dirn) * H, 4 * H, dG, None, 0, dbias, T))
             per.append((d, dG, dbias))
-        ops.gru_seq_bwd(rows, B, H)
+        self._gru_bwd(rows, B)
         dY0 = self.buf("dY0", B, T, 2 * H)
         y0rows = Operand(Y0, 2 * H, off=2 * H, seg=T, seg_stride=(T + 2) * 2 * H)
         for dirn, (d, dG, dbias) in enumerate(per):
@@ -399,7 +466,7 @@ class VAEEngine:
             st = self.buf(f"st_e0_{dirn}", ops.gru_stash_floats(B, T, H))
             rows.append(self._gru_bwd_stream(d, st, Y0, T, dirn, dY0, T, dhn, dirn * H, 4 * H, dG, None, 0, dbias, T))
             per.append((d, dG, dbias))
-        ops.gru_seq_bwd(rows, B, H)
+        self._gru_bwd(rows, B)
         xrows = Operand(self._win, F, seg=T, seg_stride=self._win_row)
         for dirn, (d, dG, dbias) in enumerate(per):
             self._gru_param_grads(d, dG, dbias, ntiles, B, T, Y0, dirn, xrows, F)

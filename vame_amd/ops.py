@@ -89,7 +89,8 @@ def _desc_tensor(rows, nfields):
     d = torch.zeros(len(rows), nfields, dtype=torch.int64)
     for i, r in enumerate(rows):
         for k, v in r.items():
-            d[i, k] = int(v)
+            if isinstance(k, int):
+                d[i, k] = int(v)
     return d
 
 
@@ -104,6 +105,18 @@ def gru_seq_bwd(streams, B, H):
     d = _desc_tensor(streams, GB["N"])
     rc = _lib.lib().vame_gru_seq_bwd_f32(d.data_ptr(), len(streams), B, H, _stream())
     _lib.check(rc, "vame_gru_seq_bwd_f32")
+
+
+def gru_cell_fwd(gi, gi_off, gi_row, gh, bhn, hprev, hp_off, hp_row, hout, ho_off, ho_row, stash, st_off, st_row, B, H):
+    rc = _lib.lib().vame_gru_cell_fwd_f32(_ptr(gi, gi_off), gi_row, _ptr(gh), _ptr(bhn), _ptr(hprev, hp_off), hp_row,
+                                          _ptr(hout, ho_off), ho_row, _ptr(stash, st_off), st_row, B, H, _stream())
+    _lib.check(rc, "vame_gru_cell_fwd_f32")
+
+
+def gru_cell_bwd(stash, st_off, st_row, dh, dy, dy_off, dy_row, dG, dg_off, dg_row, dgh, B, H):
+    rc = _lib.lib().vame_gru_cell_bwd_f32(_ptr(stash, st_off), st_row, _ptr(dh), _ptr(dy, dy_off), dy_row, _ptr(dG, dg_off), dg_row,
+                                          _ptr(dgh), B, H, _stream())
+    _lib.check(rc, "vame_gru_cell_bwd_f32")
 
 
 def latent_fwd(mu, lv_raw, eps, B, Z, softplus, training, logvar, z, kl_out):
