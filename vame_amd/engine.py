@@ -193,12 +193,15 @@ class VAEEngine:
             dhv.copy_(s.dhn[:rows * s.dhn_row].view(rows, s.dhn_row)[:B, s.dhn_off:s.dhn_off + H])
         else:
             dhv.zero_()
+        # (B x H) has few 128x128 tiles: split K = 3H three ways so the per-step GEMM fills the 256 CUs
+        sk_b = 3 if ((B + 127) // 128) * ((H + 127) // 128) < 512 else 1
+        ws_b = self.ws.get("splitk_step", sk_b * B * H, self.dev) if sk_b > 1 else None
         for step in range(T):
             fstep = T - 1 - step
             t = T - 1 - fstep if s.dirn else fstep
             ops.gru_cell_bwd(s.stash, t * 5 * H, T * 5 * H, dh, s.dY, (t * 2 * H + s.dirn * H) if s.dY is not None else 0,
                              s.dy_T * 2 * H, s.dG, t * 4 * H, T * 4 * H, dgh, B, H)
-            ops.gemm(B, H, 3 * H, Operand(dgh, 3 * H), 0, self.P(d.w_hh, H), 1, dh, H, accumulate=True)
+            ops.gemm(B, H, 3 * H, Operand(dgh, 3 * H), 0, self.P(d.w_hh, H), 1, dh, H, accumulate=True, splitk=sk_b, ws=ws_b)
         if s.dh0 is not None:
             s.dh0[s.dh0_off:s.dh0_off + B * H].view(B, H).copy_(dhv)
         ntiles = (B + 31) // 32                                   # bias partials: everything in row 0 of the (ntiles,4H) buffer
