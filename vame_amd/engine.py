@@ -425,7 +425,7 @@ class VAEEngine:
                 first = False
             wl = f"{name}.latent_to_hidden.weight"
             self._gemm_wgrad(2 * H, Z, B, Operand(dhid, 2 * H), Operand(z, Z), wl)
-            self._colsum_jobs.append((dhid, 0, B, 2 * H, 2 * H, self.g, t.off(f"{name}.latent_to_hidden.bias")))
+            ops.colsum(dhid, 0, B, 2 * H, 2 * H, self.g, t.off(f"{name}.latent_to_hidden.bias"))
             ops.gemm(B, Z, 2 * H, Operand(dhid, 2 * H), 0, self.P(wl, Z), 1, dz, Z, accumulate=True, splitk=0)
         if use_minv and kl_weight != 0:
             ops.gemm(B, Z, Z, Operand(z, Z), 0, Operand(self.buf("Minv", Z, Z), Z), 1, dz, Z, accumulate=True)
@@ -444,7 +444,7 @@ class VAEEngine:
         dhn = self.buf("dhn", B, 4 * H)
         for nm, dv, first in (("lmbda.hidden_to_mean", dmu, True), ("lmbda.hidden_to_logvar", dlv, False)):
             self._gemm_wgrad(Z, 4 * H, B, Operand(dv, Z), Operand(hn, 4 * H), nm + ".weight")
-            self._colsum_jobs.append((dv, 0, B, Z, Z, self.g, t.off(nm + ".bias")))
+            ops.colsum(dv, 0, B, Z, Z, self.g, t.off(nm + ".bias"))
             ops.gemm(B, 4 * H, Z, Operand(dv, Z), 0, self.P(nm + ".weight", 4 * H), 1, dhn, 4 * H, accumulate=not first)
         # ---- encoder layer 1
         Y0, Y1 = self.buf("Y0", B, T + 2, 2 * H), self.buf("Y1", B, T + 2, 2 * H)
