@@ -82,6 +82,27 @@ def ablate():
         os.environ[var] = "0"
 
 
+def gemm_tiles(rounds=4):
+    """Interleaved A/B of GEMM tile configurations (library built with `make ab`): 0 = 128x128/4 waves, 1 = 256x128/4 waves
+    (128x64 per wave), 2 = 256x128/8 waves."""
+    import statistics
+    BT = 4096 * 30
+    shapes = [(BT, 768, 512, 0, 0, 1), (BT, 512, 768, 0, 1, 1), (768, 512, BT, 1, 1, 32), (768, 256, BT, 1, 1, 64), (768, 256, BT, 1, 1, 32),
+              (4096, 4096, 4096, 1, 1, 1)]
+    for (M, N, K, akm, bkm, sk) in shapes:
+        A = torch.randn((K, M) if akm else (M, K), device=dev)
+        B = torch.randn((K, N) if bkm else (N, K), device=dev)
+        C = torch.empty(M, N, device=dev)
+        ws = torch.empty(sk * M * N, device=dev) if sk > 1 else None
+        res = {v: [] for v in (0, 1, 2)}
+        for r in range(rounds):
+            for v in res:
+                os.environ["VAME_GEMM_TILE"] = str(v)
+                ms = timeit(lambda: ops.gemm(M, N, K, Operand(A, A.shape[1]), akm, Operand(B, B.shape[1]), bkm, C, N, splitk=sk, ws=ws), reps=5)
+                res[v].append(2.0 * M * N * K / ms / 1e9)
+        print(f"M={M} N={N} K={K} akm={akm} bkm={bkm} sk={sk}: " + "  ".join(f"tile{v}: {statistics.median(t):6.1f}" for v, t in res.items()))
+
+
 def gemm_ab(rounds=4):
     """Interleaved A/B of the GEMM kernel variants (library built with `make ab`)."""
     BT = 4096 * 30
@@ -102,6 +123,9 @@ def gemm_ab(rounds=4):
 
 
 if __name__ == "__main__":
+    if len(sys.argv) > 2 and sys.argv[2] == "gemm_tiles":
+        gemm_tiles()
+        sys.exit(0)
     if len(sys.argv) > 2 and sys.argv[2] == "gemm_ab":
         gemm_ab()
         sys.exit(0)

@@ -168,7 +168,7 @@ struct TileIO {
 
 // VAR (tuning variants, tools/microbench.py A/B): 1 unpredicated interior fetch, 4 s_setprio around the MFMAs
 template <int BM, int BN, int WM, int WN, bool AKM, bool BKM, int VAR>
-__global__ __launch_bounds__(WM * WN * 64, 3) void gemm_kernel(GemmParams p) {
+__global__ __launch_bounds__(WM * WN * 64, (BM / WM) * (BN / WN) > 64 * 64 ? 2 : 3) void gemm_kernel(GemmParams p) {
     constexpr int BK = 32, NT = WM * WN * 64, TM = BM / WM / 32, TN = BN / WN / 32;
     typedef TileIO<BK, BM, NT, AKM, BKM> TA;      // x-major image only for the A operand of the NN form
     typedef TileIO<BK, BN, NT, BKM, false> TB;
@@ -318,6 +318,12 @@ extern "C" int vame_gemm_f32(int M, int N, int K, const float* A, int64_t lda, i
     hipStream_t st = (hipStream_t)stream;
     int rc;
     if (M <= 32 && N > 64) rc = launch_gemm<32, 128, 1, 4>(p, a_kmajor, b_kmajor, st);      // skinny outputs (dW of the 24/30-row heads)
+#if !defined(VAME_EMU) && defined(VAME_GEMM_AB)
+    else if (N > 64 && getenv("VAME_GEMM_TILE") && atoi(getenv("VAME_GEMM_TILE")) == 1 && M >= 256)
+        rc = launch_gemm<256, 128, 2, 2>(p, a_kmajor, b_kmajor, st);                          // 128x64 per wave (A/B tuning build only)
+    else if (N > 64 && getenv("VAME_GEMM_TILE") && atoi(getenv("VAME_GEMM_TILE")) == 2 && M >= 256)
+        rc = launch_gemm<256, 128, 4, 2>(p, a_kmajor, b_kmajor, st);                          // 8 waves, 64x64 per wave
+#endif
     else if (N > 64) rc = launch_gemm<128, 128, 2, 2>(p, a_kmajor, b_kmajor, st);
     else if (N > 32) rc = launch_gemm<128, 64, 4, 1>(p, a_kmajor, b_kmajor, st);
     else rc = launch_gemm<128, 32, 4, 1>(p, a_kmajor, b_kmajor, st);
