@@ -126,3 +126,29 @@ def test_cfg4_shape_h512_t60_vs_oracle(hip):
     for k, prm in model.named_parameters():
         r = grads[k]
         np.testing.assert_allclose(prm.grad.cpu().numpy(), r, atol=5e-4 * max(1.0, np.abs(r).max()), err_msg=k)
+
+
+def test_large_batch_step_vs_torch_cpu_reference(hip):
+    """H=256 model, batch 2048: fused HIP step vs the stock-torch CPU restatement with the reference's own (B,B) SVD loss."""
+    from oracle.torch_ref import TorchRef, reference_loss
+    T, F, Z, H, FS, B = 30, 24, 30, 256, 15, 2048
+    torch.manual_seed(19)
+    model = RNN_VAE(2 * T, Z, F, 1, FS, H, H, H, H, 0, 0, 0, False)
+    sd = {k: v.clone() for k, v in model.state_dict().items()}
+    ref = TorchRef(T, F, Z, H, FS)
+    ref.load_reference_state(sd)
+    ref.train()
+    gen = torch.Generator().manual_seed(2)
+    win = torch.randn(B, T + FS, F, generator=gen)
+    eps = torch.randn(B, Z, generator=gen)
+    torch.set_num_threads(min(16, len(__import__("os").sched_getaffinity(0))))
+    loss, terms = reference_loss(ref(win[:, :T], eps), win[:, :T], win[:, T:], 1.0)
+    loss.backward()
+    model = model.cuda().train()
+    out = model.loss_step(win.cuda(), 1.0, beta=1.0, kloss=Z, klmbda=0.1, bsize=B, eps=eps.cuda()).cpu().numpy()
+    for i, (k, v) in enumerate(zip(["rec", "fut", "kl", "kmeans"], terms)):
+        assert abs(out[i] - v.item()) <= 1e-4 * max(1.0, abs(v.item())), (k, out[i], v.item())
+    rg = ref.reference_named_grads()
+    for k, prm in model.named_parameters():
+        r = rg[k].numpy()
+        np.testing.assert_allclose(prm.grad.cpu().numpy(), r, atol=1e-3 * max(1.0, np.abs(r).max()), err_msg=k)
