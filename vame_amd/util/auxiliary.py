@@ -9,13 +9,6 @@ from pathlib import Path
 
 import yaml
 
-# optional keys added by this build (a stock VAME config.yaml keeps working without them)
-AMD_DEFAULTS = {
-    "amd_reference_rng": False,       # draw eps / window starts exactly like the reference's CPU streams (parity runs)
-    "amd_log_every_epoch": True,
-}
-
-
 def read_config(configname):
     path = Path(configname)
     if not os.path.exists(path):
