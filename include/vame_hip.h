@@ -128,6 +128,12 @@ int vame_mse_fwd_bwd_f32(const float* pred, const float* target, int64_t tgt_row
 int vame_nuclear_f32(const float* G, int Z, int kloss, int nrows, float lmbda, float bsize, float gscale,
                      float* loss_out, float* Minv, double* vstate, void* stream);
 
+/* k-means E-step over the latent vectors (vame/analysis/pose_segmentation.py:141,179 run sklearn KMeans on
+ * the embedding): labels[i] = argmin_k |X_i - C_k|^2 (ties -> lowest k), mind2[i] = that squared distance (optional),
+ * onehot (N,Kp) rows (optional) so the M-step sums = onehot^T X is a vame_gemm_f32 call. */
+int vame_kmeans_assign_f32(const float* X, int64_t N, int D, const float* C, int K, int* labels, float* mind2,
+                           float* onehot, int Kp, void* stream);
+
 /* out[b,c] = sum_t in[(b*T+t)*ld + c], c < C (C % 4 == 0): sum over time of a (B,T,ld) sequence -- the
  * gradient wrt the time-constant decoder input z (vame/model/rnn_model.py:169-170). */
 int vame_timesum_f32(const float* in, int B, int T, int C, int64_t ld, float* out, void* stream);

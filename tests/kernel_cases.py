@@ -287,3 +287,33 @@ def check_nuclear(dev, B, Z, k):
     ref_loss2, ref_dz2 = vo.cluster_loss_gram(z2, k, 0.1, B)
     assert abs(N_(loss)[0] - ref_loss2) <= 1e-5 * max(1, abs(ref_loss2))
     np.testing.assert_allclose(z2 @ N_(Minv), ref_dz2, atol=2e-5 * max(1, np.abs(ref_dz2).max()))
+
+
+def check_kmeans(dev, N=3000, K=6, D=30, n_init=3):
+    """GPU k-means vs scikit-learn: same partition on separable data, inertia within rounding; the E-step kernel
+    vs a numpy argmin."""
+    from sklearn.cluster import KMeans
+    from sklearn.metrics import adjusted_rand_score
+    from vame_amd.analysis.kmeans_hip import KMeansHIP
+    rng = np.random.default_rng(0)
+    cent = rng.standard_normal((K, D)) * 4
+    X = (cent[rng.integers(0, K, N)] + rng.standard_normal((N, D))).astype(np.float32)
+    C = X[rng.choice(N, K, replace=False)]
+    labels = torch.empty(N, dtype=torch.int32, device=dev)
+    mind2 = torch.empty(N, device=dev)
+    Kp = (K + 3) // 4 * 4
+    onehot = torch.empty(N, Kp, device=dev)
+    ops.kmeans_assign(T_(X, dev), N, D, T_(C, dev), K, labels, mind2, onehot, Kp)
+    d2 = ((X[:, None, :].astype(np.float64) - C[None].astype(np.float64)) ** 2).sum(-1)
+    np.testing.assert_array_equal(N_(labels), d2.argmin(1))
+    np.testing.assert_allclose(N_(mind2), d2.min(1), rtol=1e-5)
+    oh = N_(onehot)
+    assert (oh.sum(1) == 1).all() and (oh.argmax(1) == d2.argmin(1)).all()
+    km = KMeansHIP(K, n_init=n_init, random_state=42).fit(X)
+    sk = KMeans(init="k-means++", n_clusters=K, random_state=42, n_init=n_init).fit(X)
+    assert abs(km.inertia_ - sk.inertia_) <= 1e-5 * sk.inertia_
+    assert adjusted_rand_score(sk.labels_, km.labels_) == 1.0
+    assert (km.predict(X) == km.labels_).all()
+    order = np.argsort(km.cluster_centers_[:, 0])
+    order_sk = np.argsort(sk.cluster_centers_[:, 0])
+    np.testing.assert_allclose(km.cluster_centers_[order], sk.cluster_centers_[order_sk], atol=1e-4)

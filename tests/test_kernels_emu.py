@@ -9,7 +9,7 @@ import torch
 
 from oracle import vame_oracle as vo
 from vame_amd import ops
-from kernel_cases import (check_adam, check_colsum, check_colsum_batch, check_gather, check_gemm_cases, check_gru_bwd, check_gru_fwd, check_gru_fwd_fused,
+from kernel_cases import (check_adam, check_colsum, check_colsum_batch, check_kmeans, check_gather, check_gemm_cases, check_gru_bwd, check_gru_fwd, check_gru_fwd_fused,
                           check_latent, check_mse, check_nuclear)
 
 DEV = "cpu"
@@ -46,3 +46,7 @@ def test_nuclear(emu, B, Z, k):
 @pytest.mark.parametrize("H,B,T,I", [(32, 5, 4, 24), (64, 40, 3, 8)])
 def test_gru_fwd_fused_input(emu, H, B, T, I):
     check_gru_fwd_fused(DEV, H, B, T, I)
+
+
+def test_kmeans_next_row_n1(emu):
+    check_kmeans(DEV)

@@ -1,7 +1,7 @@
 """The kernel checks of test_kernels_emu.py on the real MI355X through libvame_hip.so (C ABI)."""
 import pytest
 
-from kernel_cases import (check_adam, check_colsum, check_colsum_batch, check_gather, check_gemm_cases, check_gru_bwd, check_gru_fwd, check_gru_fwd_fused,
+from kernel_cases import (check_adam, check_colsum, check_colsum_batch, check_kmeans, check_gather, check_gemm_cases, check_gru_bwd, check_gru_fwd, check_gru_fwd_fused,
                           check_latent, check_mse, check_nuclear)
 
 pytestmark = pytest.mark.gpu
@@ -39,3 +39,8 @@ def test_nuclear(hip, B, Z, k):
 @pytest.mark.parametrize("H,B,T,I", [(32, 5, 4, 24), (64, 40, 3, 8), (256, 100, 30, 24), (256, 4096, 3, 24)])
 def test_gru_fwd_fused_input(hip, H, B, T, I):
     check_gru_fwd_fused(DEV, H, B, T, I)
+
+
+def test_kmeans_next_row_n1(hip):
+    check_kmeans(DEV)
+    check_kmeans(DEV, N=200000, K=15, D=30, n_init=2)

@@ -102,8 +102,21 @@ def get_motif_usage(label):
     return usage
 
 
-def same_parameterization(cfg, files, latent_vector_files, states, parameterization):
+def _kmeans_cls(cfg):
+    """scikit-learn by default (the reference's exact behaviour); cfg['amd_gpu_kmeans']: True runs the same algorithm on
+    the MI355X (vame_amd/analysis/kmeans_hip.py) -- not bit-identical to scikit-learn, see that module."""
+    if cfg.get('amd_gpu_kmeans', False):
+        from .kmeans_hip import KMeansHIP
+
+        def make(init, n_clusters, random_state, n_init):
+            return KMeansHIP(n_clusters, n_init=n_init, random_state=random_state)
+        return make
     from sklearn.cluster import KMeans
+    return KMeans
+
+
+def same_parameterization(cfg, files, latent_vector_files, states, parameterization):
+    KMeans = _kmeans_cls(cfg)
     labels, cluster_centers, motif_usages = [], [], []
     latent_vector_cat = np.concatenate(latent_vector_files, axis=0)
     if parameterization == "kmeans":
@@ -140,7 +153,7 @@ def same_parameterization(cfg, files, latent_vector_files, states, parameterizat
 
 
 def individual_parameterization(cfg, files, latent_vector_files, cluster):
-    from sklearn.cluster import KMeans
+    KMeans = _kmeans_cls(cfg)
     random_state = cfg['random_state_kmeans']          # the reference has a KeyError typo here (:175)
     n_init = cfg['n_init_kmeans']
     labels, cluster_centers, motif_usages = [], [], []

@@ -370,6 +370,60 @@ extern "C" int vame_gru_cell_bwd_f32(const float* stash, int64_t st_row, float* 
     return VAME_OK;
 }
 
+// --------------------------------------------------------------------------------- k-means E-step
+// Nearest-centre assignment over the (N, D) latent vectors (vame/analysis/pose_segmentation.py:141,179: sklearn KMeans on the
+// embedding).  HBM-bound scan: 4*D bytes in per row; rows are staged through LDS with coalesced loads, the K centres live in
+// LDS, each thread scores one row.  Writes label, squared distance to it and (optionally) a one-hot row so the M-step is a
+// deterministic split-K MFMA GEMM  sums = onehot^T X  (vame_gemm_f32) instead of float atomics.
+#define KM_ROWS 256
+__global__ __launch_bounds__(KM_ROWS) void kmeans_assign_kernel(const float* __restrict__ X, int64_t N, int D,
+                                                                const float* __restrict__ C, int K, int Kp,
+                                                                int* __restrict__ labels, float* __restrict__ mind2,
+                                                                float* __restrict__ onehot) {
+    VAME_DYN_SMEM(smem_raw);
+    float* cs = reinterpret_cast<float*>(smem_raw);          // [K][D]
+    float* xs = cs + ((K * D + 3) & ~3);                       // [KM_ROWS][D + 1]
+    const int DP = D + 1;
+    for (int i = threadIdx.x; i < K * D; i += KM_ROWS) cs[i] = C[i];
+    for (int64_t r0 = (int64_t)blockIdx.x * KM_ROWS; r0 < N; r0 += (int64_t)gridDim.x * KM_ROWS) {
+        const int nr = (int)(N - r0 < KM_ROWS ? N - r0 : KM_ROWS);
+        __syncthreads();
+        for (int i = threadIdx.x; i < nr * D; i += KM_ROWS) xs[(i / D) * DP + i % D] = X[r0 * D + i];      // contiguous block
+        __syncthreads();
+        if ((int)threadIdx.x < nr) {
+            const float* x = &xs[threadIdx.x * DP];
+            float best = 3.4e38f;
+            int bk = 0;
+            for (int k = 0; k < K; ++k) {
+                const float* c = &cs[k * D];
+                float d2 = 0.f;
+                for (int j = 0; j < D; ++j) { const float t = x[j] - c[j]; d2 = fmaf(t, t, d2); }
+                if (d2 < best) { best = d2; bk = k; }            // ties: lowest index, like argmin
+            }
+            const int64_t r = r0 + threadIdx.x;
+            labels[r] = bk;
+            if (mind2) mind2[r] = best;
+            if (onehot) {
+                float* o = onehot + r * Kp;
+                for (int k = 0; k < Kp; ++k) o[k] = k == bk ? 1.0f : 0.0f;
+            }
+        }
+    }
+}
+
+extern "C" int vame_kmeans_assign_f32(const float* X, int64_t N, int D, const float* C, int K, int* labels, float* mind2,
+                                      float* onehot, int Kp, void* stream) {
+    VAME_CHECK_ARG(X && C && labels && N >= 1 && D >= 1 && K >= 1, VAME_E_BADARG, "kmeans_assign: bad argument");
+    VAME_CHECK_ARG(!onehot || Kp >= K, VAME_E_SHAPE, "kmeans_assign: one-hot width %d < K=%d", Kp, K);
+    const size_t sh = (((size_t)K * D + 3) & ~(size_t)3) * 4 + (size_t)KM_ROWS * (D + 1) * 4;
+    VAME_CHECK_ARG(sh <= 150 * 1024, VAME_E_SHAPE, "kmeans_assign: K*D too large for LDS");
+    const int64_t nb = cdiv64(N, KM_ROWS);
+    hipLaunchKernelGGL(kmeans_assign_kernel, dim3((unsigned)(nb < 2048 ? nb : 2048)), dim3(KM_ROWS), sh, (hipStream_t)stream, X, N, D, C,
+                       K, Kp, labels, mind2, onehot);
+    VAME_LAUNCH_CHECK("kmeans_assign");
+    return VAME_OK;
+}
+
 // --------------------------------------------------------------------------------- nuclear norm
 // Symmetric eigen-decomposition of G/bsize (Z<=64) by parallel-ordered cyclic Jacobi in fp64: a
 // round-robin schedule gives Z/2 disjoint rotations per round, applied as a column pass and a row

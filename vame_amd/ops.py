@@ -146,6 +146,12 @@ def nuclear(G, Z, kloss, nrows, lmbda, bsize, loss_out, loss_off, Minv, gscale=1
     _lib.check(rc, "vame_nuclear_f32")
 
 
+def kmeans_assign(X, N, D, C, K, labels, mind2=None, onehot=None, Kp=0):
+    assert labels.dtype == torch.int32
+    rc = _lib.lib().vame_kmeans_assign_f32(_ptr(X), N, D, _ptr(C), K, labels.data_ptr(), _ptr(mind2), _ptr(onehot), Kp, _stream())
+    _lib.check(rc, "vame_kmeans_assign_f32")
+
+
 def timesum(inp, B, T, C, ld, out):
     rc = _lib.lib().vame_timesum_f32(_ptr(inp), B, T, C, ld, _ptr(out), _stream())
     _lib.check(rc, "vame_timesum_f32")
