@@ -376,36 +376,48 @@ extern "C" int vame_gru_cell_bwd_f32(const float* stash, int64_t st_row, float* 
 // LDS, each thread scores one row.  Writes label, squared distance to it and (optionally) a one-hot row so the M-step is a
 // deterministic split-K MFMA GEMM  sums = onehot^T X  (vame_gemm_f32) instead of float atomics.
 #define KM_ROWS 256
+// DP = feature count padded to a multiple of 4 (<= 64): the row lives in registers, centres are read from LDS as
+// broadcast float4's -> ~1 LDS instruction and 8 VALU per (centre, 4 features) per wave
+template <int DP>
 __global__ __launch_bounds__(KM_ROWS) void kmeans_assign_kernel(const float* __restrict__ X, int64_t N, int D,
                                                                 const float* __restrict__ C, int K, int Kp,
                                                                 int* __restrict__ labels, float* __restrict__ mind2,
                                                                 float* __restrict__ onehot) {
     VAME_DYN_SMEM(smem_raw);
-    float* cs = reinterpret_cast<float*>(smem_raw);          // [K][D]
-    float* xs = cs + ((K * D + 3) & ~3);                       // [KM_ROWS][D + 1]
-    const int DP = D + 1;
-    for (int i = threadIdx.x; i < K * D; i += KM_ROWS) cs[i] = C[i];
+    float* cs = reinterpret_cast<float*>(smem_raw);          // [K][DP], zero padded
+    float* xs = cs + K * DP;                                   // [KM_ROWS][DP + 1]
+    constexpr int LX = DP + 1;
+    for (int i = threadIdx.x; i < K * DP; i += KM_ROWS) { const int k = i / DP, j = i % DP; cs[i] = j < D ? C[k * D + j] : 0.f; }
     for (int64_t r0 = (int64_t)blockIdx.x * KM_ROWS; r0 < N; r0 += (int64_t)gridDim.x * KM_ROWS) {
         const int nr = (int)(N - r0 < KM_ROWS ? N - r0 : KM_ROWS);
         __syncthreads();
-        for (int i = threadIdx.x; i < nr * D; i += KM_ROWS) xs[(i / D) * DP + i % D] = X[r0 * D + i];      // contiguous block
+        for (int i = threadIdx.x; i < nr * D; i += KM_ROWS) xs[(i / D) * LX + i % D] = X[r0 * D + i];      // contiguous block, coalesced
         __syncthreads();
         if ((int)threadIdx.x < nr) {
-            const float* x = &xs[threadIdx.x * DP];
+            float x[DP];
+#pragma unroll
+            for (int j = 0; j < DP; ++j) x[j] = j < D ? xs[threadIdx.x * LX + j] : 0.f;
             float best = 3.4e38f;
             int bk = 0;
             for (int k = 0; k < K; ++k) {
-                const float* c = &cs[k * D];
-                float d2 = 0.f;
-                for (int j = 0; j < D; ++j) { const float t = x[j] - c[j]; d2 = fmaf(t, t, d2); }
+                const float4* c4 = reinterpret_cast<const float4*>(&cs[k * DP]);
+                float d0 = 0.f, d1 = 0.f;
+#pragma unroll
+                for (int q = 0; q < DP / 4; ++q) {
+                    const float4 c = c4[q];
+                    const float t0 = x[4 * q] - c.x, t1 = x[4 * q + 1] - c.y, t2 = x[4 * q + 2] - c.z, t3 = x[4 * q + 3] - c.w;
+                    d0 = fmaf(t0, t0, d0); d1 = fmaf(t1, t1, d1); d0 = fmaf(t2, t2, d0); d1 = fmaf(t3, t3, d1);
+                }
+                const float d2 = d0 + d1;
                 if (d2 < best) { best = d2; bk = k; }            // ties: lowest index, like argmin
             }
             const int64_t r = r0 + threadIdx.x;
             labels[r] = bk;
             if (mind2) mind2[r] = best;
             if (onehot) {
-                float* o = onehot + r * Kp;
-                for (int k = 0; k < Kp; ++k) o[k] = k == bk ? 1.0f : 0.0f;
+                float4* o = reinterpret_cast<float4*>(onehot + r * Kp);
+                for (int k4 = 0; k4 < Kp / 4; ++k4)
+                    o[k4] = make_float4(4 * k4 == bk ? 1.f : 0.f, 4 * k4 + 1 == bk ? 1.f : 0.f, 4 * k4 + 2 == bk ? 1.f : 0.f, 4 * k4 + 3 == bk ? 1.f : 0.f);
             }
         }
     }
@@ -414,12 +426,16 @@ __global__ __launch_bounds__(KM_ROWS) void kmeans_assign_kernel(const float* __r
 extern "C" int vame_kmeans_assign_f32(const float* X, int64_t N, int D, const float* C, int K, int* labels, float* mind2,
                                       float* onehot, int Kp, void* stream) {
     VAME_CHECK_ARG(X && C && labels && N >= 1 && D >= 1 && K >= 1, VAME_E_BADARG, "kmeans_assign: bad argument");
-    VAME_CHECK_ARG(!onehot || Kp >= K, VAME_E_SHAPE, "kmeans_assign: one-hot width %d < K=%d", Kp, K);
-    const size_t sh = (((size_t)K * D + 3) & ~(size_t)3) * 4 + (size_t)KM_ROWS * (D + 1) * 4;
+    VAME_CHECK_ARG(!onehot || (Kp >= K && Kp % 4 == 0 && (uintptr_t)onehot % 16 == 0), VAME_E_SHAPE,
+                   "kmeans_assign: one-hot width %d must be a multiple of 4 >= K=%d, 16-byte aligned", Kp, K);
+    VAME_CHECK_ARG(D <= 64, VAME_E_UNSUPPORTED, "kmeans_assign: D=%d > 64 features", D);
+    const int DP = D <= 32 ? 32 : 64;
+    const size_t sh = ((size_t)K * DP + (size_t)KM_ROWS * (DP + 1)) * 4;
     VAME_CHECK_ARG(sh <= 150 * 1024, VAME_E_SHAPE, "kmeans_assign: K*D too large for LDS");
     const int64_t nb = cdiv64(N, KM_ROWS);
-    hipLaunchKernelGGL(kmeans_assign_kernel, dim3((unsigned)(nb < 2048 ? nb : 2048)), dim3(KM_ROWS), sh, (hipStream_t)stream, X, N, D, C,
-                       K, Kp, labels, mind2, onehot);
+    const dim3 grid((unsigned)(nb < 4096 ? nb : 4096));
+    if (DP == 32) hipLaunchKernelGGL(kmeans_assign_kernel<32>, grid, dim3(KM_ROWS), sh, (hipStream_t)stream, X, N, D, C, K, Kp, labels, mind2, onehot);
+    else hipLaunchKernelGGL(kmeans_assign_kernel<64>, grid, dim3(KM_ROWS), sh, (hipStream_t)stream, X, N, D, C, K, Kp, labels, mind2, onehot);
     VAME_LAUNCH_CHECK("kmeans_assign");
     return VAME_OK;
 }
