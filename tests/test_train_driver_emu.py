@@ -86,3 +86,19 @@ def test_read_config_contract(tmp_path):
     cfg = read_config(str(p))
     assert cfg["project_path"] == str(tmp_path)                 # rewritten when the folder moved (auxiliary.py:139-142)
     assert yaml.safe_load(open(p))["project_path"] == str(tmp_path)
+
+
+def test_parameterization_with_gpu_kmeans_option(emu):
+    """cfg['amd_gpu_kmeans'] routes same_/individual_parameterization through KMeansHIP with the same return contract."""
+    from vame_amd.analysis.pose_segmentation import individual_parameterization, same_parameterization
+    rng = np.random.default_rng(1)
+    cent = rng.standard_normal((4, 30)) * 5
+    lat = [(cent[rng.integers(0, 4, n)] + 0.3 * rng.standard_normal((n, 30))).astype(np.float32) for n in (90, 70)]
+    cfg = dict(amd_gpu_kmeans=True, random_state_kmeans=42, n_init_kmeans=2, project_path="/tmp")
+    for fn, args in ((same_parameterization, (cfg, ["a", "b"], lat, 4, "kmeans")), (individual_parameterization, (cfg, ["a", "b"], lat, 4))):
+        labels, centers, usage = fn(*args)
+        assert [len(l) for l in labels] == [90, 70] and all(c.shape == (4, 30) for c in centers)
+        assert all(u.sum() == n for u, n in zip(usage, (90, 70)))
+        ref, _, _ = fn(dict(cfg, amd_gpu_kmeans=False), *args[1:])
+        from sklearn.metrics import adjusted_rand_score
+        assert all(adjusted_rand_score(a, b) == 1.0 for a, b in zip(labels, ref))
