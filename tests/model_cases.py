@@ -109,3 +109,48 @@ def check_noise_input(dev):
     for k, prm in model.named_parameters():
         r = grads[k]
         np.testing.assert_allclose(prm.grad.cpu().numpy(), r, atol=3e-4 * max(1.0, np.abs(r).max()), err_msg=k)
+
+
+def check_adam_trajectory(dev):
+    """Three optimizer steps (fused loss_step + FusedAdamAMSGrad) reproduce the reference's torch.optim.Adam(amsgrad=True)
+    trajectory recorded in step_tiny.npz (same eps per step): losses per step and all final weights."""
+    from vame_amd.model.rnn_vae import FusedAdamAMSGrad
+    g = load_golden("step_tiny")
+    model, (T, F, Z, H, FS, fut, sp) = build_model(g, dev)
+    model.train()
+    opt = FusedAdamAMSGrad(model, lr=5e-4)
+    win = torch.cat([torch.from_numpy(g["x"]), torch.from_numpy(g["xfut"])], 1).contiguous().to(dev)
+    B = win.shape[0]
+    for s_ in range(g["adam/eps"].shape[0]):
+        terms = model.loss_step(win, 1.0, beta=1.0, kloss=Z, klmbda=0.1, bsize=B, eps=torch.from_numpy(g["adam/eps"][s_]).to(dev)).cpu().numpy()
+        total = terms[0] + terms[1] + terms[2] + terms[3]
+        assert abs(total - g["adam/loss"][s_]) <= 1e-4 * abs(g["adam/loss"][s_])
+        opt.step()
+    sd = model.state_dict()
+    for k, v in golden_weights(g, "adam/w/").items():
+        np.testing.assert_allclose(sd[k].cpu().numpy(), v, atol=2e-5, err_msg=k)
+
+
+def check_odd_dims_vs_oracle(dev, F=10, Z=7, H=32, T=9, FS=4, B=5):
+    """Unaligned shapes (F, Z not multiples of 4; egocentric_data=False gives F = num_features - 2): exercises the scalar-load
+    GEMM paths and the non-fused layer-0 input projection, against the numpy oracle (no golden needed)."""
+    from oracle import vame_oracle as vo
+    torch.manual_seed(3)
+    model = RNN_VAE(2 * T, Z, F, 1, FS, H, H, H, H, 0, 0, 0, False)
+    p = {k: v.numpy().copy() for k, v in model.state_dict().items()}
+    model = model.to(dev).train()
+    rng = np.random.default_rng(9)
+    win = rng.standard_normal((B, T + FS, F)).astype(np.float32)
+    eps = rng.standard_normal((B, Z)).astype(np.float32)
+    out = model.loss_step(torch.from_numpy(win).to(dev), 0.7, beta=2.0, kloss=4, klmbda=0.3, bsize=B, eps=torch.from_numpy(eps).to(dev)).cpu().numpy()
+    spec = vo.Spec(T=T, F=F, Z=Z, H=H, FS=FS)
+    cache = vo.FwdCache()
+    x, xf = win[:, :T], win[:, T:]
+    res = vo.model_forward(p, x, eps, spec, True, cache)
+    L = vo.total_loss(*res, x, xf, spec, 0.7, beta=2.0, kloss=4, klmbda=0.3)
+    for i, k in enumerate(["rec", "fut", "kl", "kmeans"]):
+        assert abs(out[i] - L[k]) <= 1e-4 * max(1.0, abs(L[k])), (k, out[i], L[k])
+    grads = vo.model_backward(p, cache, spec, x, xf, 0.7, beta=2.0, kloss=4, klmbda=0.3)
+    for k, prm in model.named_parameters():
+        r = grads[k]
+        np.testing.assert_allclose(prm.grad.cpu().numpy(), r, atol=3e-4 * max(1.0, np.abs(r).max()), err_msg=k)

@@ -2,7 +2,7 @@
 reference's golden vectors (tiny model).  The same bodies run on the GPU in test_model_gpu.py."""
 import pytest
 
-from model_cases import check_eval_and_submodules, check_h0_view, check_noise_input, check_step
+from model_cases import check_adam_trajectory, check_odd_dims_vs_oracle, check_eval_and_submodules, check_h0_view, check_noise_input, check_step
 
 
 @pytest.mark.parametrize("name,kw,mse", [("step_tiny", 1.0, "sum"), ("step_tiny", 0.25, "sum"), ("step_tiny_oddB", 1.0, "sum"),
@@ -32,3 +32,12 @@ def test_noise_option_separate_encoder_input(emu):
 def test_stepwise_large_h_path_matches_reference(emu, name, kw):
     """The per-step GEMM + gate-kernel path used for H > 256, forced on small models."""
     check_step("cpu", name, kw, stepwise=True)
+
+
+def test_three_step_adam_trajectory_matches_reference(emu):
+    check_adam_trajectory("cpu")
+
+
+def test_unaligned_feature_and_latent_dims(emu):
+    check_odd_dims_vs_oracle("cpu")
+    check_odd_dims_vs_oracle("cpu", F=12, Z=30, H=64, T=6, FS=3, B=33)

@@ -5,7 +5,7 @@ import pytest
 import torch
 
 from conftest import load_golden
-from model_cases import check_eval_and_submodules, check_h0_view, check_noise_input, check_step
+from model_cases import check_adam_trajectory, check_odd_dims_vs_oracle, check_eval_and_submodules, check_h0_view, check_noise_input, check_step
 from oracle import vame_oracle as vo
 from vame_amd.model.rnn_model import RNN_VAE
 
@@ -152,3 +152,12 @@ def test_large_batch_step_vs_torch_cpu_reference(hip):
     for k, prm in model.named_parameters():
         r = rg[k].numpy()
         np.testing.assert_allclose(prm.grad.cpu().numpy(), r, atol=1e-3 * max(1.0, np.abs(r).max()), err_msg=k)
+
+
+def test_three_step_adam_trajectory_matches_reference(hip):
+    check_adam_trajectory("cuda")
+
+
+def test_unaligned_feature_and_latent_dims(hip):
+    check_odd_dims_vs_oracle("cuda")
+    check_odd_dims_vs_oracle("cuda", F=12, Z=30, H=64, T=6, FS=3, B=33)
