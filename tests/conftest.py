@@ -53,5 +53,8 @@ def hip():
     from vame_amd import _lib
     _reset_lib()
     assert torch.cuda.is_available(), "gpu tests need a GPU"
+    if not os.path.exists(_lib.LIB_PATH):                      # normally shipped by __graft_entry__.build(); hipcc is on the box too
+        import subprocess
+        subprocess.run(["make", "-s", "vame_amd/libvame_hip.so"], cwd=ROOT, check=True)
     _lib.lib()
     yield _lib
