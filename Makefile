@@ -15,7 +15,7 @@ tests/emu/libvame_emu.so: $(SRC) $(HDR) tests/emu/hip_emu.h tests/emu/hip_emu.cp
 
 # tuning build with all GEMM variants selectable through VAME_GEMM_VAR (tools/microbench.py ab)
 ab: $(SRC) $(HDR)
-	$(HIPCC) --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -DVAME_GEMM_AB -o tools/libvame_hip_ab.so $(SRC)
+	$(HIPCC) --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -DVAME_GEMM_AB -DVAME_TUNING_BUILD -o tools/libvame_hip_ab.so $(SRC)
 	@echo "use: VAME_LIB=tools/libvame_hip_ab.so python tools/microbench.py 10 gemm_ab"
 
 clean:

@@ -486,13 +486,13 @@ __global__ __launch_bounds__(H / 32 * 64) void gru_seq_bwd_kernel(GruBwdParams P
 
 // ------------------------------------------------------------------------------------------- host
 #include <stdlib.h>
-static int abl_env(const char* name) { const char* e = getenv(name); return e ? atoi(e) : 0; }
+[[maybe_unused]] static int abl_env(const char* name) { const char* e = getenv(name); return e ? atoi(e) : 0; }
 #define ABL_CASE(K, H, A, P, st) case A: hipLaunchKernelGGL((K<H, A>), dim3(grid_blocks(P.nstreams, P.ntiles)), dim3(H / 32 * 64), 0, st, P); return;
 
 template <int H>
 static void launch_fwd(const GruFwdParams& P, hipStream_t st) {
-#ifndef VAME_EMU
-    if (H == 256) switch (abl_env("VAME_ABL_FWD")) {      // profiling-only ablations (tools/microbench.py)
+#if !defined(VAME_EMU) && defined(VAME_GEMM_AB)
+    if (H == 256) switch (abl_env("VAME_ABL_FWD")) {      // profiling-only ablations, tuning build (make ab) only
         ABL_CASE(gru_seq_fwd_kernel, 256, 1, P, st) ABL_CASE(gru_seq_fwd_kernel, 256, 2, P, st) ABL_CASE(gru_seq_fwd_kernel, 256, 4, P, st)
         ABL_CASE(gru_seq_fwd_kernel, 256, 8, P, st) ABL_CASE(gru_seq_fwd_kernel, 256, 16, P, st) ABL_CASE(gru_seq_fwd_kernel, 256, 32, P, st)
         ABL_CASE(gru_seq_fwd_kernel, 256, 7, P, st) ABL_CASE(gru_seq_fwd_kernel, 256, 63, P, st)
@@ -504,7 +504,7 @@ static void launch_fwd(const GruFwdParams& P, hipStream_t st) {
 }
 template <int H>
 static void launch_bwd(const GruBwdParams& P, hipStream_t st) {
-#ifndef VAME_EMU
+#if !defined(VAME_EMU) && defined(VAME_GEMM_AB)
     if (H == 256) switch (abl_env("VAME_ABL_BWD")) {
         ABL_CASE(gru_seq_bwd_kernel, 256, 1, P, st) ABL_CASE(gru_seq_bwd_kernel, 256, 2, P, st) ABL_CASE(gru_seq_bwd_kernel, 256, 3, P, st)
         ABL_CASE(gru_seq_bwd_kernel, 256, 16, P, st) ABL_CASE(gru_seq_bwd_kernel, 256, 32, P, st) ABL_CASE(gru_seq_bwd_kernel, 256, 51, P, st)
