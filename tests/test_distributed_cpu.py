@@ -5,12 +5,11 @@ import socket
 import sys
 
 import numpy as np
-import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from conftest import ROOT, golden_weights, load_golden
+from conftest import ROOT, load_golden
 
 
 def _free_port():

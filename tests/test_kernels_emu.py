@@ -3,12 +3,8 @@
 These exercise the exact kernel code (index math, MFMA fragment layouts, LDS staging, masking) on
 the CPU; the same checks run on the real GPU in test_kernels_gpu.py.
 """
-import numpy as np
 import pytest
-import torch
 
-from oracle import vame_oracle as vo
-from vame_amd import ops
 from kernel_cases import (check_adam, check_colsum, check_colsum_batch, check_kmeans, check_gather, check_gemm_cases, check_gru_bwd, check_gru_fwd, check_gru_fwd_fused,
                           check_latent, check_mse, check_nuclear)
 

@@ -12,7 +12,7 @@ The torch.nn.GRU / nn.Linear objects are parameter containers only; they are nev
 import torch
 from torch import nn
 
-from .. import _lib, ops
+from .. import _lib
 from ..engine import ParamTable, Spec, VAEEngine
 
 
