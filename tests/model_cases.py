@@ -71,6 +71,24 @@ def check_eval_and_submodules(dev):
     assert all(tuple(sd[k].shape) == golden_weights(g)[k].shape for k in sd)
 
 
+def check_evaluate_and_generative_cores(dev):
+    """Numeric cores of vame.evaluate_model / vame.generative_model against the reference's eval-mode
+    golden outputs: reconstruct_test_batch = model(data) in eval, decode_latents = model.decoder(tiled z, z)."""
+    from vame_amd.analysis.generative_functions import decode_latents
+    from vame_amd.model.evaluate import reconstruct_test_batch
+    g = load_golden("step_tiny")
+    model, (T, F, Z, H, FS, fut, sp) = build_model(g, dev)
+    model.eval()
+    win = torch.from_numpy(np.concatenate([g["x"], g["xfut"]], 1)).to(dev)
+    r = reconstruct_test_batch(model, win, T, fut, FS)
+    np.testing.assert_array_equal(r["data"], g["x"])
+    np.testing.assert_array_equal(r["fut_orig"], g["xfut"])
+    np.testing.assert_allclose(r["data_tilde"], g["eval_pred"], atol=3e-5)
+    np.testing.assert_allclose(r["mu"], g["eval_mu"], atol=1e-5)
+    assert r["fut"].shape == g["xfut"].shape
+    np.testing.assert_allclose(decode_latents(model, g["eval_mu"], T), g["eval_pred"], atol=3e-5)
+
+
 def check_h0_view(dev):
     g = load_golden("h0view")
     T, F, Z, H = [int(v) for v in g["spec"]]

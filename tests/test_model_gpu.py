@@ -5,7 +5,7 @@ import pytest
 import torch
 
 from conftest import load_golden
-from model_cases import check_adam_trajectory, check_odd_dims_vs_oracle, check_eval_and_submodules, check_h0_view, check_noise_input, check_step
+from model_cases import check_adam_trajectory, check_odd_dims_vs_oracle, check_eval_and_submodules, check_evaluate_and_generative_cores, check_h0_view, check_noise_input, check_step
 from oracle import vame_oracle as vo
 from vame_amd.model.rnn_model import RNN_VAE
 
@@ -25,6 +25,10 @@ def test_autograd_path_matches_reference(hip):
 
 def test_eval_and_submodules(hip):
     check_eval_and_submodules("cuda")
+
+
+def test_evaluate_and_generative_cores(hip):
+    check_evaluate_and_generative_cores("cuda")
 
 
 def test_decoder_h0_view(hip):
