@@ -18,5 +18,8 @@ ab: $(SRC) $(HDR)
 	$(HIPCC) --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -DVAME_GEMM_AB -DVAME_TUNING_BUILD -o tools/libvame_hip_ab.so $(SRC)
 	@echo "use: VAME_LIB=tools/libvame_hip_ab.so python tools/microbench.py 10 gemm_ab"
 
+probe: $(SRC) $(HDR) tools/probe_gemm.hip
+	$(HIPCC) --offload-arch=gfx950 -O3 -std=c++17 -DVAME_PROBE -Wno-unused-value -Wno-unused-result -o tools/probe_gemm tools/probe_gemm.hip vame_amd/csrc/elementwise.hip
+
 clean:
-	rm -f vame_amd/libvame_hip.so tests/emu/libvame_emu.so tools/libvame_hip_ab.so
+	rm -f vame_amd/libvame_hip.so tests/emu/libvame_emu.so tools/libvame_hip_ab.so tools/probe_gemm

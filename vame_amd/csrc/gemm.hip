@@ -166,6 +166,16 @@ struct TileIO {
     }
 };
 
+#ifdef VAME_PROBE   // tools/probe_gemm.hip only: per-wave phase timers (s_memtime) written to a global buffer
+__device__ long long* g_gemm_probe;
+#define PROBE_T() ((long long)__builtin_amdgcn_s_memtime())
+#define PROBE_DECL long long pt0 = PROBE_T(), pr0 = (long long)__builtin_amdgcn_s_memrealtime(), pa = pt0, ps = 0, pb1 = 0, pm = 0, pb2 = 0
+#define PROBE_ADD(acc) do { const long long t_ = PROBE_T(); acc += t_ - pa; pa = t_; } while (0)
+#else
+#define PROBE_DECL
+#define PROBE_ADD(acc)
+#endif
+
 // VAR (tuning variants, tools/microbench.py A/B): 1 unpredicated interior fetch, 4 s_setprio around the MFMAs
 template <int BM, int BN, int WM, int WN, bool AKM, bool BKM, int VAR>
 __global__ __launch_bounds__(WM * WN * 64, (BM / WM) * (BN / WN) > 64 * 64 ? 2 : 3) void gemm_kernel(GemmParams p) {
@@ -194,10 +204,13 @@ __global__ __launch_bounds__(WM * WN * 64, (BM / WM) * (BN / WN) > 64 * 64 ? 2 :
     ta.init(p.A, m0, p.M, kb, tid);
     tb.init(p.B, n0, p.N, kb, tid);
     if (kb < ke) { ta.template fetch<(VAR & 1) != 0>(p.A, m0, p.M, kb, ke, tid); tb.template fetch<(VAR & 1) != 0>(p.B, n0, p.N, kb, ke, tid); }
+    PROBE_DECL;
     for (int k0 = kb; k0 < ke; k0 += BK) {
         ta.store(As, tid);
         tb.store(Bs, tid);
+        PROBE_ADD(ps);
         __syncthreads();
+        PROBE_ADD(pb1);
         if (k0 + BK < ke) { ta.template fetch<(VAR & 1) != 0>(p.A, m0, p.M, k0 + BK, ke, tid); tb.template fetch<(VAR & 1) != 0>(p.B, n0, p.N, k0 + BK, ke, tid); }   // in flight during the MFMAs
         if (VAR & 4) SETPRIO(1);
         // MFMA step (c, e) contracts k = {8c + e, 8c + 4 + e}: any k order is valid as long as A and B agree
@@ -216,8 +229,17 @@ __global__ __launch_bounds__(WM * WN * 64, (BM / WM) * (BN / WN) > 64 * 64 ? 2 :
                     for (int j = 0; j < TN; ++j) acc[i][j] = MFMA_32x32x2(a[i][e], b[j][e], acc[i][j]);
         }
         if (VAR & 4) SETPRIO(0);
+        PROBE_ADD(pm);
         __syncthreads();
+        PROBE_ADD(pb2);
     }
+#ifdef VAME_PROBE
+    if (lane == 0 && g_gemm_probe) {
+        long long* o = g_gemm_probe + ((long long)blockIdx.x * (NT / 64) + wv) * 8;
+        o[0] = pt0; o[1] = PROBE_T(); o[2] = pr0; o[3] = (long long)__builtin_amdgcn_s_memrealtime();
+        o[4] = ps; o[5] = pb1; o[6] = pm; o[7] = pb2;
+    }
+#endif
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
