@@ -20,6 +20,7 @@ ab: $(SRC) $(HDR)
 
 probe: $(SRC) $(HDR) tools/probe_gemm.hip
 	$(HIPCC) --offload-arch=gfx950 -O3 -std=c++17 -DVAME_PROBE -Wno-unused-value -Wno-unused-result -o tools/probe_gemm tools/probe_gemm.hip vame_amd/csrc/elementwise.hip
+	$(HIPCC) --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -DVAME_PROBE -o tools/libvame_hip_probe.so $(SRC)
 
 clean:
-	rm -f vame_amd/libvame_hip.so tests/emu/libvame_emu.so tools/libvame_hip_ab.so tools/probe_gemm
+	rm -f vame_amd/libvame_hip.so tests/emu/libvame_emu.so tools/libvame_hip_ab.so tools/libvame_hip_probe.so tools/probe_gemm

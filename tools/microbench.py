@@ -39,7 +39,7 @@ def bench_gemm(M, N, K, akm, bkm, sk=1, label=""):
     print(f"gemm {label:10s} M={M:6d} N={N:4d} K={K:6d} akm={akm} bkm={bkm} sk={sk:3d}: {ms*1e3:8.1f} us  {2.0*M*N*K/ms/1e9:7.1f} TF")
 
 
-def bench_gru(H, B, T, nstreams, quiet=False):
+def bench_gru(H, B, T, nstreams, quiet=False, hook=None):
     from kernel_cases import _gru_weights, _pack
     import numpy as np
     rng = np.random.default_rng(0)
@@ -67,7 +67,11 @@ def bench_gru(H, B, T, nstreams, quiet=False):
     ms = timeit(lambda: ops.gru_seq_fwd(rows_f, B, H))
     if not quiet:
         print(f"gru_fwd H={H} B={B} T={T} streams={nstreams}: {ms*1e3:8.1f} us  {fl/ms/1e9:7.1f} TF")
+    if hook:
+        hook("fwd")
     ms2 = timeit(lambda: ops.gru_seq_bwd(rows_b, B, H))
+    if hook:
+        hook("bwd")
     if not quiet:
         print(f"gru_bwd H={H} B={B} T={T} streams={nstreams}: {ms2*1e3:8.1f} us  {fl/ms2/1e9:7.1f} TF")
     return ms * 1e3, ms2 * 1e3

@@ -1,0 +1,32 @@
+#!/usr/bin/env python3
+"""Shader clock actually sustained inside the GRU sequence kernels (tuning build: make probe).
+Every workgroup stamps s_memtime (shader-clock counter) and s_memrealtime (100 MHz) at entry and exit;
+ratio x 100 MHz = average clock over the kernel.  usage: VAME_LIB=tools/libvame_hip_probe.so python tools/probe_clock.py"""
+import ctypes
+import os
+import sys
+
+sys.argv = sys.argv[:1] + ["5"]
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import torch  # noqa: E402
+import microbench as mb  # noqa: E402
+from vame_amd import _lib  # noqa: E402
+
+L = _lib._lib
+L.vame_probe_set_gru.argtypes = [ctypes.c_void_p]
+probe = torch.zeros(1 << 14, 4, dtype=torch.int64, device="cuda")
+L.vame_probe_set_gru(probe.data_ptr())
+
+
+def report(tag, nwg):
+    torch.cuda.synchronize()
+    p = probe[:nwg].cpu().numpy().astype("float64")
+    p = p[p[:, 1] > 0]
+    span = (p[:, 3].max() - p[:, 2].min()) / 100.0
+    print(f"{tag}: {len(p)} workgroups, clock ratio {p[:, 0].sum() / p[:, 1].sum():.3f} (x100 MHz), workgroup length "
+          f"min {p[:, 1].min() / 100:.1f} p50 {sorted(p[:, 1])[len(p) // 2] / 100:.1f} max {p[:, 1].max() / 100:.1f} us, span {span:.1f} us", flush=True)
+    probe.zero_()
+
+
+for (H, B, T, ns) in ((256, 4096, 30, 2), (256, 4096, 30, 4), (256, 256, 30, 2)):
+    mb.bench_gru(H, B, T, ns, hook=lambda which: report(f"  gru_{which} H={H} B={B} T={T} streams={ns}", ns * ((B + 31) // 32) + 64))

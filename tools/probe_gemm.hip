@@ -4,10 +4,66 @@
 // its begin/end with s_memtime and the constant-rate s_memrealtime, which also gives the shader clock under load.
 #include "../vame_amd/csrc/gemm.hip"
 #include <algorithm>
+#include <string.h>
 #include <vector>
 
 
+// calibration: what s_memtime counts, and the MFMA rate / clock the chip sustains with no memory traffic at all
+__global__ void spin_kernel(long long* out, int iters) {
+    const long long t0 = PROBE_T(), r0 = (long long)__builtin_amdgcn_s_memrealtime();
+    int x = threadIdx.x;
+    for (int i = 0; i < iters; ++i) x = x * 1664525 + 1013904223;
+    if (threadIdx.x == 0) { out[0] = PROBE_T() - t0; out[1] = (long long)__builtin_amdgcn_s_memrealtime() - r0; out[2] = x; }
+}
+template <int NACC>
+__global__ __launch_bounds__(256) void mfma_only_kernel(long long* out, float* sink, int iters) {
+    f32x16 acc[NACC];
+#pragma unroll
+    for (int j = 0; j < NACC; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+    float a = (float)threadIdx.x * 1e-3f, b = 1.0f - a;
+    const long long t0 = PROBE_T(), r0 = (long long)__builtin_amdgcn_s_memrealtime();
+    for (int i = 0; i < iters; ++i) {
+#pragma unroll
+        for (int j = 0; j < NACC; ++j) acc[j] = MFMA_32x32x2(a, b, acc[j]);
+    }
+    const long long t1 = PROBE_T(), r1 = (long long)__builtin_amdgcn_s_memrealtime();
+    float v = 0.f;
+#pragma unroll
+    for (int j = 0; j < NACC; ++j) v += acc[j][0] + acc[j][7];
+    if (v == 123.456f) sink[0] = v;
+    if ((threadIdx.x & 63) == 0) {
+        long long* o = out + ((long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * 4;
+        o[0] = t1 - t0; o[1] = r1 - r0; o[2] = r0; o[3] = r1;
+    }
+}
+static void calib() {
+    long long* d; float* sink; hipMalloc(&d, 1 << 22); hipMalloc(&sink, 64);
+    long long h[4];
+    hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(64), 0, 0, d, 400000); hipDeviceSynchronize();
+    hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(64), 0, 0, d, 400000); hipMemcpy(h, d, 32, hipMemcpyDeviceToHost);
+    printf("spin (1 wave, idle chip): %lld memtime ticks / %lld realtime ticks (100 MHz) -> ratio %.3f\n", h[0], h[1], (double)h[0] / h[1]);
+    for (int wgs_per_cu = 1; wgs_per_cu <= 3; ++wgs_per_cu) {
+        const int grid = 256 * wgs_per_cu, iters = 40000 / wgs_per_cu, NACC = 4;
+        hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+        hipLaunchKernelGGL(mfma_only_kernel<4>, dim3(grid), dim3(256), 0, 0, d, sink, iters); hipDeviceSynchronize();
+        hipEventRecord(e0, 0);
+        hipLaunchKernelGGL(mfma_only_kernel<4>, dim3(grid), dim3(256), 0, 0, d, sink, iters);
+        hipEventRecord(e1, 0); hipEventSynchronize(e1);
+        float ms; hipEventElapsedTime(&ms, e0, e1);
+        std::vector<long long> v((size_t)grid * 4 * 4); hipMemcpy(v.data(), d, v.size() * 8, hipMemcpyDeviceToHost);
+        double t = 0, r = 0; long long rmin = v[2], rmax = v[3];
+        for (size_t w = 0; w < (size_t)grid * 4; ++w) { t += v[w * 4]; r += v[w * 4 + 1]; rmin = std::min(rmin, v[w * 4 + 2]); rmax = std::max(rmax, v[w * 4 + 3]); }
+        const double flops = (double)grid * 4 * iters * NACC * 4096.0;
+        printf("mfma-only, %d WG/CU (4 waves, %d accumulators each): %.1f us, %.1f TF (event) / %.1f TF (in-kernel span); clock ratio %.3f; cycles per MFMA per SIMD %.1f\n",
+               wgs_per_cu, NACC, ms * 1e3, flops / ms / 1e9, flops / ((double)(rmax - rmin) * 10.0) / 1e3, t / r,
+               t / ((double)grid * 4) / ((double)iters * NACC) / wgs_per_cu);
+    }
+}
+
 int main(int argc, char** argv) {
+    if (argc >= 2 && !strcmp(argv[1], "calib")) { calib(); return 0; }
     if (argc < 7) { fprintf(stderr, "usage: probe_gemm M N K akm bkm splitk\n"); return 2; }
     const int M = atoi(argv[1]), N = atoi(argv[2]), K = atoi(argv[3]), akm = atoi(argv[4]), bkm = atoi(argv[5]), sk = atoi(argv[6]);
     const size_t na = (size_t)M * K, nb = (size_t)N * K;
@@ -18,7 +74,7 @@ int main(int argc, char** argv) {
     hipMemcpy(A, h.data(), na * 4, hipMemcpyHostToDevice); hipMemcpy(B, h.data(), nb * 4, hipMemcpyHostToDevice);
     const int maxwg = 1 << 16, waves = 4;
     long long* probe; hipMalloc(&probe, (size_t)maxwg * waves * 8 * 8); hipMemset(probe, 0, (size_t)maxwg * waves * 8 * 8);
-    hipMemcpyToSymbol(HIP_SYMBOL(g_gemm_probe), &probe, sizeof(probe));
+    vame_probe_set_gemm(probe);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     auto run = [&]() { return vame_gemm_f32(M, N, K, A, akm ? M : K, akm, 0, 0, B, bkm ? N : K, bkm, 0, 0, nullptr, C, N, 0, sk, ws, 0, 0, nullptr); };
     for (int i = 0; i < 3; ++i) if (run()) return 1;

@@ -168,6 +168,7 @@ struct TileIO {
 
 #ifdef VAME_PROBE   // tools/probe_gemm.hip only: per-wave phase timers (s_memtime) written to a global buffer
 __device__ long long* g_gemm_probe;
+extern "C" int vame_probe_set_gemm(long long* p) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_gemm_probe), &p, sizeof(p)); }
 #define PROBE_T() ((long long)__builtin_amdgcn_s_memtime())
 #define PROBE_DECL long long pt0 = PROBE_T(), pr0 = (long long)__builtin_amdgcn_s_memrealtime(), pa = pt0, ps = 0, pb1 = 0, pm = 0, pb2 = 0
 #define PROBE_ADD(acc) do { const long long t_ = PROBE_T(); acc += t_ - pa; pa = t_; } while (0)

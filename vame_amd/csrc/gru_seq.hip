@@ -13,6 +13,21 @@
 // Reference semantics: torch.nn.GRU as instantiated at vame/model/rnn_model.py:34-35,91-92,125-126.
 #include "vame_common.h"
 
+#ifdef VAME_PROBE   // tuning build (make probe): per-workgroup begin/end stamps, s_memtime (shader clock) vs s_memrealtime (100 MHz)
+__device__ long long* g_gru_probe;
+extern "C" int vame_probe_set_gru(long long* p) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_gru_probe), &p, sizeof(p)); }
+#define GRU_PROBE_BEGIN() const long long pk_t0 = (long long)__builtin_amdgcn_s_memtime(), pk_r0 = (long long)__builtin_amdgcn_s_memrealtime()
+#define GRU_PROBE_END()                                                                                      \
+    if (threadIdx.x == 0 && g_gru_probe) {                                                                    \
+        long long* o_ = g_gru_probe + (long long)blockIdx.x * 4;                                              \
+        o_[0] = (long long)__builtin_amdgcn_s_memtime() - pk_t0; o_[2] = pk_r0;                               \
+        o_[3] = (long long)__builtin_amdgcn_s_memrealtime(); o_[1] = o_[3] - pk_r0;                           \
+    }
+#else
+#define GRU_PROBE_BEGIN()
+#define GRU_PROBE_END()
+#endif
+
 struct GruFwdStream {
     const float* gi; int64_t gi_row, gi_t;
     const float* wp; const float* bhn;
@@ -152,6 +167,7 @@ __global__ __launch_bounds__(H / 32 * 64) void gru_seq_fwd_kernel(GruFwdParams P
     __shared__ float xs[XIN ? 2 : 1][XIN ? 32 * LDX : 4];
     int sidx, tile;
     if (!map_block(P.nstreams, P.ntiles, sidx, tile)) return;
+    GRU_PROBE_BEGIN();
     const GruFwdStream& S = P.s[sidx];
     const int B = P.B, T = (int)S.T;
     const int tid = threadIdx.x, lane = tid & 63, li = lane & 31, hh = lane >> 5;
@@ -336,6 +352,7 @@ __global__ __launch_bounds__(H / 32 * 64) void gru_seq_fwd_kernel(GruFwdParams P
             if (grow < B) S.hn[(int64_t)grow * S.hn_row + col0 + li] = hprev[r];
         }
     }
+    GRU_PROBE_END();
 }
 
 // ------------------------------------------------------------------------------------------- backward
@@ -346,6 +363,7 @@ __global__ __launch_bounds__(H / 32 * 64) void gru_seq_bwd_kernel(GruBwdParams P
     __shared__ float gs[32 * LDG];      // per row [da_r | da_z | dgh_n | dgi_n]: first 3H = MFMA A operand
     int sidx, tile;
     if (!map_block(P.nstreams, P.ntiles, sidx, tile)) return;
+    GRU_PROBE_BEGIN();
     const GruBwdStream& S = P.s[sidx];
     const int B = P.B, T = (int)S.T;
     const int tid = threadIdx.x, lane = tid & 63, li = lane & 31, hh = lane >> 5;
@@ -482,6 +500,7 @@ __global__ __launch_bounds__(H / 32 * 64) void gru_seq_bwd_kernel(GruBwdParams P
             o[0] = dbs0; o[H] = dbs1; o[2 * H] = dbs2; o[3 * H] = dbs3;
         }
     }
+    GRU_PROBE_END();
 }
 
 // ------------------------------------------------------------------------------------------- host
