@@ -14,17 +14,27 @@ from vame_amd import _lib  # noqa: E402
 
 L = _lib._lib
 L.vame_probe_set_gru.argtypes = [ctypes.c_void_p]
-probe = torch.zeros(1 << 14, 4, dtype=torch.int64, device="cuda")
+probe = torch.zeros((1 << 16) + (1 << 14) * 8, dtype=torch.int64, device="cuda")
 L.vame_probe_set_gru(probe.data_ptr())
+
+
+FWD_PHASES = ["loop-top", "mfma", "gates+h->lds", "stash-st", "barrier", "y-store", "", ""]
+BWD_PHASES = ["loop-top", "coef+lds", "barrier1", "dG-copy", "ld-issue", "mfma", "barrier2", ""]
+T_CUR = [30]
 
 
 def report(tag, nwg):
     torch.cuda.synchronize()
-    p = probe[:nwg].cpu().numpy().astype("float64")
+    p = probe[:4 * nwg].view(-1, 4).cpu().numpy().astype("float64")
+    ph = probe[1 << 16:(1 << 16) + 8 * nwg].view(-1, 8).cpu().numpy().astype("float64")[p[:, 1] > 0]
     p = p[p[:, 1] > 0]
     span = (p[:, 3].max() - p[:, 2].min()) / 100.0
     print(f"{tag}: {len(p)} workgroups, clock ratio {p[:, 0].sum() / p[:, 1].sum():.3f} (x100 MHz), workgroup length "
           f"min {p[:, 1].min() / 100:.1f} p50 {sorted(p[:, 1])[len(p) // 2] / 100:.1f} max {p[:, 1].max() / 100:.1f} us, span {span:.1f} us", flush=True)
+    tot = ph.sum()
+    names = FWD_PHASES if "fwd" in tag else BWD_PHASES
+    print("      wave-0 cycles per step: " + "  ".join(f"{n} {ph[:, i].mean() / T_CUR[0]:.0f}" for i, n in enumerate(names) if n)
+          + f"   (sum {tot / len(ph) / T_CUR[0]:.0f}; MFMA floor 2 waves x 384 x 64 = 49152)", flush=True)
     probe.zero_()
 
 

@@ -23,9 +23,20 @@ extern "C" int vame_probe_set_gru(long long* p) { return (int)hipMemcpyToSymbol(
         o_[0] = (long long)__builtin_amdgcn_s_memtime() - pk_t0; o_[2] = pk_r0;                               \
         o_[3] = (long long)__builtin_amdgcn_s_memrealtime(); o_[1] = o_[3] - pk_r0;                           \
     }
+// phase timers of one wave (wave 0 of each workgroup reports): 8 accumulators after the 4 stamp slots of all workgroups
+#define GRU_PHASE_DECL() long long pp_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, pa_ = (long long)__builtin_amdgcn_s_memtime()
+#define GRU_PHASE(i) do { const long long t_ = (long long)__builtin_amdgcn_s_memtime(); pp_[i] += t_ - pa_; pa_ = t_; } while (0)
+#define GRU_PHASE_END()                                                                                      \
+    if (threadIdx.x == 0 && g_gru_probe) {                                                                    \
+        long long* o_ = g_gru_probe + (1 << 16) + (long long)blockIdx.x * 8;                                  \
+        for (int i_ = 0; i_ < 8; ++i_) o_[i_] = pp_[i_];                                                      \
+    }
 #else
 #define GRU_PROBE_BEGIN()
 #define GRU_PROBE_END()
+#define GRU_PHASE_DECL()
+#define GRU_PHASE(i)
+#define GRU_PHASE_END()
 #endif
 
 struct GruFwdStream {
@@ -262,9 +273,11 @@ __global__ __launch_bounds__(H / 32 * 64) void gru_seq_fwd_kernel(GruFwdParams P
         for (int c = 0; c < PD; ++c) { wq[c][0] = w0[(c * 3 + 0) * 64]; wq[c][1] = w0[(c * 3 + 1) * 64]; wq[c][2] = w0[(c * 3 + 2) * 64]; }
     }
     if (XIN) __syncthreads();
+    GRU_PHASE_DECL();
     for (int step = 0; step < T; ++step) {
         const int t = S.reverse ? T - 1 - step : step;
         f32x16 ar, au, ani, anh;
+        GRU_PHASE(0);
         if (XIN) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) { ar[r] = bgr; au[r] = bgu; ani[r] = bgn; anh[r] = bhn; }
@@ -312,6 +325,7 @@ __global__ __launch_bounds__(H / 32 * 64) void gru_seq_fwd_kernel(GruFwdParams P
             ar = MFMA_32x32x2(a.w, b0.w, ar); au = MFMA_32x32x2(a.w, b1.w, au); anh = MFMA_32x32x2(a.w, b2.w, anh);
         }
         }
+        GRU_PHASE(1);                 // input projection + recurrent MFMA loop
         float* hnext = &hs[cur ^ 1][lrow * LDH + col0 + li];
         f32x16 ust;
 #pragma unroll
@@ -329,6 +343,7 @@ __global__ __launch_bounds__(H / 32 * 64) void gru_seq_fwd_kernel(GruFwdParams P
             hprev[r] = hv;
             hnext[CR(r) * LDH] = hv;
         }
+        GRU_PHASE(2);                 // gate math + h -> LDS
         if (!(ABL & 1) && stash) {
             float4* sp = stash + ((((int64_t)tile * T + t) * NW + w) * 20) * 64 + lane;
 #pragma unroll
@@ -341,10 +356,14 @@ __global__ __launch_bounds__(H / 32 * 64) void gru_seq_fwd_kernel(GruFwdParams P
             }
         }
         if (XIN) store_x(xs[cur ^ 1]);
+        GRU_PHASE(3);                 // stash stores (issue)
         if (!(ABL & 32)) __syncthreads();
+        GRU_PHASE(4);                 // barrier
         cur ^= 1;
         if (!(ABL & 4) && y_tile) store_h(hs[cur], t);
+        GRU_PHASE(5);                 // y stores through LDS
     }
+    GRU_PHASE_END();
     if (S.hn) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -420,10 +439,12 @@ __global__ __launch_bounds__(H / 32 * 64) void gru_seq_bwd_kernel(GruBwdParams P
     float4 wq[PD][2];
 #pragma unroll
     for (int c = 0; c < PD; ++c) { wq[c][0] = wpt[(2 * c) * 64]; wq[c][1] = wpt[(2 * c + 1) * 64]; }
+    GRU_PHASE_DECL();
     for (int step = 0; step < T; ++step) {
         const int fstep = T - 1 - step;
         const int t = S.reverse ? T - 1 - fstep : fstep;
         f32x16 acc0;
+        GRU_PHASE(0);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const float av[4] = {sa[q].x, sa[q].y, sa[q].z, sa[q].w}, bv[4] = {sb[q].x, sb[q].y, sb[q].z, sb[q].w},
@@ -443,7 +464,9 @@ __global__ __launch_bounds__(H / 32 * 64) void gru_seq_bwd_kernel(GruBwdParams P
                 dbs0 += dar; dbs1 += dau; dbs2 += dan; dbs3 += dgh;
             }
         }
+        GRU_PHASE(1);                 // coefficient math + LDS tile writes (incl. the wait for the stash loads)
         if (!(ABL & 32)) __syncthreads();
+        GRU_PHASE(2);                 // barrier 1
         if (!(ABL & 1)) {
             // dG[b][t][da_r | da_z | dgi_n | dgh_n] leaves through LDS: 16 coalesced 16-byte stores per thread
             float* dgt = dg_copy + (int64_t)t * 4 * H;
@@ -460,7 +483,9 @@ __global__ __launch_bounds__(H / 32 * 64) void gru_seq_bwd_kernel(GruBwdParams P
                             *reinterpret_cast<const float4*>((i < 8 ? gs_copy : gs_copy + 16 * LDG) + 2 * (i & 7) * LDG);
             }
         }
+        GRU_PHASE(3);                 // dG copy-out
         if (!(ABL & 2) && step + 1 < T) load_step(step + 1);
+        GRU_PHASE(4);                 // next step's stash / dy loads (issue)
         f32x16 acc1;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc1[r] = 0.f;
@@ -483,8 +508,11 @@ __global__ __launch_bounds__(H / 32 * 64) void gru_seq_bwd_kernel(GruBwdParams P
         }
 #pragma unroll
         for (int r = 0; r < 16; ++r) dh[r] = acc0[r] + acc1[r];
+        GRU_PHASE(5);                 // MFMA loop
         if (!(ABL & 32)) __syncthreads();
+        GRU_PHASE(6);                 // barrier 2
     }
+    GRU_PHASE_END();
     if (S.dh0) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
