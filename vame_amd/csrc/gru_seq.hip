@@ -266,11 +266,11 @@ __global__ __launch_bounds__(H / 32 * 64) void gru_seq_fwd_kernel(GruFwdParams P
     };
     if (!XIN) load_gi(S.reverse ? T - 1 : 0);
     constexpr int PD = 4;                       // KC % PD == 0 for every supported H; the fused input has exactly PD chunks
-    float4 wq[PD][3];
+    f32x4 wq[PD][3];
     {
         const float4* w0 = XIN ? wpx : wp;
 #pragma unroll
-        for (int c = 0; c < PD; ++c) { wq[c][0] = w0[(c * 3 + 0) * 64]; wq[c][1] = w0[(c * 3 + 1) * 64]; wq[c][2] = w0[(c * 3 + 2) * 64]; }
+        for (int c = 0; c < PD; ++c) { RING_LOAD(wq[c][0], w0, (c * 3 + 0) * 64); RING_LOAD(wq[c][1], w0, (c * 3 + 1) * 64); RING_LOAD(wq[c][2], w0, (c * 3 + 2) * 64); }
     }
     if (XIN) __syncthreads();
     GRU_PHASE_DECL();
@@ -287,12 +287,14 @@ __global__ __launch_bounds__(H / 32 * 64) void gru_seq_fwd_kernel(GruFwdParams P
 #pragma unroll
             for (int j = 0; j < PD; ++j) {
                 const float4 a = *reinterpret_cast<const float4*>(xrow + 8 * j);
-                const float4 b0 = wq[j][0], b1 = wq[j][1], b2 = wq[j][2];
-                wq[j][0] = wp[(j * 3 + 0) * 64]; wq[j][1] = wp[(j * 3 + 1) * 64]; wq[j][2] = wp[(j * 3 + 2) * 64];
-                ar = MFMA_32x32x2(a.x, b0.x, ar); au = MFMA_32x32x2(a.x, b1.x, au); ani = MFMA_32x32x2(a.x, b2.x, ani);
-                ar = MFMA_32x32x2(a.y, b0.y, ar); au = MFMA_32x32x2(a.y, b1.y, au); ani = MFMA_32x32x2(a.y, b2.y, ani);
-                ar = MFMA_32x32x2(a.z, b0.z, ar); au = MFMA_32x32x2(a.z, b1.z, au); ani = MFMA_32x32x2(a.z, b2.z, ani);
-                ar = MFMA_32x32x2(a.w, b0.w, ar); au = MFMA_32x32x2(a.w, b1.w, au); ani = MFMA_32x32x2(a.w, b2.w, ani);
+                RING_WAIT3(3 * (PD - 1), wq[j][0], wq[j][1], wq[j][2]);
+                const f32x4 b0 = wq[j][0], b1 = wq[j][1], b2 = wq[j][2];
+                ar = MFMA_32x32x2(a.x, b0[0], ar); au = MFMA_32x32x2(a.x, b1[0], au); ani = MFMA_32x32x2(a.x, b2[0], ani);
+                ar = MFMA_32x32x2(a.y, b0[1], ar); au = MFMA_32x32x2(a.y, b1[1], au); ani = MFMA_32x32x2(a.y, b2[1], ani);
+                ar = MFMA_32x32x2(a.z, b0[2], ar); au = MFMA_32x32x2(a.z, b1[2], au); ani = MFMA_32x32x2(a.z, b2[2], ani);
+                ar = MFMA_32x32x2(a.w, b0[3], ar); au = MFMA_32x32x2(a.w, b1[3], au); ani = MFMA_32x32x2(a.w, b2[3], ani);
+                RING_FENCE();                  // refill only after the slot's last use: see the note at the main loop
+                RING_LOAD(wq[j][0], wp, (j * 3 + 0) * 64); RING_LOAD(wq[j][1], wp, (j * 3 + 1) * 64); RING_LOAD(wq[j][2], wp, (j * 3 + 2) * 64);
             }
         } else {
             ar = gr; au = gu; ani = gn;
@@ -310,19 +312,23 @@ __global__ __launch_bounds__(H / 32 * 64) void gru_seq_fwd_kernel(GruFwdParams P
         for (int j = 0; j < PD; ++j) {
             const int c = c0 + j;
             const float4 a = *reinterpret_cast<const float4*>(hrow + 8 * c);
-            const float4 b0 = wq[j][0], b1 = wq[j][1], b2 = wq[j][2];
+            RING_WAIT3(3 * (PD - 1), wq[j][0], wq[j][1], wq[j][2]);
+            const f32x4 b0 = wq[j][0], b1 = wq[j][1], b2 = wq[j][2];
+            ar = MFMA_32x32x2(a.x, b0[0], ar); au = MFMA_32x32x2(a.x, b1[0], au); anh = MFMA_32x32x2(a.x, b2[0], anh);
+            ar = MFMA_32x32x2(a.y, b0[1], ar); au = MFMA_32x32x2(a.y, b1[1], au); anh = MFMA_32x32x2(a.y, b2[1], anh);
+            ar = MFMA_32x32x2(a.z, b0[2], ar); au = MFMA_32x32x2(a.z, b1[2], au); anh = MFMA_32x32x2(a.z, b2[2], anh);
+            ar = MFMA_32x32x2(a.w, b0[3], ar); au = MFMA_32x32x2(a.w, b1[3], au); anh = MFMA_32x32x2(a.w, b2[3], anh);
+            RING_FENCE();
             {
-                // ring refill, PD chunks ahead; the last group wraps into the next step's first chunks (the input-projection
-                // chunks when XIN) -- pointer select, no branch
+                // ring refill for chunk c + PD, issued AFTER the slot's last use so the load lands in the same registers
+                // (a refill placed before the MFMAs makes hipcc load into fresh registers and rotate the ring with v_mov
+                // at every back edge).  The last group wraps into the next step's first chunks (the input-projection
+                // chunks when XIN): pointer select, no branch
                 const bool wrap = c0 + PD == KC;
                 const float4* src = (XIN && wrap) ? wpx : wp;
                 const int cn = (ABL & 16) ? 0 : (wrap ? j : c + PD);
-                wq[j][0] = src[(cn * 3 + 0) * 64]; wq[j][1] = src[(cn * 3 + 1) * 64]; wq[j][2] = src[(cn * 3 + 2) * 64];
+                RING_LOAD(wq[j][0], src, (cn * 3 + 0) * 64); RING_LOAD(wq[j][1], src, (cn * 3 + 1) * 64); RING_LOAD(wq[j][2], src, (cn * 3 + 2) * 64);
             }
-            ar = MFMA_32x32x2(a.x, b0.x, ar); au = MFMA_32x32x2(a.x, b1.x, au); anh = MFMA_32x32x2(a.x, b2.x, anh);
-            ar = MFMA_32x32x2(a.y, b0.y, ar); au = MFMA_32x32x2(a.y, b1.y, au); anh = MFMA_32x32x2(a.y, b2.y, anh);
-            ar = MFMA_32x32x2(a.z, b0.z, ar); au = MFMA_32x32x2(a.z, b1.z, au); anh = MFMA_32x32x2(a.z, b2.z, anh);
-            ar = MFMA_32x32x2(a.w, b0.w, ar); au = MFMA_32x32x2(a.w, b1.w, au); anh = MFMA_32x32x2(a.w, b2.w, anh);
         }
         }
         GRU_PHASE(1);                 // input projection + recurrent MFMA loop
@@ -436,9 +442,9 @@ __global__ __launch_bounds__(H / 32 * 64) void gru_seq_bwd_kernel(GruBwdParams P
     };
     load_step(0);
     constexpr int PD = 3;                       // W_hh fragment prefetch distance in chunk pairs ((KC/2) % PD == 0 for H = 32..256)
-    float4 wq[PD][2];
+    f32x4 wq[PD][2];
 #pragma unroll
-    for (int c = 0; c < PD; ++c) { wq[c][0] = wpt[(2 * c) * 64]; wq[c][1] = wpt[(2 * c + 1) * 64]; }
+    for (int c = 0; c < PD; ++c) { RING_LOAD(wq[c][0], wpt, (2 * c) * 64); RING_LOAD(wq[c][1], wpt, (2 * c + 1) * 64); }
     GRU_PHASE_DECL();
     for (int step = 0; step < T; ++step) {
         const int fstep = T - 1 - step;
@@ -496,15 +502,17 @@ __global__ __launch_bounds__(H / 32 * 64) void gru_seq_bwd_kernel(GruBwdParams P
             const int c = 2 * (c0 + j);
             const float4 a0 = *reinterpret_cast<const float4*>(grow_a + 8 * c);
             const float4 a1 = *reinterpret_cast<const float4*>(grow_a + 8 * c + 8);
-            const float4 b0 = wq[j][0], b1 = wq[j][1];
-            {
-                const int cn = (ABL & 16) ? 0 : (c0 + j + PD == KC / 2 + j ? 2 * j : c + 2 * PD);   // wraps into the next step
-                wq[j][0] = wpt[cn * 64]; wq[j][1] = wpt[(cn + 1) * 64];
+            RING_WAIT2(2 * (PD - 1), wq[j][0], wq[j][1]);
+            const f32x4 b0 = wq[j][0], b1 = wq[j][1];
+            acc0 = MFMA_32x32x2(a0.x, b0[0], acc0); acc1 = MFMA_32x32x2(a1.x, b1[0], acc1);
+            acc0 = MFMA_32x32x2(a0.y, b0[1], acc0); acc1 = MFMA_32x32x2(a1.y, b1[1], acc1);
+            acc0 = MFMA_32x32x2(a0.z, b0[2], acc0); acc1 = MFMA_32x32x2(a1.z, b1[2], acc1);
+            acc0 = MFMA_32x32x2(a0.w, b0[3], acc0); acc1 = MFMA_32x32x2(a1.w, b1[3], acc1);
+            RING_FENCE();
+            {   // refill after the slot's last use (see the forward kernel); wraps into the next step
+                const int cn = (ABL & 16) ? 0 : (c0 + j + PD == KC / 2 + j ? 2 * j : c + 2 * PD);
+                RING_LOAD(wq[j][0], wpt, cn * 64); RING_LOAD(wq[j][1], wpt, (cn + 1) * 64);
             }
-            acc0 = MFMA_32x32x2(a0.x, b0.x, acc0); acc1 = MFMA_32x32x2(a1.x, b1.x, acc1);
-            acc0 = MFMA_32x32x2(a0.y, b0.y, acc0); acc1 = MFMA_32x32x2(a1.y, b1.y, acc1);
-            acc0 = MFMA_32x32x2(a0.z, b0.z, acc0); acc1 = MFMA_32x32x2(a1.z, b1.z, acc1);
-            acc0 = MFMA_32x32x2(a0.w, b0.w, acc0); acc1 = MFMA_32x32x2(a1.w, b1.w, acc1);
         }
 #pragma unroll
         for (int r = 0; r < 16; ++r) dh[r] = acc0[r] + acc1[r];

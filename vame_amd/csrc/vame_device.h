@@ -11,6 +11,10 @@ typedef f32x4_emu f32x4;
 #define VAME_DYN_SMEM(name) char* name = emu::dyn_smem()
 #define SETPRIO(n)
 #define SCHED_FENCE()
+#define RING_FENCE()
+#define RING_LOAD(dst, ptr, idx) (dst) = *reinterpret_cast<const f32x4*>((ptr) + (idx))
+#define RING_WAIT2(n, a, b)
+#define RING_WAIT3(n, a, b, c)
 #define VAME_EXPF(x) expf(x)
 #define VAME_RCP(x) (1.0f / (x))
 #else
@@ -23,6 +27,16 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define VAME_DYN_SMEM(name) extern __shared__ __attribute__((aligned(16))) char name[]
 #define SETPRIO(n) __builtin_amdgcn_s_setprio(n)
 #define SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)   /* keep the scheduler from merging phases (register pressure) */
+#define RING_FENCE() __builtin_amdgcn_sched_barrier(0)    /* prefetch-ring refills stay behind the MFMAs that read the slot */
+// Register prefetch ring for the L2-resident weight fragments.  hipcc's own s_waitcnt insertion drains the whole vector-memory
+// queue (vmcnt(0)) at the back edge of a loop that carries in-flight loads, which turns a ring into "load, wait, use".  So the
+// ring loads are issued from inline asm (invisible to that pass) and the consumer waits with an explicit vmcnt(n), n = number
+// of ring loads issued after the slot's own.  Memory operations the compiler issues in between only make the wait more
+// conservative (vmcnt counts in order), never unsafe.  The asm wait takes the slot registers as in/out operands so that no
+// consumer can be scheduled above it.  (ptr: float4 pointer, idx: float4 index; offsets stay < 4 KiB of a per-lane base.)
+#define RING_LOAD(dst, ptr, idx) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"((ptr) + (idx)))
+#define RING_WAIT2(n, a, b) asm volatile("s_waitcnt vmcnt(%2)" : "+v"(a), "+v"(b) : "n"(n))
+#define RING_WAIT3(n, a, b, c) asm volatile("s_waitcnt vmcnt(%3)" : "+v"(a), "+v"(b), "+v"(c) : "n"(n))
 #define VAME_EXPF(x) __expf(x)
 #define VAME_RCP(x) __builtin_amdgcn_rcpf(x)   /* v_rcp_f32, 1 ulp */
 #endif
