@@ -14,7 +14,7 @@ from vame_amd import _lib  # noqa: E402
 
 L = _lib._lib
 L.vame_probe_set_gru.argtypes = [ctypes.c_void_p]
-probe = torch.zeros((1 << 16) + (1 << 14) * 8, dtype=torch.int64, device="cuda")
+probe = torch.zeros((1 << 16) + (1 << 14) * 24, dtype=torch.int64, device="cuda")
 L.vame_probe_set_gru(probe.data_ptr())
 
 
@@ -26,12 +26,13 @@ T_CUR = [30]
 def report(tag, nwg):
     torch.cuda.synchronize()
     p = probe[:4 * nwg].view(-1, 4).cpu().numpy().astype("float64")
-    ph = probe[1 << 16:(1 << 16) + 8 * nwg].view(-1, 8).cpu().numpy().astype("float64")[p[:, 1] > 0]
+    ph = probe[1 << 16:(1 << 16) + 24 * nwg].view(-1, 24).cpu().numpy().astype("float64")[p[:, 1] > 0]
     p = p[p[:, 1] > 0]
     span = (p[:, 3].max() - p[:, 2].min()) / 100.0
     print(f"{tag}: {len(p)} workgroups, clock ratio {p[:, 0].sum() / p[:, 1].sum():.3f} (x100 MHz), workgroup length "
           f"min {p[:, 1].min() / 100:.1f} p50 {sorted(p[:, 1])[len(p) // 2] / 100:.1f} max {p[:, 1].max() / 100:.1f} us, span {span:.1f} us", flush=True)
-    tot = ph.sum()
+    tot = ph[:, :8].sum()
+    print("      MFMA-loop groups (cycles/step): " + " ".join(f"{ph[:, 8 + g].mean() / T_CUR[0]:.0f}" for g in range(16) if ph[:, 8 + g].sum() > 0), flush=True)
     names = FWD_PHASES if "fwd" in tag else BWD_PHASES
     print("      wave-0 cycles per step: " + "  ".join(f"{n} {ph[:, i].mean() / T_CUR[0]:.0f}" for i, n in enumerate(names) if n)
           + f"   (sum {tot / len(ph) / T_CUR[0]:.0f}; MFMA floor 2 waves x 384 x 64 = 49152)", flush=True)

@@ -24,18 +24,21 @@ extern "C" int vame_probe_set_gru(long long* p) { return (int)hipMemcpyToSymbol(
         o_[3] = (long long)__builtin_amdgcn_s_memrealtime(); o_[1] = o_[3] - pk_r0;                           \
     }
 // phase timers of one wave (wave 0 of each workgroup reports): 8 accumulators after the 4 stamp slots of all workgroups
-#define GRU_PHASE_DECL() long long pp_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, pa_ = (long long)__builtin_amdgcn_s_memtime()
+#define GRU_PHASE_DECL() long long pp_[24] = {0}, pa_ = (long long)__builtin_amdgcn_s_memtime()
 #define GRU_PHASE(i) do { const long long t_ = (long long)__builtin_amdgcn_s_memtime(); pp_[i] += t_ - pa_; pa_ = t_; } while (0)
+#define GRU_PHASE_DYN(i) do { const long long t_ = (long long)__builtin_amdgcn_s_memtime(); const long long d_ = t_ - pa_; pa_ = t_; \
+        _Pragma("unroll") for (int k_ = 8; k_ < 24; ++k_) if (k_ == (i)) pp_[k_] += d_; } while (0)
 #define GRU_PHASE_END()                                                                                      \
     if (threadIdx.x == 0 && g_gru_probe) {                                                                    \
-        long long* o_ = g_gru_probe + (1 << 16) + (long long)blockIdx.x * 8;                                  \
-        for (int i_ = 0; i_ < 8; ++i_) o_[i_] = pp_[i_];                                                      \
+        long long* o_ = g_gru_probe + (1 << 16) + (long long)blockIdx.x * 24;                                 \
+        for (int i_ = 0; i_ < 24; ++i_) o_[i_] = pp_[i_];                                                     \
     }
 #else
 #define GRU_PROBE_BEGIN()
 #define GRU_PROBE_END()
 #define GRU_PHASE_DECL()
 #define GRU_PHASE(i)
+#define GRU_PHASE_DYN(i)
 #define GRU_PHASE_END()
 #endif
 
@@ -330,6 +333,7 @@ __global__ __launch_bounds__(H / 32 * 64) void gru_seq_fwd_kernel(GruFwdParams P
                 RING_LOAD(wq[j][0], src, (cn * 3 + 0) * 64); RING_LOAD(wq[j][1], src, (cn * 3 + 1) * 64); RING_LOAD(wq[j][2], src, (cn * 3 + 2) * 64);
             }
         }
+        GRU_PHASE_DYN(8 + c0 / PD);
         }
         GRU_PHASE(1);                 // input projection + recurrent MFMA loop
         float* hnext = &hs[cur ^ 1][lrow * LDH + col0 + li];
@@ -441,7 +445,7 @@ __global__ __launch_bounds__(H / 32 * 64) void gru_seq_bwd_kernel(GruBwdParams P
         }
     };
     load_step(0);
-    constexpr int PD = 3;                       // W_hh fragment prefetch distance in chunk pairs ((KC/2) % PD == 0 for H = 32..256)
+    constexpr int PD = 3;                       // W_hh fragment prefetch distance in chunk pairs ((KC/2) % PD == 0 for H = 32..256; 4 measured slower)
     f32x4 wq[PD][2];
 #pragma unroll
     for (int c = 0; c < PD; ++c) { RING_LOAD(wq[c][0], wpt, (2 * c) * 64); RING_LOAD(wq[c][1], wpt, (2 * c + 1) * 64); }
@@ -513,6 +517,7 @@ __global__ __launch_bounds__(H / 32 * 64) void gru_seq_bwd_kernel(GruBwdParams P
                 const int cn = (ABL & 16) ? 0 : (c0 + j + PD == KC / 2 + j ? 2 * j : c + 2 * PD);
                 RING_LOAD(wq[j][0], wpt, cn * 64); RING_LOAD(wq[j][1], wpt, (cn + 1) * 64);
             }
+            if (j == PD - 1) GRU_PHASE_DYN(8 + c0 / PD);
         }
 #pragma unroll
         for (int r = 0; r < 16; ++r) dh[r] = acc0[r] + acc1[r];
