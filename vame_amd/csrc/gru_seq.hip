@@ -338,33 +338,37 @@ __global__ __launch_bounds__(H / 32 * 64) void gru_seq_fwd_kernel(GruFwdParams P
         GRU_PHASE(1);                 // input projection + recurrent MFMA loop
         float* hnext = &hs[cur ^ 1][lrow * LDH + col0 + li];
         f32x16 ust;
+        float4* sp = stash ? stash + ((((int64_t)tile * T + t) * NW + w) * 20) * 64 + lane : nullptr;
+        // four groups of 4 fragment rows: gate math of a group, then its 5 stash stores, so that the stores' trip through the
+        // vector-memory path overlaps the next group's VALU work instead of following all of it
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const float rr = (ABL & 8) ? ar[r] * 0.01f : fast_sigmoid(ar[r]);
-            const float uu = (ABL & 8) ? au[r] * 0.01f : fast_sigmoid(au[r]);
-            const float nn = (ABL & 8) ? (ani[r] + rr * anh[r]) * 0.01f : fast_tanh(ani[r] + rr * anh[r]);
-            const float hp = hprev[r];
-            const float hv = nn + uu * (hp - nn);
-            const float omu = 1.0f - uu;
-            ani[r] = omu * (1.0f - nn * nn);          // cA
-            au[r] = (hp - nn) * uu * omu;             // cB
-            ar[r] = rr;
-            ust[r] = uu;
-            hprev[r] = hv;
-            hnext[CR(r) * LDH] = hv;
-        }
-        GRU_PHASE(2);                 // gate math + h -> LDS
-        if (!(ABL & 1) && stash) {
-            float4* sp = stash + ((((int64_t)tile * T + t) * NW + w) * 20) * 64 + lane;
+        for (int q = 0; q < 4; ++q) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
+            for (int j = 0; j < 4; ++j) {
+                const int r = 4 * q + j;
+                const float rr = (ABL & 8) ? ar[r] * 0.01f : fast_sigmoid(ar[r]);
+                const float uu = (ABL & 8) ? au[r] * 0.01f : fast_sigmoid(au[r]);
+                const float nn = (ABL & 8) ? (ani[r] + rr * anh[r]) * 0.01f : fast_tanh(ani[r] + rr * anh[r]);
+                const float hp = hprev[r];
+                const float hv = nn + uu * (hp - nn);
+                const float omu = 1.0f - uu;
+                ani[r] = omu * (1.0f - nn * nn);          // cA
+                au[r] = (hp - nn) * uu * omu;             // cB
+                ar[r] = rr;
+                ust[r] = uu;
+                hprev[r] = hv;
+                hnext[CR(r) * LDH] = hv;
+            }
+            if (!(ABL & 1) && stash) {
                 sp[(0 * 4 + q) * 64] = make_float4(ani[4 * q], ani[4 * q + 1], ani[4 * q + 2], ani[4 * q + 3]);
                 sp[(1 * 4 + q) * 64] = make_float4(au[4 * q], au[4 * q + 1], au[4 * q + 2], au[4 * q + 3]);
                 sp[(2 * 4 + q) * 64] = make_float4(ust[4 * q], ust[4 * q + 1], ust[4 * q + 2], ust[4 * q + 3]);
                 sp[(3 * 4 + q) * 64] = make_float4(ar[4 * q], ar[4 * q + 1], ar[4 * q + 2], ar[4 * q + 3]);
                 sp[(4 * 4 + q) * 64] = make_float4(anh[4 * q], anh[4 * q + 1], anh[4 * q + 2], anh[4 * q + 3]);
             }
+            SCHED_FENCE();
         }
+        GRU_PHASE(2);                 // gate math + h -> LDS + stash stores
         if (XIN) store_x(xs[cur ^ 1]);
         GRU_PHASE(3);                 // stash stores (issue)
         if (!(ABL & 32)) __syncthreads();
