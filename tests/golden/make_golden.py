@@ -254,7 +254,52 @@ def train_model_fixture(rnn_vae):
     print("wrote train_model_run", {k: v.shape for k, v in out.items() if k.endswith("VAME")})
 
 
+def synth_pose_file(F, N, seed, anchors):
+    """Pose series with a few gross tracking errors (what the IQR rule removes); two constant rows when `anchors`."""
+    rng = np.random.default_rng(seed)
+    n = np.arange(N)
+    X = 5 * np.sin(2 * np.pi * n[None, :] * (np.arange(F)[:, None] + 1) / 97.0) + rng.standard_normal((F, N))
+    spikes = rng.integers(0, N, size=max(3, N // 40))
+    fs = rng.integers(0, F, size=len(spikes))
+    X[fs, spikes] += rng.choice([-1, 1], size=len(spikes)) * 60
+    if anchors:
+        X[3] = 0.0
+        X[7] = 0.0
+    return X
+
+
+def prep_fixture():
+    """create_trainset arithmetic: the reference's traindata_aligned / traindata_fixed on two small files."""
+    import matplotlib
+    matplotlib.use("Agg")
+    spec = importlib.util.spec_from_file_location("vame.model.create_training", os.path.join(REF, "vame/model/create_training.py"))
+    ct = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ct)
+    for fixed in (False, True):
+        F = 24 if fixed else 26
+        datas = [synth_pose_file(F, 300, 1, not fixed), synth_pose_file(F, 220, 2, not fixed)]
+        with tempfile.TemporaryDirectory() as d:
+            files = ["vidA", "vidB"]
+            os.makedirs(os.path.join(d, "data", "train"))
+            for f, x in zip(files, datas):
+                os.makedirs(os.path.join(d, "data", f))
+                np.save(os.path.join(d, "data", f, f + "-PE-seq.npy"), x)
+            cfg = dict(project_path=d, robust=True, iqr_factor=4, savgol_length=5, savgol_order=2)
+            (ct.traindata_fixed if fixed else ct.traindata_aligned)(cfg, files, 0.1, 26, True, False)
+            out = dict(in0=datas[0], in1=datas[1],
+                       train=np.load(os.path.join(d, "data", "train", "train_seq.npy")),
+                       test=np.load(os.path.join(d, "data", "train", "test_seq.npy")),
+                       clean0=np.load(os.path.join(d, "data", "vidA", "vidA-PE-seq-clean.npy")),
+                       clean1=np.load(os.path.join(d, "data", "vidB", "vidB-PE-seq-clean.npy")),
+                       params=np.array([4, 5, 2, 0.1]))
+        np.savez_compressed(os.path.join(OUT, "prep_fixed.npz" if fixed else "prep_aligned.npz"), **out)
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "prep":
+        load_reference()
+        prep_fixture()
+        return
     rnn_model, dataloader, rnn_vae, pose = load_reference()
     torch.set_num_threads(4)
     step_fixture(rnn_model, rnn_vae, "step_tiny")                                       # H=32,B=8, all grads + Adam
@@ -270,6 +315,7 @@ def main():
     h0view_fixture(rnn_model)
     anneal_fixture(rnn_vae)
     train_model_fixture(rnn_vae)
+    prep_fixture()
 
 
 if __name__ == "__main__":

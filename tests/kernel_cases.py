@@ -317,3 +317,95 @@ def check_kmeans(dev, N=3000, K=6, D=30, n_init=3):
     order = np.argsort(km.cluster_centers_[:, 0])
     order_sk = np.argsort(sk.cluster_centers_[:, 0])
     np.testing.assert_allclose(km.cluster_centers_[order], sk.cluster_centers_[order_sk], atol=1e-4)
+
+
+# ------------------------------------------------------------------ training-set preparation (float64)
+def _prep_kw(g):
+    f, L, p, _ = g["params"]
+    return dict(robust=True, iqr_factor=int(f), savgol_filter=True, savgol_length=int(L), savgol_order=int(p))
+
+
+def check_prepare_series_golden(dev):
+    """Device pipeline of vame_amd.model.create_training against the REFERENCE's outputs (tests/golden/prep_*.npz): bit-exact."""
+    from conftest import load_golden
+    from vame_amd.model.create_training import prepare_series
+    for name, fixed in (("prep_aligned", False), ("prep_fixed", True)):
+        g = load_golden(name)
+        out, pos, info = prepare_series([g["in0"], g["in1"]], fixed=fixed, device=torch.device(dev), **_prep_kw(g))
+        ntest = g["test"].shape[1]
+        np.testing.assert_array_equal(out[:, :ntest], g["test"])
+        np.testing.assert_array_equal(out[:, ntest:], g["train"])
+        np.testing.assert_array_equal(out[:, pos[0]:pos[1]], g["clean0"])
+        np.testing.assert_array_equal(out[:, pos[1]:pos[2]], g["clean1"])
+        assert (info["anchors"] == (7, 3)) if not fixed else info["anchors"] is None
+
+
+def check_prepare_series_vs_oracle(dev, F=26, sizes=(5000, 3001), seed=5, L=7, p=3):
+    """Other sizes / filter settings against the numpy restatement (oracle/prep_oracle.py), incl. no-savgol and not-robust."""
+    from oracle import prep_oracle as po
+    from vame_amd.model.create_training import prepare_series
+    rng = np.random.default_rng(seed)
+    datas = []
+    for N in sizes:
+        X = rng.standard_normal((F, N)).cumsum(axis=1) * 0.1 + rng.standard_normal((F, N))
+        idx = rng.integers(0, N, size=N // 25)
+        X[rng.integers(0, F, size=len(idx)), idx] *= 40.0
+        X[1] = 0.0
+        X[F - 2] = 0.0
+        datas.append(X)
+    for fixed in (False, True):
+        for robust, sg in ((True, True), (True, False), (False, True)):
+            kw = dict(fixed=fixed, robust=robust, iqr_factor=3, savgol_filter=sg, savgol_length=L, savgol_order=p)
+            ref = po.traindata(datas, test_fraction=0.1, **kw)
+            out, pos, _ = prepare_series(datas, device=torch.device(dev), **kw)
+            np.testing.assert_array_equal(out, np.concatenate([ref["test"], ref["train"]], axis=1), err_msg=str(kw))
+
+
+def check_prep_fill_rules(dev):
+    """The two NaN-fill kernels against np.interp called exactly as the reference's interpol() calls it, incl. runs of NaNs at
+    the ends, a feature without any valid sample (aligned rule) and the empty-frame count (fixed rule)."""
+    from vame_amd import ops
+    rng = np.random.default_rng(11)
+    F, N = 9, 257
+    z = rng.standard_normal((F, N))
+    z[rng.random((F, N)) < 0.2] = np.nan
+    z[2, :40] = np.nan
+    z[5, -30:] = np.nan
+    z[:, 100] = np.nan                                   # one frame with no valid feature
+    z[0, 7] = np.nan
+    z[F - 1, 9] = np.nan
+    # --- fixed rule, frame by frame (create_training.py:236)
+    ref = z.T.copy()
+    xs = np.arange(F, dtype=float)
+    for i in range(N):
+        nan = np.isnan(ref[i])
+        if nan.any() and not nan.all():
+            ref[i, nan] = np.interp(xs[nan], xs[~nan], ref[i, ~nan])
+    t = torch.from_numpy(z.copy()).to(dev)
+    n_empty = torch.zeros(1, dtype=torch.int32, device=dev)
+    ops.prep_fill_across_features(t, F, N, N, n_empty)
+    np.testing.assert_array_equal(t.cpu().numpy(), ref.T)
+    assert int(n_empty.item()) == 1
+    # --- aligned rule on the whole array (create_training.py:27-32): np.interp over the FEATURE index
+    za = z.copy()
+    za[:, 100] = 0.5
+    y = za.copy()
+    nans = np.isnan(y)
+    y[nans] = np.interp(nans.nonzero()[0], (~nans).nonzero()[0], y[~nans])
+    t = torch.from_numpy(za.copy()).to(dev)
+    fl = torch.empty(F, 2, dtype=torch.float64, device=dev)
+    ops.prep_fill_last_valid(t, F, N, N, fl)
+    np.testing.assert_array_equal(t.cpu().numpy(), y)
+    # a feature without valid samples is reported (NaN, NaN) and left alone; the host rule reproduces np.interp for it
+    from vame_amd.model.create_training import _resolve_empty_features
+    for empty in (0, 4, F - 1):
+        zb = za.copy()
+        zb[empty] = np.nan
+        y = zb.copy()
+        nans = np.isnan(y)
+        y[nans] = np.interp(nans.nonzero()[0], (~nans).nonzero()[0], y[~nans])
+        t = torch.from_numpy(zb.copy()).to(dev)
+        ops.prep_fill_last_valid(t, F, N, N, fl)
+        assert np.isnan(fl.cpu().numpy()[empty]).all()
+        _resolve_empty_features(t, fl)
+        np.testing.assert_array_equal(t.cpu().numpy(), y)

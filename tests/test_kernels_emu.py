@@ -6,7 +6,8 @@ the CPU; the same checks run on the real GPU in test_kernels_gpu.py.
 import pytest
 
 from kernel_cases import (check_adam, check_colsum, check_colsum_batch, check_kmeans, check_gather, check_gemm_cases, check_gru_bwd, check_gru_fwd, check_gru_fwd_fused,
-                          check_latent, check_mse, check_nuclear)
+                          check_latent, check_mse, check_nuclear, check_prep_fill_rules, check_prepare_series_golden,
+                          check_prepare_series_vs_oracle)
 
 DEV = "cpu"
 
@@ -46,3 +47,15 @@ def test_gru_fwd_fused_input(emu, H, B, T, I):
 
 def test_kmeans_next_row_n1(emu):
     check_kmeans(DEV)
+
+
+def test_prepare_series_matches_reference(emu):
+    check_prepare_series_golden("cpu")
+
+
+def test_prepare_series_vs_oracle(emu):
+    check_prepare_series_vs_oracle("cpu")
+
+
+def test_prep_fill_rules(emu):
+    check_prep_fill_rules("cpu")

@@ -2,7 +2,8 @@
 import pytest
 
 from kernel_cases import (check_adam, check_colsum, check_colsum_batch, check_kmeans, check_gather, check_gemm_cases, check_gru_bwd, check_gru_fwd, check_gru_fwd_fused,
-                          check_latent, check_mse, check_nuclear)
+                          check_latent, check_mse, check_nuclear, check_prep_fill_rules, check_prepare_series_golden,
+                          check_prepare_series_vs_oracle)
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
@@ -44,3 +45,15 @@ def test_gru_fwd_fused_input(hip, H, B, T, I):
 def test_kmeans_next_row_n1(hip):
     check_kmeans(DEV)
     check_kmeans(DEV, N=200000, K=15, D=30, n_init=2)
+
+
+def test_prepare_series_matches_reference(hip):
+    check_prepare_series_golden(DEV)
+
+
+def test_prepare_series_vs_oracle(hip):
+    check_prepare_series_vs_oracle(DEV, sizes=(200000, 123457))
+
+
+def test_prep_fill_rules(hip):
+    check_prep_fill_rules(DEV)

@@ -126,3 +126,18 @@ def test_torch_cpu_baseline_model_matches_reference():
     for k, gr in m.reference_named_grads().items():
         r = g["kw1/g/" + k]
         np.testing.assert_allclose(gr.numpy(), r, atol=1e-5 * max(1, np.abs(r).max()), err_msg=k)
+
+
+@pytest.mark.parametrize("name,fixed", [("prep_aligned", False), ("prep_fixed", True)])
+def test_prep_oracle_matches_reference_outputs(name, fixed):
+    """oracle/prep_oracle.py (create_trainset arithmetic incl. the two NaN-fill quirks) vs the reference's saved files: bit-exact."""
+    from oracle import prep_oracle as po
+    g = load_golden(name)
+    f, L, p, frac = g["params"]
+    r = po.traindata([g["in0"], g["in1"]], fixed=fixed, robust=True, iqr_factor=int(f), savgol_filter=True, savgol_length=int(L),
+                     savgol_order=int(p), test_fraction=float(frac))
+    np.testing.assert_array_equal(r["train"], g["train"])
+    np.testing.assert_array_equal(r["test"], g["test"])
+    np.testing.assert_array_equal(r["clean"][0], g["clean0"])
+    np.testing.assert_array_equal(r["clean"][1], g["clean1"])
+    assert not np.isnan(g["train"]).any() and g["train"].shape[0] == 24

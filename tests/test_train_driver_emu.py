@@ -146,6 +146,31 @@ def test_generative_model_modes(project):
     plt.close("all")
 
 
+def test_create_trainset_files(tmp_path, emu):
+    """vame.create_trainset (create_training.py:267-300): train/test split + per-video clean files, equal to the files the
+    REFERENCE wrote for the same inputs (tests/golden/prep_*.npz)."""
+    import vame_amd as vame
+    for name, fixed in (("prep_aligned", False), ("prep_fixed", True)):
+        g = load_golden(name)
+        root = tmp_path / name
+        for f, k in (("vidA", "in0"), ("vidB", "in1")):
+            os.makedirs(root / "data" / f)
+            np.save(root / "data" / f / (f + "-PE-seq.npy"), g[k])
+        cfg = dict(project_path=str(root), Project="demo", legacy=False, egocentric_data=fixed, all_data="yes", video_sets=["vidA", "vidB"],
+                   robust=True, iqr_factor=int(g["params"][0]), savgol_filter=True, savgol_length=int(g["params"][1]),
+                   savgol_order=int(g["params"][2]), test_fraction=float(g["params"][3]), num_features=26)
+        with open(root / "config.yaml", "w") as f:
+            yaml.safe_dump(cfg, f)
+        vame.create_trainset(str(root / "config.yaml"))
+        np.testing.assert_array_equal(np.load(root / "data" / "train" / "train_seq.npy"), g["train"])
+        np.testing.assert_array_equal(np.load(root / "data" / "train" / "test_seq.npy"), g["test"])
+        np.testing.assert_array_equal(np.load(root / "data" / "vidA" / "vidA-PE-seq-clean.npy"), g["clean0"])
+        np.testing.assert_array_equal(np.load(root / "data" / "vidB" / "vidB-PE-seq-clean.npy"), g["clean1"])
+        vame.create_trainset(str(root / "config.yaml"), check_parameter=True)          # plots only, writes nothing new
+    import matplotlib.pyplot as plt
+    plt.close("all")
+
+
 def test_read_config_contract(tmp_path):
     from vame_amd.util.auxiliary import read_config
     with pytest.raises(FileNotFoundError):

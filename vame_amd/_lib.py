@@ -7,7 +7,7 @@ package calls it.
 """
 import ctypes
 import os
-from ctypes import c_char_p, c_float, c_int, c_int64, c_void_p
+from ctypes import c_char_p, c_double, c_float, c_int, c_int64, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libvame_hip.so")
@@ -48,6 +48,11 @@ _SIGS = {
     "vame_adam_amsgrad_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, c_float,
                                       c_float, c_int, c_float, c_void_p]),
     "vame_axpy_f32": (c_int, [c_void_p, c_float, c_void_p, c_int64, c_void_p]),
+    "vame_prep_zscore_mask_f64": (c_int, [c_void_p, c_int, c_int64, c_int64, c_double, c_double, c_double, c_int, c_void_p, c_int64, c_void_p]),
+    "vame_prep_fill_last_valid_f64": (c_int, [c_void_p, c_int, c_int64, c_int64, c_void_p, c_void_p]),
+    "vame_prep_fill_across_features_f64": (c_int, [c_void_p, c_int, c_int64, c_int64, c_void_p, c_void_p]),
+    "vame_prep_rowstats_f64": (c_int, [c_void_p, c_int, c_int64, c_int64, c_void_p, c_void_p, c_void_p]),
+    "vame_prep_savgol_f64": (c_int, [c_void_p, c_int, c_int64, c_int64, c_void_p, c_int, c_void_p, c_int64, c_void_p]),
 }
 EXPORTS = tuple(_SIGS)
 

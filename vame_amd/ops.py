@@ -21,7 +21,7 @@ def _ptr(t, off=0):
         return None
     if not _lib.emulated() and not t.is_cuda:
         raise _lib.VameHipError("vame_amd ops need CUDA(HIP) tensors; there is no CPU path")
-    assert t.dtype in (torch.float32, torch.int64), t.dtype
+    assert t.dtype in (torch.float32, torch.float64, torch.int64, torch.int32), t.dtype
     return t.data_ptr() + off * t.element_size()
 
 
@@ -187,3 +187,30 @@ def adam_amsgrad(p, g, m, v, vmax, n, lr, step, gscale=1.0, beta1=0.9, beta2=0.9
 def axpy(x, a, y, n, x_off=0, y_off=0):
     rc = _lib.lib().vame_axpy_f32(_ptr(x, x_off), float(a), _ptr(y, y_off), n, _stream())
     _lib.check(rc, "vame_axpy_f32")
+
+
+# ------------------------------------------------------------------ training-set preparation (float64, (F, N) feature-major)
+def prep_zscore_mask(x, F, N, ldx, mean, sd, cutoff, robust, z, ldz, z_off=0):
+    rc = _lib.lib().vame_prep_zscore_mask_f64(_ptr(x), F, N, ldx, float(mean), float(sd), float(cutoff), int(bool(robust)),
+                                              _ptr(z, z_off), ldz, _stream())
+    _lib.check(rc, "vame_prep_zscore_mask_f64")
+
+
+def prep_fill_last_valid(z, F, N, ld, first_last, z_off=0):
+    rc = _lib.lib().vame_prep_fill_last_valid_f64(_ptr(z, z_off), F, N, ld, _ptr(first_last), _stream())
+    _lib.check(rc, "vame_prep_fill_last_valid_f64")
+
+
+def prep_fill_across_features(z, F, N, ld, n_empty, z_off=0):
+    rc = _lib.lib().vame_prep_fill_across_features_f64(_ptr(z, z_off), F, N, ld, _ptr(n_empty), _stream())
+    _lib.check(rc, "vame_prep_fill_across_features_f64")
+
+
+def prep_rowstats(x, F, N, ld, mean_out, std_out):
+    rc = _lib.lib().vame_prep_rowstats_f64(_ptr(x), F, N, ld, _ptr(mean_out), _ptr(std_out), _stream())
+    _lib.check(rc, "vame_prep_rowstats_f64")
+
+
+def prep_savgol(x, F, N, ldx, w, L, y, ldy):
+    rc = _lib.lib().vame_prep_savgol_f64(_ptr(x), F, N, ldx, _ptr(w), L, _ptr(y), ldy, _stream())
+    _lib.check(rc, "vame_prep_savgol_f64")
