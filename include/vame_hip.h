@@ -157,18 +157,20 @@ int vame_axpy_f32(const float* x, float a, float* y, int64_t n, void* stream);
  * Arrays are (F, N) feature-major with a leading dimension (elements), like <file>-PE-seq.npy; results are bit-identical to
  * the reference's numpy / scipy arithmetic.  mean, sd, cutoff come from the host (np.mean / np.std / iqr_factor * scipy iqr). */
 
+/* bytes of caller-provided scratch `ws` for the two reductions below (index pairs / partial sums per feature) */
+int64_t vame_prep_ws_bytes(int F);
 /* z[f, n] = (x[f, n] - mean) / sd; robust != 0: z > cutoff or z < -cutoff -> NaN   (create_training.py:112-143, 217-234) */
 int vame_prep_zscore_mask_f64(const double* x, int F, int64_t N, int64_t ldx, double mean, double sd, double cutoff,
                               int robust, double* z, int64_t ldz, void* stream);
 /* interpol() as the reference applies it to a whole aligned file (create_training.py:27-32,145): every NaN of feature f becomes
  * the last valid sample (in time) of feature f.  first_last[2f], [2f+1] = first / last valid value of feature f (NaN if none:
  * such features are left untouched for the caller to resolve). */
-int vame_prep_fill_last_valid_f64(double* z, int F, int64_t N, int64_t ld, double* first_last, void* stream);
+int vame_prep_fill_last_valid_f64(double* z, int F, int64_t N, int64_t ld, double* first_last, void* ws, void* stream);
 /* interpol() per frame of a fixed (egocentric) file (create_training.py:236): np.interp across the feature index.
  * *n_empty += number of frames without any valid feature (left as NaN). */
 int vame_prep_fill_across_features_f64(double* z, int F, int64_t N, int64_t ld, int* n_empty, void* stream);
 /* np.mean / np.std over time per feature (create_training.py:153), deterministic two-pass. */
-int vame_prep_rowstats_f64(const double* x, int F, int64_t N, int64_t ld, double* mean_out, double* std_out, void* stream);
+int vame_prep_rowstats_f64(const double* x, int F, int64_t N, int64_t ld, double* mean_out, double* std_out, void* ws, void* stream);
 /* scipy.signal.savgol_filter along time, interior samples (create_training.py:181,245): w = reversed savgol_coeffs (L odd);
  * the first / last L/2 columns are copied through (mode='interp' refits them from the edge windows). */
 int vame_prep_savgol_f64(const double* x, int F, int64_t N, int64_t ldx, const double* w, int L, double* y, int64_t ldy,

@@ -139,5 +139,22 @@ static inline f32x4_emu emu_mfma_16x16x4(float a, float b, f32x4_emu c) {
     emu::wave_sync();
     return c;
 }
-static inline float atomicAdd(float* p, float v) { float o = *p; *p = o + v; return o; }
-static inline int atomicAdd(int* p, int v) { int o = *p; *p = o + v; return o; }
+static inline float atomicAdd(float* p, float v) {
+    unsigned* u = reinterpret_cast<unsigned*>(p);
+    unsigned o = __atomic_load_n(u, __ATOMIC_RELAXED), n;
+    float f;
+    do { __builtin_memcpy(&f, &o, 4); f += v; __builtin_memcpy(&n, &f, 4); } while (!__atomic_compare_exchange_n(u, &o, n, true, __ATOMIC_RELAXED, __ATOMIC_RELAXED));
+    __builtin_memcpy(&f, &o, 4);
+    return f;
+}
+static inline int atomicAdd(int* p, int v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
+static inline long long atomicMin(long long* p, long long v) {
+    long long o = __atomic_load_n(p, __ATOMIC_RELAXED);
+    while (v < o && !__atomic_compare_exchange_n(p, &o, v, true, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {}
+    return o;
+}
+static inline long long atomicMax(long long* p, long long v) {
+    long long o = __atomic_load_n(p, __ATOMIC_RELAXED);
+    while (v > o && !__atomic_compare_exchange_n(p, &o, v, true, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {}
+    return o;
+}

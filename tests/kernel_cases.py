@@ -394,7 +394,8 @@ def check_prep_fill_rules(dev):
     y[nans] = np.interp(nans.nonzero()[0], (~nans).nonzero()[0], y[~nans])
     t = torch.from_numpy(za.copy()).to(dev)
     fl = torch.empty(F, 2, dtype=torch.float64, device=dev)
-    ops.prep_fill_last_valid(t, F, N, N, fl)
+    ws = ops.prep_ws(F, t.device)
+    ops.prep_fill_last_valid(t, F, N, N, fl, ws)
     np.testing.assert_array_equal(t.cpu().numpy(), y)
     # a feature without valid samples is reported (NaN, NaN) and left alone; the host rule reproduces np.interp for it
     from vame_amd.model.create_training import _resolve_empty_features
@@ -405,7 +406,7 @@ def check_prep_fill_rules(dev):
         nans = np.isnan(y)
         y[nans] = np.interp(nans.nonzero()[0], (~nans).nonzero()[0], y[~nans])
         t = torch.from_numpy(zb.copy()).to(dev)
-        ops.prep_fill_last_valid(t, F, N, N, fl)
+        ops.prep_fill_last_valid(t, F, N, N, fl, ws)
         assert np.isnan(fl.cpu().numpy()[empty]).all()
         _resolve_empty_features(t, fl)
         np.testing.assert_array_equal(t.cpu().numpy(), y)

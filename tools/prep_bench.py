@@ -66,10 +66,11 @@ y = torch.empty_like(z)
 fl = torch.empty(F, 2, dtype=torch.float64, device=dev)
 m, s = torch.empty(F, dtype=torch.float64, device=dev), torch.empty(F, dtype=torch.float64, device=dev)
 w = torch.from_numpy(np.ascontiguousarray(po.savgol_coeffs(5, 2)[::-1])).to(dev)
+ws = ops.prep_ws(F, dev)
 kern = dict(
     zscore_mask=rate(lambda: ops.prep_zscore_mask(x, F, N, N, 0.1, 1.3, 5.0, True, z, Nt), 16 * F * N),
-    fill_last_valid=rate(lambda: ops.prep_fill_last_valid(z, F, N, Nt, fl), 8 * F * N),
-    rowstats=rate(lambda: ops.prep_rowstats(z, F, Nt, Nt, m, s), 16 * F * Nt),
+    fill_last_valid=rate(lambda: ops.prep_fill_last_valid(z, F, N, Nt, fl, ws), 16 * F * N),
+    rowstats=rate(lambda: ops.prep_rowstats(z, F, Nt, Nt, m, s, ws), 16 * F * Nt),
     savgol=rate(lambda: ops.prep_savgol(z, F, Nt, Nt, w, 5, y, Nt), 16 * F * Nt),
 )
 t_cpu, _ = po.traindata_as_written_seconds(datas[0][:, :cpu_frames].copy(), fixed=False)

@@ -1,14 +1,4 @@
 cd $GRAFT_REPO_ROOT
-python - <<'PY'
-import sys, os
-sys.argv = [sys.argv[0], "10"]
-sys.path.insert(0, "tools")
-import microbench as mb
-for T in (8, 15, 30, 60, 120):
-    for ns in (2,):
-        f, b = mb.bench_gru(256, 4096, T, ns, quiet=True)
-        print(f"B=4096 T={T:3d} streams={ns}: fwd {f:8.1f} us ({f/T:6.2f} us/step)  bwd {b:8.1f} us ({b/T:6.2f} us/step)", flush=True)
-for B in (2048, 4096, 8192, 16384):
-    f, b = mb.bench_gru(256, B, 30, 2, quiet=True)
-    print(f"B={B} T=30 streams=2: fwd {f:8.1f} us  bwd {b:8.1f} us   per 4096 rows: fwd {f*4096/B:7.1f} bwd {b*4096/B:7.1f}", flush=True)
-PY
+mkdir -p gpurun_out/prep
+timeout 600 python -m pytest tests/test_kernels_gpu.py -x -q -k "prep" 2>&1 | tail -3
+timeout 600 python tools/prep_bench.py 1000000 > gpurun_out/prep/prep_bench.json 2> gpurun_out/prep/prep_bench.err; cat gpurun_out/prep/prep_bench.json; tail -3 gpurun_out/prep/prep_bench.err

@@ -49,9 +49,10 @@ _SIGS = {
                                       c_float, c_int, c_float, c_void_p]),
     "vame_axpy_f32": (c_int, [c_void_p, c_float, c_void_p, c_int64, c_void_p]),
     "vame_prep_zscore_mask_f64": (c_int, [c_void_p, c_int, c_int64, c_int64, c_double, c_double, c_double, c_int, c_void_p, c_int64, c_void_p]),
-    "vame_prep_fill_last_valid_f64": (c_int, [c_void_p, c_int, c_int64, c_int64, c_void_p, c_void_p]),
+    "vame_prep_ws_bytes": (c_int64, [c_int]),
+    "vame_prep_fill_last_valid_f64": (c_int, [c_void_p, c_int, c_int64, c_int64, c_void_p, c_void_p, c_void_p]),
     "vame_prep_fill_across_features_f64": (c_int, [c_void_p, c_int, c_int64, c_int64, c_void_p, c_void_p]),
-    "vame_prep_rowstats_f64": (c_int, [c_void_p, c_int, c_int64, c_int64, c_void_p, c_void_p, c_void_p]),
+    "vame_prep_rowstats_f64": (c_int, [c_void_p, c_int, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
     "vame_prep_savgol_f64": (c_int, [c_void_p, c_int, c_int64, c_int64, c_void_p, c_int, c_void_p, c_int64, c_void_p]),
 }
 EXPORTS = tuple(_SIGS)

@@ -38,20 +38,25 @@ extern "C" int vame_prep_zscore_mask_f64(const double* x, int F, int64_t N, int6
 
 // ---------------------------------------------------------------------------------------------- NaN fill, "aligned" rule
 // The reference's interpol() on a whole (N, F) array interpolates over the FEATURE index (create_training.py:27-32,145):
-// a NaN of feature f becomes the LAST valid sample (in time) of feature f.  One block per feature: find the first and
-// last valid frame, report their values (first_last[f] = {first, last}, NaN when the feature has no valid sample -- the
-// host resolves that rare case exactly as np.interp does), then overwrite the NaNs.
-__global__ __launch_bounds__(256) void prep_fill_last_kernel(double* __restrict__ z, int64_t N, int64_t ld,
-                                                             double* __restrict__ first_last) {
+// a NaN of feature f becomes the LAST valid sample (in time) of feature f.  Three launches over a (chunks, F) grid:
+// reset the per-feature {first, last} valid frame indices, reduce them with 64-bit atomic min / max (order-independent),
+// then overwrite the NaNs of every chunk with row[last].  first_last[f] = {row[first], row[last]} (NaN when the feature
+// has no valid sample -- the host resolves that rare case exactly as np.interp does).
+constexpr int PREP_CHUNK = 8192;           // frames per block
+
+__global__ void prep_fill_init_kernel(long long* __restrict__ idx, int F, int64_t N) {
+    const int f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f < F) { idx[2 * f] = (long long)N; idx[2 * f + 1] = -1; }
+}
+
+__global__ __launch_bounds__(256) void prep_fill_scan_kernel(const double* __restrict__ z, int64_t N, int64_t ld,
+                                                             long long* __restrict__ idx) {
     __shared__ long long s_first[256], s_last[256];
-    double* row = z + (int64_t)blockIdx.x * ld;
+    const double* row = z + (int64_t)blockIdx.y * ld;
+    const int64_t n0 = (int64_t)blockIdx.x * PREP_CHUNK, n1 = n0 + PREP_CHUNK < N ? n0 + PREP_CHUNK : N;
     long long first = N, last = -1;
-    bool any_nan = false;
-    for (int64_t n = threadIdx.x; n < N; n += blockDim.x) {
-        const bool ok = !isnan(row[n]);
-        if (ok) { if (n < first) first = n; if (n > last) last = n; }
-        else any_nan = true;
-    }
+    for (int64_t n = n0 + threadIdx.x; n < n1; n += blockDim.x)
+        if (!isnan(row[n])) { if (n < first) first = n; if (n > last) last = n; }
     s_first[threadIdx.x] = first; s_last[threadIdx.x] = last;
     __syncthreads();
     for (int s = 128; s > 0; s >>= 1) {
@@ -61,23 +66,40 @@ __global__ __launch_bounds__(256) void prep_fill_last_kernel(double* __restrict_
         }
         __syncthreads();
     }
-    first = s_first[0]; last = s_last[0];
-    const double nanv = __builtin_nan("");
-    const double fill = last >= 0 ? row[last] : nanv;
-    if (threadIdx.x == 0) {
-        first_last[2 * blockIdx.x] = last >= 0 ? row[first] : nanv;
-        first_last[2 * blockIdx.x + 1] = fill;
+    if (threadIdx.x == 0 && s_last[0] >= 0) {
+        atomicMin(&idx[2 * blockIdx.y], s_first[0]);
+        atomicMax(&idx[2 * blockIdx.y + 1], s_last[0]);
     }
-    __syncthreads();                        // row[last] / row[first] are never NaN, so nobody rewrites them below
-    if (last >= 0 && any_nan)
-        for (int64_t n = threadIdx.x; n < N; n += blockDim.x)
-            if (isnan(row[n])) row[n] = fill;
 }
 
-extern "C" int vame_prep_fill_last_valid_f64(double* z, int F, int64_t N, int64_t ld, double* first_last, void* stream) {
-    VAME_CHECK_ARG(z && first_last, VAME_E_BADARG, "prep_fill_last_valid: null pointer");
+__global__ __launch_bounds__(256) void prep_fill_apply_kernel(double* __restrict__ z, int64_t N, int64_t ld,
+                                                              const long long* __restrict__ idx, double* __restrict__ first_last) {
+    double* row = z + (int64_t)blockIdx.y * ld;
+    const long long first = idx[2 * blockIdx.y], last = idx[2 * blockIdx.y + 1];
+    const double nanv = __builtin_nan("");
+    const double fill = last >= 0 ? row[last] : nanv;       // row[last] / row[first] are valid: no block rewrites them
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        first_last[2 * blockIdx.y] = last >= 0 ? row[first] : nanv;
+        first_last[2 * blockIdx.y + 1] = fill;
+    }
+    if (last < 0) return;
+    const int64_t n0 = (int64_t)blockIdx.x * PREP_CHUNK, n1 = n0 + PREP_CHUNK < N ? n0 + PREP_CHUNK : N;
+    for (int64_t n = n0 + threadIdx.x; n < n1; n += blockDim.x)
+        if (isnan(row[n])) row[n] = fill;
+}
+
+extern "C" int64_t vame_prep_ws_bytes(int F) { return (int64_t)F * 2 * 256 * 8; }
+
+extern "C" int vame_prep_fill_last_valid_f64(double* z, int F, int64_t N, int64_t ld, double* first_last, void* ws,
+                                             void* stream) {
+    VAME_CHECK_ARG(z && first_last && ws, VAME_E_BADARG, "prep_fill_last_valid: null pointer");
     VAME_CHECK_ARG(F >= 1 && N >= 1 && ld >= N, VAME_E_SHAPE, "prep_fill_last_valid: bad shape F=%d N=%lld", F, (long long)N);
-    hipLaunchKernelGGL(prep_fill_last_kernel, dim3(F), dim3(256), 0, (hipStream_t)stream, z, N, ld, first_last);
+    hipStream_t st = (hipStream_t)stream;
+    long long* idx = reinterpret_cast<long long*>(ws);
+    const dim3 grid((unsigned)cdiv64(N, PREP_CHUNK), (unsigned)F);
+    hipLaunchKernelGGL(prep_fill_init_kernel, dim3((F + 63) / 64), dim3(64), 0, st, idx, F, N);
+    hipLaunchKernelGGL(prep_fill_scan_kernel, grid, dim3(256), 0, st, (const double*)z, N, ld, idx);
+    hipLaunchKernelGGL(prep_fill_apply_kernel, grid, dim3(256), 0, st, z, N, ld, (const long long*)idx, first_last);
     VAME_LAUNCH_CHECK("prep_fill_last_valid");
     return VAME_OK;
 }
@@ -126,8 +148,10 @@ extern "C" int vame_prep_fill_across_features_f64(double* z, int F, int64_t N, i
 }
 
 // ---------------------------------------------------------------------------------------------- per-feature mean / std
-// Population std over time per feature (np.std(X.T, axis=1), create_training.py:153), two passes, one block per feature,
-// fixed summation tree: rows with identical contents give identical results (the anchor search relies on exact ties).
+// Population std over time per feature (np.std(X.T, axis=1), create_training.py:153).  Two passes (mean, then squared
+// deviations), each a (<= 256 chunks, F) grid of fixed-tree block sums into a partial table plus one block per feature that adds
+// the partials in index order: the summation tree depends only on N, so rows with identical contents give identical results
+// (the anchor search relies on exact ties).
 __device__ __forceinline__ double block_sum_f64(double v, double* sh) {
     sh[threadIdx.x] = v;
     __syncthreads();
@@ -140,24 +164,43 @@ __device__ __forceinline__ double block_sum_f64(double v, double* sh) {
     return r;
 }
 
-__global__ __launch_bounds__(256) void prep_rowstats_kernel(const double* __restrict__ x, int64_t N, int64_t ld,
-                                                            double* __restrict__ mean_out, double* __restrict__ std_out) {
+__global__ __launch_bounds__(256) void prep_rowpartial_kernel(const double* __restrict__ x, int64_t N, int64_t ld, int64_t per,
+                                                              const double* __restrict__ centre, double* __restrict__ partial) {
     __shared__ double sh[256];
-    const double* row = x + (int64_t)blockIdx.x * ld;
+    const double* row = x + (int64_t)blockIdx.y * ld;
+    const double c = centre ? centre[blockIdx.y] : 0.0;
+    const int64_t n0 = (int64_t)blockIdx.x * per, n1 = n0 + per < N ? n0 + per : N;
     double s = 0.0;
-    for (int64_t n = threadIdx.x; n < N; n += blockDim.x) s += row[n];
-    const double mean = block_sum_f64(s, sh) / (double)N;
-    double q = 0.0;
-    for (int64_t n = threadIdx.x; n < N; n += blockDim.x) { const double d = row[n] - mean; q += d * d; }
-    const double var = block_sum_f64(q, sh) / (double)N;
-    if (threadIdx.x == 0) { mean_out[blockIdx.x] = mean; std_out[blockIdx.x] = sqrt(var); }
+    if (centre) for (int64_t n = n0 + threadIdx.x; n < n1; n += blockDim.x) { const double d = row[n] - c; s += d * d; }
+    else for (int64_t n = n0 + threadIdx.x; n < n1; n += blockDim.x) s += row[n];
+    s = block_sum_f64(s, sh);
+    if (threadIdx.x == 0) partial[(int64_t)blockIdx.y * gridDim.x + blockIdx.x] = s;
 }
 
-extern "C" int vame_prep_rowstats_f64(const double* x, int F, int64_t N, int64_t ld, double* mean_out, double* std_out,
+__global__ void prep_rowfinal_kernel(const double* __restrict__ partial, int nblk, int F, int64_t N, int take_sqrt,
+                                     double* __restrict__ out) {
+    const int f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= F) return;
+    double s = 0.0;
+    for (int b = 0; b < nblk; ++b) s += partial[(int64_t)f * nblk + b];
+    s /= (double)N;
+    out[f] = take_sqrt ? sqrt(s) : s;
+}
+
+extern "C" int vame_prep_rowstats_f64(const double* x, int F, int64_t N, int64_t ld, double* mean_out, double* std_out, void* ws,
                                       void* stream) {
-    VAME_CHECK_ARG(x && mean_out && std_out, VAME_E_BADARG, "prep_rowstats: null pointer");
+    VAME_CHECK_ARG(x && mean_out && std_out && ws, VAME_E_BADARG, "prep_rowstats: null pointer");
     VAME_CHECK_ARG(F >= 1 && N >= 1 && ld >= N, VAME_E_SHAPE, "prep_rowstats: bad shape F=%d N=%lld", F, (long long)N);
-    hipLaunchKernelGGL(prep_rowstats_kernel, dim3(F), dim3(256), 0, (hipStream_t)stream, x, N, ld, mean_out, std_out);
+    hipStream_t st = (hipStream_t)stream;
+    double* partial = reinterpret_cast<double*>(ws);
+    int64_t per = cdiv64(N, 256);
+    per = cdiv64(per < 2048 ? 2048 : per, 256) * 256;
+    const int nblk = (int)cdiv64(N, per);                     // <= 256
+    const dim3 grid((unsigned)nblk, (unsigned)F);
+    hipLaunchKernelGGL(prep_rowpartial_kernel, grid, dim3(256), 0, st, x, N, ld, per, (const double*)nullptr, partial);
+    hipLaunchKernelGGL(prep_rowfinal_kernel, dim3((F + 63) / 64), dim3(64), 0, st, (const double*)partial, nblk, F, N, 0, mean_out);
+    hipLaunchKernelGGL(prep_rowpartial_kernel, grid, dim3(256), 0, st, x, N, ld, per, (const double*)mean_out, partial);
+    hipLaunchKernelGGL(prep_rowfinal_kernel, dim3((F + 63) / 64), dim3(64), 0, st, (const double*)partial, nblk, F, N, 1, std_out);
     VAME_LAUNCH_CHECK("prep_rowstats");
     return VAME_OK;
 }

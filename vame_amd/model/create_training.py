@@ -63,6 +63,7 @@ def prepare_series(files_data, *, fixed, robust, iqr_factor, savgol_filter, savg
     X = torch.empty(F, N, dtype=torch.float64, device=dev)
     first_last = torch.empty(F, 2, dtype=torch.float64, device=dev)
     n_empty = torch.zeros(1, dtype=torch.int32, device=dev)
+    ws = ops.prep_ws(F, dev)
     info = dict(iqr=[], anchors=None)
     for i, data in enumerate(files_data):
         if data.shape[0] != F:
@@ -83,7 +84,7 @@ def prepare_series(files_data, *, fixed, robust, iqr_factor, savgol_filter, savg
             if fixed:
                 ops.prep_fill_across_features(X, F, Ni, N, n_empty, z_off=int(pos[i]))
             else:
-                ops.prep_fill_last_valid(X, F, Ni, N, first_last, z_off=int(pos[i]))
+                ops.prep_fill_last_valid(X, F, Ni, N, first_last, ws, z_off=int(pos[i]))
                 _resolve_empty_features(X[:, int(pos[i]):int(pos[i + 1])], first_last)
     if fixed and robust and int(n_empty.item()) > 0:
         raise ValueError("array of sample points is empty")          # np.interp on an all-outlier frame (create_training.py:236)
@@ -92,7 +93,7 @@ def prepare_series(files_data, *, fixed, robust, iqr_factor, savgol_filter, savg
     if not fixed:
         mean_f = torch.empty(F, dtype=torch.float64, device=dev)
         std_f = torch.empty(F, dtype=torch.float64, device=dev)
-        ops.prep_rowstats(X, F, N, N, mean_f, std_f)
+        ops.prep_rowstats(X, F, N, N, mean_f, std_f, ws)
         d = std_f.cpu().numpy()
         s = np.sort(d)
         if s[0] == s[1]:

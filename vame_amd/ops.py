@@ -196,8 +196,12 @@ def prep_zscore_mask(x, F, N, ldx, mean, sd, cutoff, robust, z, ldz, z_off=0):
     _lib.check(rc, "vame_prep_zscore_mask_f64")
 
 
-def prep_fill_last_valid(z, F, N, ld, first_last, z_off=0):
-    rc = _lib.lib().vame_prep_fill_last_valid_f64(_ptr(z, z_off), F, N, ld, _ptr(first_last), _stream())
+def prep_ws(F, dev):
+    return torch.empty(_lib.lib().vame_prep_ws_bytes(F) // 8, dtype=torch.float64, device=dev)
+
+
+def prep_fill_last_valid(z, F, N, ld, first_last, ws, z_off=0):
+    rc = _lib.lib().vame_prep_fill_last_valid_f64(_ptr(z, z_off), F, N, ld, _ptr(first_last), _ptr(ws), _stream())
     _lib.check(rc, "vame_prep_fill_last_valid_f64")
 
 
@@ -206,8 +210,8 @@ def prep_fill_across_features(z, F, N, ld, n_empty, z_off=0):
     _lib.check(rc, "vame_prep_fill_across_features_f64")
 
 
-def prep_rowstats(x, F, N, ld, mean_out, std_out):
-    rc = _lib.lib().vame_prep_rowstats_f64(_ptr(x), F, N, ld, _ptr(mean_out), _ptr(std_out), _stream())
+def prep_rowstats(x, F, N, ld, mean_out, std_out, ws):
+    rc = _lib.lib().vame_prep_rowstats_f64(_ptr(x), F, N, ld, _ptr(mean_out), _ptr(std_out), _ptr(ws), _stream())
     _lib.check(rc, "vame_prep_rowstats_f64")
 
 
