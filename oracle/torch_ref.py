@@ -66,6 +66,44 @@ class TorchRef(nn.Module):
         return pred, fut, z, mu, lv
 
 
+class TorchRefLegacy(nn.Module):
+    """Stock-torch restatement of RNN_VAE_LEGACY (reference rnn_model.py:186-324): two stacked 1-layer bi-GRUs, an unused
+    hidden_to_linear layer, softplus on the log-variance always, uni-directional reconstruction decoder, zero initial states.
+    Sub-module names are the reference's, so its state_dict loads directly.  Pinned by tests/golden/step_legacy.npz."""
+
+    def __init__(self, T=30, F=24, Z=30, H=256, FS=15, future=True):
+        super().__init__()
+        self.T, self.F, self.Z, self.H, self.FS, self.future = T, F, Z, H, FS, future
+        self.encoder = nn.ModuleDict(dict(rnn_1=nn.GRU(F, H, batch_first=True, bidirectional=True),
+                                          rnn_2=nn.GRU(2 * H, H, batch_first=True, bidirectional=True)))
+        self.lmbda = nn.ModuleDict(dict(hidden_to_linear=nn.Linear(4 * H, 4 * H), hidden_to_mean=nn.Linear(4 * H, Z),
+                                        hidden_to_logvar=nn.Linear(4 * H, Z)))
+        self.decoder = nn.ModuleDict(dict(rnn_rec=nn.GRU(Z, H, batch_first=True, bidirectional=False),
+                                          hidden_to_output=nn.Linear(H, F)))
+        if future:
+            self.decoder_future = nn.ModuleDict(dict(rnn_pred=nn.GRU(Z, H, batch_first=True, bidirectional=True),
+                                                     hidden_to_output=nn.Linear(2 * H, F)))
+
+    def forward(self, x, eps=None):
+        o1, h1 = self.encoder["rnn_1"](x)
+        _, h2 = self.encoder["rnn_2"](o1)
+        h = torch.cat([h1[0], h1[1], h2[0], h2[1]], 1)
+        mu = self.lmbda["hidden_to_mean"](h)
+        lv = Fn.softplus(self.lmbda["hidden_to_logvar"](h))
+        if self.training:
+            if eps is None:
+                eps = torch.randn_like(mu)
+            z = eps * torch.exp(0.5 * lv) + mu
+        else:
+            z = mu
+        ins = z.unsqueeze(1).expand(z.shape[0], self.T, self.Z).contiguous()
+        pred = self.decoder["hidden_to_output"](self.decoder["rnn_rec"](ins)[0])
+        fut = None
+        if self.future:
+            fut = self.decoder_future["hidden_to_output"](self.decoder_future["rnn_pred"](ins[:, :self.FS])[0])
+        return pred, fut, z, mu, lv
+
+
 def reference_loss(out, x, xfut, kl_weight, beta=1.0, kloss=30, klmbda=0.1, bsize=None, red="sum"):
     pred, fut, z, mu, lv = out
     bsize = z.shape[0] if bsize is None else bsize

@@ -268,6 +268,46 @@ def synth_pose_file(F, N, seed, anchors):
     return X
 
 
+def legacy_fixture(rnn_model, rnn_vae):
+    """RNN_VAE_LEGACY (cfg['legacy'], rnn_model.py:186-324): one train step of the reference on a tiny model -- outputs, the
+    four loss terms, every gradient (hidden_to_linear gets none), and the eval-mode outputs."""
+    T, Z, F, FS, H, B = 30, 30, 24, 15, 32, 6
+    torch.manual_seed(23)
+    model = rnn_model.RNN_VAE_LEGACY(2 * T, Z, F, 1, FS, H, H, H, H, 0, 0, 0, False)
+    model.train()
+    out = {"w/" + k: v.detach().numpy().copy() for k, v in model.state_dict().items()}
+    X = synth_series(F, 400, seed=4)
+    Xn = (X - X.mean()) / X.std()
+    starts = np.random.RandomState(5).randint(0, 400 - 2 * T, size=B)
+    item = torch.from_numpy(np.stack([Xn[:, s:s + 2 * T] for s in starts])).permute(0, 2, 1)
+    data = item[:, :T, :].type("torch.FloatTensor")
+    fut_t = item[:, T:T + FS, :].type("torch.FloatTensor")
+    torch.manual_seed(7)
+    eps = torch.randn(B, Z)
+    torch.manual_seed(7)                                  # Lambda_LEGACY draws std.data.new(...).normal_(): same stream
+    pred, fut, latent, mu, logvar = model(data)
+    kw = 0.5
+    rec = rnn_vae.reconstruction_loss(data, pred, "sum")
+    fl = rnn_vae.future_reconstruction_loss(fut_t, fut, "sum")
+    km = rnn_vae.cluster_loss(latent.T, Z, 0.1, B)
+    kl = rnn_vae.kullback_leibler_loss(mu, logvar)
+    loss = rec + fl + 1.0 * kw * kl + kw * km
+    loss.backward()
+    np.testing.assert_allclose(latent.detach().numpy(), (eps * torch.exp(0.5 * logvar) + mu).detach().numpy(), atol=1e-6)
+    out.update(x=data.numpy().copy(), xfut=fut_t.numpy().copy(), eps=eps.numpy(), pred=pred.detach().numpy(), fut=fut.detach().numpy(),
+               z=latent.detach().numpy(), mu=mu.detach().numpy(), logvar=logvar.detach().numpy(),
+               losses=np.array([rec.item(), fl.item(), kl.item(), km.item()]), kw=np.array([kw]),
+               spec=np.array([T, F, Z, H, FS, 1, 1, B]))
+    for k, p in model.named_parameters():
+        out["g/" + k] = p.grad.numpy().copy() if p.grad is not None else np.zeros(tuple(p.shape), np.float32)
+    out["no_grad"] = np.array([k for k, p in model.named_parameters() if p.grad is None])
+    model.eval()
+    with torch.no_grad():
+        ep, ef, ez, emu, elv = model(data)
+    out.update(eval_pred=ep.numpy(), eval_fut=ef.numpy(), eval_mu=emu.numpy())
+    np.savez_compressed(os.path.join(OUT, "step_legacy.npz"), **out)
+
+
 def prep_fixture():
     """create_trainset arithmetic: the reference's traindata_aligned / traindata_fixed on two small files."""
     import matplotlib
@@ -300,6 +340,10 @@ def main():
         load_reference()
         prep_fixture()
         return
+    if len(sys.argv) > 1 and sys.argv[1] == "legacy":
+        rnn_model, dataloader, rnn_vae, pose = load_reference()
+        legacy_fixture(rnn_model, rnn_vae)
+        return
     rnn_model, dataloader, rnn_vae, pose = load_reference()
     torch.set_num_threads(4)
     step_fixture(rnn_model, rnn_vae, "step_tiny")                                       # H=32,B=8, all grads + Adam
@@ -315,6 +359,7 @@ def main():
     h0view_fixture(rnn_model)
     anneal_fixture(rnn_vae)
     train_model_fixture(rnn_vae)
+    legacy_fixture(rnn_model, rnn_vae)
     prep_fixture()
 
 

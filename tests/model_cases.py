@@ -172,3 +172,48 @@ def check_odd_dims_vs_oracle(dev, F=10, Z=7, H=32, T=9, FS=4, B=5):
     for k, prm in model.named_parameters():
         r = grads[k]
         np.testing.assert_allclose(prm.grad.cpu().numpy(), r, atol=3e-4 * max(1.0, np.abs(r).max()), err_msg=k)
+
+
+def check_legacy_step(dev):
+    """RNN_VAE_LEGACY (cfg['legacy'], reference rnn_model.py:186-324) against one train step of the reference
+    (tests/golden/step_legacy.npz): outputs, the four loss terms, all gradients, eval mode, sub-module call patterns."""
+    from vame_amd.model.rnn_model import RNN_VAE_LEGACY
+    g = load_golden("step_legacy")
+    T, F, Z, H, FS, fut, sp, B = [int(v) for v in g["spec"]]
+    model = RNN_VAE_LEGACY(2 * T, Z, F, 1, FS, H, H, H, H, 0, 0, 0, False)
+    w = {k[2:]: g[k] for k in g if k.startswith("w/")}
+    assert list(model.state_dict().keys()) == list(w.keys())
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in w.items()})
+    model = model.to(dev).train()
+    x, xfut, eps = [torch.from_numpy(g[k]).to(dev) for k in ("x", "xfut", "eps")]
+    win = torch.cat([x, xfut], 1).contiguous()
+    kw = float(g["kw"][0])
+    out = model.loss_step(win, kw, beta=1.0, kloss=Z, klmbda=0.1, bsize=B, eps=eps).cpu().numpy()
+    ref = g["losses"]
+    for i in range(4):
+        assert abs(out[i] - ref[i]) <= 1e-4 * max(1.0, abs(ref[i])), (i, out[i], ref[i])
+    eng = model._engine
+    for name, ref_v in (("pred", g["pred"]), ("futp", g["fut"]), ("z", g["z"]), ("mu", g["mu"]), ("logvar", g["logvar"])):
+        got = eng.ws.t[name][:ref_v.size].view(*ref_v.shape).cpu().numpy()
+        np.testing.assert_allclose(got, ref_v, atol=3e-5, err_msg=name)
+    for k, p in model.named_parameters():
+        gr = g["g/" + k]
+        np.testing.assert_allclose(p.grad.cpu().numpy(), gr, atol=3e-4 * max(np.abs(gr).max(), 1e-3), err_msg=k)
+    assert set(g["no_grad"]) == {"lmbda.hidden_to_linear.weight", "lmbda.hidden_to_linear.bias"}
+    # autograd path through model(x)
+    model.zero_grad(set_to_none=False)
+    pred, futp, z, mu, lv = model(x, eps=eps)
+    np.testing.assert_allclose(pred.detach().cpu().numpy(), g["pred"], atol=3e-5)
+    (pred.sum() + futp.sum()).backward()
+    assert float(model.decoder.hidden_to_output.weight.grad.abs().sum()) > 0
+    # eval mode + the legacy sub-module signatures: decoder(inputs) takes the tiled latent only (rnn_model.py:263,288)
+    model.eval()
+    ep, ef, ez, emu, elv = model(x)
+    np.testing.assert_allclose(ep.cpu().numpy(), g["eval_pred"], atol=3e-5)
+    np.testing.assert_allclose(ef.cpu().numpy(), g["eval_fut"], atol=3e-5)
+    np.testing.assert_allclose(emu.cpu().numpy(), g["eval_mu"], atol=1e-5)
+    ins = emu.unsqueeze(2).repeat(1, 1, T).permute(0, 2, 1)
+    np.testing.assert_allclose(model.decoder(ins).cpu().numpy(), g["eval_pred"], atol=3e-5)
+    np.testing.assert_allclose(model.decoder_future(ins).cpu().numpy(), g["eval_fut"], atol=3e-5)
+    h = model.encoder(x)
+    np.testing.assert_allclose(model.lmbda(h)[1].cpu().numpy(), g["eval_mu"], atol=1e-5)

@@ -2,7 +2,7 @@
 reference's golden vectors (tiny model).  The same bodies run on the GPU in test_model_gpu.py."""
 import pytest
 
-from model_cases import check_adam_trajectory, check_odd_dims_vs_oracle, check_eval_and_submodules, check_evaluate_and_generative_cores, check_h0_view, check_noise_input, check_step
+from model_cases import check_adam_trajectory, check_odd_dims_vs_oracle, check_eval_and_submodules, check_evaluate_and_generative_cores, check_h0_view, check_legacy_step, check_noise_input, check_step
 
 
 @pytest.mark.parametrize("name,kw,mse", [("step_tiny", 1.0, "sum"), ("step_tiny", 0.25, "sum"), ("step_tiny_oddB", 1.0, "sum"),
@@ -22,6 +22,10 @@ def test_eval_and_submodules(emu):
 
 def test_evaluate_and_generative_cores(emu):
     check_evaluate_and_generative_cores("cpu")
+
+
+def test_legacy_model_matches_reference(emu):
+    check_legacy_step("cpu")
 
 
 def test_decoder_h0_view(emu):

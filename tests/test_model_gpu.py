@@ -5,7 +5,7 @@ import pytest
 import torch
 
 from conftest import load_golden
-from model_cases import check_adam_trajectory, check_odd_dims_vs_oracle, check_eval_and_submodules, check_evaluate_and_generative_cores, check_h0_view, check_noise_input, check_step
+from model_cases import check_adam_trajectory, check_odd_dims_vs_oracle, check_eval_and_submodules, check_evaluate_and_generative_cores, check_h0_view, check_legacy_step, check_noise_input, check_step
 from oracle import vame_oracle as vo
 from vame_amd.model.rnn_model import RNN_VAE
 
@@ -29,6 +29,10 @@ def test_eval_and_submodules(hip):
 
 def test_evaluate_and_generative_cores(hip):
     check_evaluate_and_generative_cores("cuda")
+
+
+def test_legacy_model_matches_reference(hip):
+    check_legacy_step("cuda")
 
 
 def test_decoder_h0_view(hip):

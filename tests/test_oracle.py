@@ -141,3 +141,24 @@ def test_prep_oracle_matches_reference_outputs(name, fixed):
     np.testing.assert_array_equal(r["clean"][0], g["clean0"])
     np.testing.assert_array_equal(r["clean"][1], g["clean1"])
     assert not np.isnan(g["train"]).any() and g["train"].shape[0] == 24
+
+
+def test_torch_legacy_restatement_matches_reference():
+    """oracle/torch_ref.TorchRefLegacy (stock torch modules) vs one train step of the reference's RNN_VAE_LEGACY."""
+    import torch
+    from oracle.torch_ref import TorchRefLegacy, reference_loss
+    g = load_golden("step_legacy")
+    T, F, Z, H, FS, fut, sp, B = [int(v) for v in g["spec"]]
+    m = TorchRefLegacy(T, F, Z, H, FS, True)
+    m.load_state_dict({k[2:]: torch.from_numpy(g[k]) for k in g if k.startswith("w/")})
+    m.train()
+    x, xfut, eps = [torch.from_numpy(g[k]) for k in ("x", "xfut", "eps")]
+    out = m(x, eps)
+    loss, terms = reference_loss(out, x, xfut, float(g["kw"][0]), kloss=Z, bsize=B)
+    loss.backward()
+    np.testing.assert_allclose([float(t) for t in terms], g["losses"], rtol=2e-5)
+    np.testing.assert_allclose(out[0].detach().numpy(), g["pred"], atol=2e-6)
+    for k, p in m.named_parameters():
+        ref = g["g/" + k]
+        got = p.grad.numpy() if p.grad is not None else np.zeros_like(ref)
+        np.testing.assert_allclose(got, ref, atol=2e-4 * max(np.abs(ref).max(), 1e-3), err_msg=k)

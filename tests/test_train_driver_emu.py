@@ -146,6 +146,31 @@ def test_generative_model_modes(project):
     plt.close("all")
 
 
+def test_train_model_legacy_topology(project, tmp_path):
+    """cfg['legacy'] = True trains RNN_VAE_LEGACY (rnn_vae.py:294-297): checkpoint keys / shapes of the legacy model."""
+    import shutil
+    import vame_amd as vame
+    from vame_amd.model.rnn_model import RNN_VAE_LEGACY
+    root, cfg, g = project
+    lroot = tmp_path / "legacy"
+    shutil.copytree(root / "data", lroot / "data")
+    os.makedirs(lroot / "model")
+    lcfg = dict(cfg, project_path=str(lroot), legacy=True, max_epochs=3, model_snapshot=50, kl_start=0, annealtime=1)
+    with open(lroot / "config.yaml", "w") as f:
+        yaml.safe_dump(lcfg, f)
+    np.random.seed(1)
+    vame.train_model(str(lroot / "config.yaml"))
+    sd = torch.load(lroot / "model" / "best_model" / "VAME_demo.pkl")
+    H = cfg["hidden_size_layer_1"]
+    ref = RNN_VAE_LEGACY(60, 30, 24, 1, 15, H, H, H, H, 0, 0, 0, False).state_dict()
+    assert list(sd.keys()) == list(ref.keys()) and all(sd[k].shape == ref[k].shape for k in sd)
+    assert "decoder.rnn_rec.weight_ih_l0_reverse" not in sd and "lmbda.hidden_to_linear.weight" in sd
+    losses = np.load(lroot / "model" / "model_losses" / "train_losses_VAME.npy")
+    assert losses.shape == (2,) and np.isfinite(losses).all()
+    with pytest.raises(NotImplementedError):
+        vame.pose_segmentation(str(lroot / "config.yaml"))
+
+
 def test_create_trainset_files(tmp_path, emu):
     """vame.create_trainset (create_training.py:267-300): train/test split + per-video clean files, equal to the files the
     REFERENCE wrote for the same inputs (tests/golden/prep_*.npz)."""

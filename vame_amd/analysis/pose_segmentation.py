@@ -177,7 +177,8 @@ def pose_segmentation(config):
     parameterization = cfg['parameterization']
     print('Pose segmentation for VAME model: %s \n' % model_name)
     if legacy == True:  # noqa: E712
-        raise NotImplementedError("vame_amd: the legacy model is outside the MI355X hot path (SURVEY.md row 1b)")
+        raise NotImplementedError("pose_segmentation with cfg['legacy']: the reference imports a `segment_behavior` module that is not part "
+                                  "of the repository (pose_segmentation.py:205-207), so there is no behaviour to reproduce")
     ind_param = cfg['individual_parameterization']
     pp = cfg['project_path']
     for folders in cfg['video_sets']:

@@ -34,6 +34,8 @@ class Spec:
     FS: int
     future: bool
     softplus: bool
+    legacy: bool = False      # RNN_VAE_LEGACY topology (rnn_model.py:186-324): encoder = two stacked 1-layer bi-GRUs, softplus
+                              # always, uni-directional reconstruction decoder, no latent->hidden initial states
 
 
 class ParamTable:
@@ -89,10 +91,17 @@ class VAEEngine:
         # H <= 256: persistent sequence kernels (h and the gate tiles stay on chip for all T steps).  Larger H: the gate
         # GEMM per step is a real dense contraction (M = batch) -> per-step vame_gemm_f32 + gate-math kernels
         self.stepwise = H > 256
-        e = "encoder.encoder_rnn"
-        self.enc = [[GruDir(e, "_l0", H, F, self.dev), GruDir(e, "_l0_reverse", H, F, self.dev)],
-                    [GruDir(e, "_l1", H, 2 * H, self.dev), GruDir(e, "_l1_reverse", H, 2 * H, self.dev)]]
-        self.dec = [GruDir("decoder.rnn_rec", "_l0", H, Z, self.dev), GruDir("decoder.rnn_rec", "_l0_reverse", H, Z, self.dev)]
+        if spec.legacy:       # same arithmetic as the 2-layer encoder, parameters live in two 1-layer modules
+            e0, e1, s1 = "encoder.rnn_1", "encoder.rnn_2", "_l0"
+        else:
+            e0 = e1 = "encoder.encoder_rnn"
+            s1 = "_l1"
+        self.enc = [[GruDir(e0, "_l0", H, F, self.dev), GruDir(e0, "_l0_reverse", H, F, self.dev)],
+                    [GruDir(e1, s1, H, 2 * H, self.dev), GruDir(e1, s1 + "_reverse", H, 2 * H, self.dev)]]
+        self.dec = [GruDir("decoder.rnn_rec", "_l0", H, Z, self.dev)]
+        if not spec.legacy:
+            self.dec.append(GruDir("decoder.rnn_rec", "_l0_reverse", H, Z, self.dev))
+        self.h0_from_z = not spec.legacy      # Linear(z).view(2,B,H) initial states (rnn_model.py:103-104,136-137); legacy: zeros
         self.fut = ([GruDir("decoder_future.rnn_pred", "_l0", H, Z, self.dev),
                      GruDir("decoder_future.rnn_pred", "_l0_reverse", H, Z, self.dev)] if spec.future else [])
         self.ws = Workspace()
@@ -271,9 +280,11 @@ class VAEEngine:
 
     def _decode_one(self, tag, name, dirs, steps, z, B, training, rows):
         H, Z = self.spec.H, self.spec.Z
-        hid = self.buf(f"hid_{tag}", B, 2 * H)
-        ops.gemm(B, 2 * H, Z, Operand(z, Z), 0, self.P(f"{name}.latent_to_hidden.weight", Z), 0, hid, 2 * H,
-                 bias=self._pv(f"{name}.latent_to_hidden.bias"))
+        hid = None
+        if self.h0_from_z:
+            hid = self.buf(f"hid_{tag}", B, 2 * H)
+            ops.gemm(B, 2 * H, Z, Operand(z, Z), 0, self.P(f"{name}.latent_to_hidden.weight", Z), 0, hid, 2 * H,
+                     bias=self._pv(f"{name}.latent_to_hidden.bias"))
         Y = self.buf(f"Y_{tag}", B, steps + 2, 2 * H)
         for dirn, d in enumerate(dirs):
             gi = self.buf(f"gi_{tag}_{dirn}", B, 3 * H)
@@ -291,8 +302,9 @@ class VAEEngine:
         Yf = self._decode_one("fut", "decoder_future", self.fut, FS, z, B, training, rows) if s.future else None
         self._gru_fwd(rows, B)
         pred = self.buf("pred", B, T, F)
-        ops.gemm(B * T, F, 2 * H, Operand(Yd, 2 * H, off=2 * H, seg=T, seg_stride=(T + 2) * 2 * H), 0,
-                 self.P("decoder.hidden_to_output.weight", 2 * H), 0, pred, F, bias=self._pv("decoder.hidden_to_output.bias"))
+        Kd = len(self.dec) * H                 # H for the uni-directional legacy decoder: only the first half of each Y row
+        ops.gemm(B * T, F, Kd, Operand(Yd, 2 * H, off=2 * H, seg=T, seg_stride=(T + 2) * 2 * H), 0,
+                 self.P("decoder.hidden_to_output.weight", Kd), 0, pred, F, bias=self._pv("decoder.hidden_to_output.bias"))
         fut = None
         if s.future:
             fut = self.buf("futp", B, FS, F)
@@ -387,17 +399,19 @@ class VAEEngine:
         Yrows = Operand(Y, 2 * H, off=2 * H, seg=steps, seg_stride=(steps + 2) * 2 * H)
         dY = self.buf(f"dY_{tag}", B, steps, 2 * H)
         wo = f"{name}.hidden_to_output.weight"
-        ops.gemm(B * steps, 2 * H, F, Operand(dpred, F), 0, self.P(wo, 2 * H), 1, dY, 2 * H)
-        self._gemm_wgrad(F, 2 * H, B * steps, Operand(dpred, F), Yrows, wo)
+        Ko = len(dirs) * H
+        ops.gemm(B * steps, Ko, F, Operand(dpred, F), 0, self.P(wo, Ko), 1, dY, 2 * H)
+        self._gemm_wgrad(F, Ko, B * steps, Operand(dpred, F), Yrows, wo)
         ops.colsum(dpred, 0, B * steps, F, F, self.g, t.off(f"{name}.hidden_to_output.bias"))
-        dhid = self.buf(f"dhid_{tag}", B, 2 * H)
+        dhid = self.buf(f"dhid_{tag}", B, 2 * H) if self.h0_from_z else None
         rows, per = [], []
         for dirn, d in enumerate(dirs):
             dG = self.buf(f"dG_{tag}_{dirn}", B, steps, 4 * H)
             dbias = self.buf(f"db_{tag}_{dirn}", ntiles, 4 * H)
             dgsum = self.buf(f"dgs_{tag}_{dirn}", B, 3 * H)
             st = self.buf(f"st_{tag}_{dirn}", ops.gru_stash_floats(B, steps, H))
-            rows.append(self._gru_bwd_stream(d, st, Y, steps, dirn, dY, steps, None, 0, 0, dG, dhid, dirn * B * H, dbias, steps))
+            rows.append(self._gru_bwd_stream(d, st, Y, steps, dirn, dY, steps, None, 0, 0, dG, dhid, dirn * B * H if dhid is not None else 0,
+                                             dbias, steps))
             per.append((d, dG, dbias, dgsum))
         return rows, per, Y, dhid
 
@@ -423,10 +437,11 @@ class VAEEngine:
                 self._gru_param_grads(d, dG, dbias, ntiles, B, steps, Y, dirn, None, Z, const_in=(dgsum, z))
                 ops.gemm(B, Z, 3 * H, Operand(dgsum, 3 * H), 0, self.P(d.w_ih, Z), 1, dz, Z, accumulate=not first, splitk=0)
                 first = False
-            wl = f"{name}.latent_to_hidden.weight"
-            self._gemm_wgrad(2 * H, Z, B, Operand(dhid, 2 * H), Operand(z, Z), wl)
-            ops.colsum(dhid, 0, B, 2 * H, 2 * H, self.g, t.off(f"{name}.latent_to_hidden.bias"))
-            ops.gemm(B, Z, 2 * H, Operand(dhid, 2 * H), 0, self.P(wl, Z), 1, dz, Z, accumulate=True, splitk=0)
+            if dhid is not None:
+                wl = f"{name}.latent_to_hidden.weight"
+                self._gemm_wgrad(2 * H, Z, B, Operand(dhid, 2 * H), Operand(z, Z), wl)
+                ops.colsum(dhid, 0, B, 2 * H, 2 * H, self.g, t.off(f"{name}.latent_to_hidden.bias"))
+                ops.gemm(B, Z, 2 * H, Operand(dhid, 2 * H), 0, self.P(wl, Z), 1, dz, Z, accumulate=True, splitk=0)
         if use_minv and kl_weight != 0:
             ops.gemm(B, Z, Z, Operand(z, Z), 0, Operand(self.buf("Minv", Z, Z), Z), 1, dz, Z, accumulate=True)
         if dz_ext is not None:

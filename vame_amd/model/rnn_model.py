@@ -2,7 +2,8 @@
 whose forward passes run on the MI355X HIP kernels (vame_amd.engine) instead of torch.nn.GRU.
 
 Drop-in surface kept (reference: vame/model/rnn_model.py):
-  Encoder :23-45, Lambda :48-76, Decoder :79-109, Decoder_Future :112-144, RNN_VAE :147-179
+  Encoder :23-45, Lambda :48-76, Decoder :79-109, Decoder_Future :112-144, RNN_VAE :147-179,
+  the *_LEGACY variants :186-324 (cfg['legacy'])
   * the same sub-module / parameter names, so `state_dict()` keys, shapes and default
     initialisation under `torch.manual_seed` are identical and .pkl checkpoints interchange;
   * `model.encoder(x)`, `model.lmbda(h)`, `model.decoder(ins, z)` stay callable on their own
@@ -164,27 +165,34 @@ class _VAEFunction(torch.autograd.Function):
 
 
 class RNN_VAE(nn.Module):
+    _LEGACY = False
+
     def __init__(self, TEMPORAL_WINDOW, ZDIMS, NUM_FEATURES, FUTURE_DECODER, FUTURE_STEPS, hidden_size_layer_1,
                  hidden_size_layer_2, hidden_size_rec, hidden_size_pred, dropout_encoder, dropout_rec, dropout_pred, softplus):
         super().__init__()
-        _check(hidden_size_layer_1 == hidden_size_rec and (not FUTURE_DECODER or hidden_size_pred == hidden_size_layer_1),
+        _check(hidden_size_layer_1 == hidden_size_rec and (not FUTURE_DECODER or hidden_size_pred == hidden_size_layer_1)
+               and (not self._LEGACY or hidden_size_layer_2 == hidden_size_layer_1),
                "vame_amd: the gfx950 kernels need one hidden size for encoder, decoder and future decoder")
         _check(not (dropout_encoder or dropout_rec or dropout_pred), "vame_amd: dropout > 0 is not supported by the HIP GRU kernels")
         self.FUTURE_DECODER = FUTURE_DECODER
         self.seq_len = int(TEMPORAL_WINDOW / 2)
-        self.encoder = Encoder(NUM_FEATURES, hidden_size_layer_1, hidden_size_layer_2, dropout_encoder)
-        self.lmbda = Lambda(ZDIMS, hidden_size_layer_1, hidden_size_layer_2, softplus)
-        self.decoder = Decoder(self.seq_len, ZDIMS, NUM_FEATURES, hidden_size_rec, dropout_rec)
-        if FUTURE_DECODER:
-            self.decoder_future = Decoder_Future(self.seq_len, ZDIMS, NUM_FEATURES, FUTURE_STEPS, hidden_size_pred, dropout_pred)
+        self._build_modules(ZDIMS, NUM_FEATURES, FUTURE_DECODER, FUTURE_STEPS, hidden_size_layer_1, hidden_size_layer_2,
+                            hidden_size_rec, hidden_size_pred, dropout_encoder, dropout_rec, dropout_pred, softplus)
         self.spec = Spec(T=self.seq_len, F=NUM_FEATURES, Z=ZDIMS, H=hidden_size_layer_1, FS=FUTURE_STEPS if FUTURE_DECODER else 0,
-                         future=bool(FUTURE_DECODER), softplus=bool(softplus))
+                         future=bool(FUTURE_DECODER), softplus=bool(softplus) or self._LEGACY, legacy=self._LEGACY)
         for m in (self.encoder, self.lmbda, self.decoder, getattr(self, "decoder_future", None)):
             if m is not None:
                 object.__setattr__(m, "_owner", (self,))       # tuple: not registered as a sub-module
         self._flat_p = self._flat_g = self._flat_gtmp = None
         self._engine = None
         self._register_state_dict_hook(_clone_state_dict)
+
+    def _build_modules(self, ZDIMS, NUM_FEATURES, FUTURE_DECODER, FUTURE_STEPS, h1, h2, h_rec, h_pred, d_enc, d_rec, d_pred, softplus):
+        self.encoder = Encoder(NUM_FEATURES, h1, h2, d_enc)
+        self.lmbda = Lambda(ZDIMS, h1, h2, softplus)
+        self.decoder = Decoder(self.seq_len, ZDIMS, NUM_FEATURES, h_rec, d_rec)
+        if FUTURE_DECODER:
+            self.decoder_future = Decoder_Future(self.seq_len, ZDIMS, NUM_FEATURES, FUTURE_STEPS, h_pred, d_pred)
 
     # ---------------------------------------------------------------- flat parameter bucket
     def _ensure_engine(self):
@@ -295,6 +303,75 @@ class RNN_VAE(nn.Module):
         if self._engine is not None:
             self._engine.version += 1
         return r
+
+
+# ------------------------------------------------------------------------------------------------ legacy topology
+# RNN_VAE_LEGACY (reference rnn_model.py:186-324, selected by cfg['legacy']): the encoder is two stacked 1-layer
+# bidirectional GRUs (the same arithmetic as the 2-layer one when both hidden sizes agree), Lambda always applies softplus to
+# the log-variance and carries an unused `hidden_to_linear` layer, the reconstruction decoder is UNI-directional, and neither
+# decoder gets an initial state from z.  Parameter names / order follow the reference so checkpoints interchange.
+class Encoder_LEGACY(Encoder):
+    def __init__(self, NUM_FEATURES, hidden_size_layer_1, hidden_size_layer_2, dropout_encoder):
+        nn.Module.__init__(self)
+        self.input_size, self.hidden_size, self.hidden_size_2 = NUM_FEATURES, hidden_size_layer_1, hidden_size_layer_2
+        self.n_layers, self.dropout = 1, dropout_encoder
+        self.rnn_1 = nn.GRU(input_size=NUM_FEATURES, hidden_size=hidden_size_layer_1, num_layers=1, bias=True, batch_first=True,
+                            dropout=dropout_encoder, bidirectional=True)
+        self.rnn_2 = nn.GRU(input_size=hidden_size_layer_1 * 2, hidden_size=hidden_size_layer_2, num_layers=1, bias=True,
+                            batch_first=True, dropout=dropout_encoder, bidirectional=True)
+
+
+class Lambda_LEGACY(Lambda):
+    def __init__(self, ZDIMS, hidden_size_layer_1, hidden_size_layer_2):
+        nn.Module.__init__(self)
+        self.hid_dim, self.latent_length = hidden_size_layer_1 * 2 + hidden_size_layer_2 * 2, ZDIMS
+        self.hidden_to_linear = nn.Linear(self.hid_dim, self.hid_dim)        # never used by forward (rnn_model.py:223,229-242)
+        self.hidden_to_mean = nn.Linear(self.hid_dim, ZDIMS)
+        self.hidden_to_logvar = nn.Linear(self.hid_dim, ZDIMS)
+        self.softplus = nn.Softplus()
+
+    def forward(self, cell_output, eps=None):
+        z, mean, logvar = Lambda.forward(self, cell_output, eps)
+        self.latent_mean, self.latent_logvar = mean, logvar
+        return z, mean, logvar
+
+
+class Decoder_LEGACY(_DecoderBase):
+    def __init__(self, TEMPORAL_WINDOW, ZDIMS, NUM_FEATURES, hidden_size_rec, dropout_rec):
+        super().__init__()
+        self.num_features, self.sequence_length, self.hidden_size = NUM_FEATURES, TEMPORAL_WINDOW, hidden_size_rec
+        self.latent_length, self.n_layers, self.dropout = ZDIMS, 1, dropout_rec
+        self.rnn_rec = nn.GRU(ZDIMS, hidden_size=hidden_size_rec, num_layers=1, bias=True, batch_first=True, dropout=dropout_rec,
+                              bidirectional=False)
+        self.hidden_to_output = nn.Linear(hidden_size_rec, NUM_FEATURES)
+
+    def forward(self, inputs):
+        """inputs = z tiled over time (B, T, Z) (rnn_model.py:311-312); the kernels read z = inputs[:, 0] once."""
+        return self._run(inputs, inputs[:, 0, :], "dec")
+
+
+class Decoder_Future_LEGACY(_DecoderBase):
+    def __init__(self, TEMPORAL_WINDOW, ZDIMS, NUM_FEATURES, FUTURE_STEPS, hidden_size_pred, dropout_pred):
+        super().__init__()
+        self.num_features, self.future_steps, self.sequence_length = NUM_FEATURES, FUTURE_STEPS, TEMPORAL_WINDOW
+        self.hidden_size, self.latent_length, self.n_layers, self.dropout = hidden_size_pred, ZDIMS, 1, dropout_pred
+        self.rnn_pred = nn.GRU(ZDIMS, hidden_size=hidden_size_pred, num_layers=1, bias=True, batch_first=True, dropout=dropout_pred,
+                               bidirectional=True)
+        self.hidden_to_output = nn.Linear(hidden_size_pred * 2, NUM_FEATURES)
+
+    def forward(self, inputs):
+        return self._run(inputs, inputs[:, 0, :], "fut")
+
+
+class RNN_VAE_LEGACY(RNN_VAE):
+    _LEGACY = True
+
+    def _build_modules(self, ZDIMS, NUM_FEATURES, FUTURE_DECODER, FUTURE_STEPS, h1, h2, h_rec, h_pred, d_enc, d_rec, d_pred, softplus):
+        self.encoder = Encoder_LEGACY(NUM_FEATURES, h1, h2, d_enc)
+        self.lmbda = Lambda_LEGACY(ZDIMS, h1, h2)
+        self.decoder = Decoder_LEGACY(self.seq_len, ZDIMS, NUM_FEATURES, h_rec, d_rec)
+        if FUTURE_DECODER:
+            self.decoder_future = Decoder_Future_LEGACY(self.seq_len, ZDIMS, NUM_FEATURES, FUTURE_STEPS, h_pred, d_pred)
 
 
 def _clone_state_dict(module, state_dict, prefix, local_metadata):

@@ -21,7 +21,7 @@ from torch.optim.lr_scheduler import ReduceLROnPlateau, StepLR
 from .. import _lib, ops
 from ..util.auxiliary import read_config
 from .dataloader import SEQUENCE_DATASET, DeviceWindowLoader
-from .rnn_model import RNN_VAE  # noqa: F401  (evaluate.py:20 imports RNN_VAE from here)
+from .rnn_model import RNN_VAE, RNN_VAE_LEGACY  # noqa: F401  (evaluate.py:20 imports RNN_VAE from here)
 
 
 # ------------------------------------------------------------------------------------ losses (API)
@@ -225,8 +225,6 @@ def train_model(config):
     pretrained_weights = cfg['pretrained_weights']
     pretrained_model = cfg['pretrained_model']
     fixed = cfg['egocentric_data']
-    if legacy:
-        raise NotImplementedError("vame_amd: RNN_VAE_LEGACY is outside the MI355X hot path (SURVEY.md row 1b)")
     rank, world = _maybe_init_distributed()
     is_main = rank == 0
 
@@ -276,7 +274,8 @@ def train_model(config):
     torch.manual_seed(SEED)
     if dev.type == "cuda":
         torch.cuda.manual_seed(SEED)
-    model = RNN_VAE(TEMPORAL_WINDOW, ZDIMS, NUM_FEATURES, FUTURE_DECODER, FUTURE_STEPS, cfg['hidden_size_layer_1'],
+    RNN = RNN_VAE_LEGACY if legacy else RNN_VAE                          # rnn_vae.py:294-297
+    model = RNN(TEMPORAL_WINDOW, ZDIMS, NUM_FEATURES, FUTURE_DECODER, FUTURE_STEPS, cfg['hidden_size_layer_1'],
                     cfg['hidden_size_layer_2'], cfg['hidden_size_rec'], cfg['hidden_size_pred'], cfg['dropout_encoder'],
                     cfg['dropout_rec'], cfg['dropout_pred'], cfg['softplus']).to(dev)
 
