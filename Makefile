@@ -1,8 +1,8 @@
 # Builds the product library (gfx950) and the CPU emulation library used by the non-GPU tests.
 HIPCC ?= /opt/rocm/bin/hipcc
 HOSTCXX ?= /opt/rocm/lib/llvm/bin/clang++
-SRC := vame_amd/csrc/gru_seq.hip vame_amd/csrc/gemm.hip vame_amd/csrc/elementwise.hip vame_amd/csrc/prep.hip
-HDR := vame_amd/csrc/vame_device.h vame_amd/csrc/vame_common.h include/vame_hip.h
+SRC := vame_amd/csrc/gru_seq.hip vame_amd/csrc/gemm.hip vame_amd/csrc/elementwise.hip vame_amd/csrc/prep.hip vame_amd/csrc/gru_coop.hip
+HDR := vame_amd/csrc/vame_device.h vame_amd/csrc/vame_common.h vame_amd/csrc/gru_desc.h include/vame_hip.h
 
 all: vame_amd/libvame_hip.so tests/emu/libvame_emu.so
 

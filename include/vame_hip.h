@@ -153,6 +153,16 @@ int vame_adam_amsgrad_f32(float* p, const float* g, float* m, float* v, float* v
 /* y = a*x + y style helpers for the host orchestration */
 int vame_axpy_f32(const float* x, float a, float* y, int64_t n, void* stream);
 
+/* ---- column-split GRU forward for small batches (vame_amd/csrc/gru_coop.hip): same descriptor table, stash and sequence layout
+ * and bit-identical results as vame_gru_seq_fwd_f32, but a 32-row tile is shared by H/32 workgroups that keep their slice of W_hh in
+ * LDS and exchange h_t through the output sequence (needs GF_Y, a precomputed gi, H = 128 or 256, and a grid that fits one
+ * workgroup per CU: vame_gru_coop_supported).  flags: vame_gru_coop_flag_ints() ints, zeroed ONCE by the caller and then only
+ * passed back; epoch_base: a value that grows by more than T between launches sharing `flags`; *status is incremented if a
+ * bounded poll ever expires (results are then undefined, the launch still terminates). */
+int64_t vame_gru_coop_flag_ints(int nstreams, int B, int H);
+int vame_gru_coop_supported(int nstreams, int B, int H);
+int vame_gru_coop_fwd_f32(const int64_t* desc, int nstreams, int B, int H, int* flags, int epoch_base, int* status, void* stream);
+
 /* ---- training-set preparation: the O(N*F) float64 passes of vame/model/create_training.py.
  * Arrays are (F, N) feature-major with a leading dimension (elements), like <file>-PE-seq.npy; results are bit-identical to
  * the reference's numpy / scipy arithmetic.  mean, sd, cutoff come from the host (np.mean / np.std / iqr_factor * scipy iqr). */

@@ -69,12 +69,15 @@ static void run_block(BlockCtx& b, dim3 grid, dim3 block, uint3 bid) {
     }
 }
 
+bool g_coop = false;      // cooperative kernels (cross-block flags): one OS thread per block so every block makes progress
+
 void launch_impl(dim3 grid, dim3 block, size_t shmem, std::function<void()> body) {
     const int nthreads = block.x * block.y * block.z;
     if (nthreads % WAVE != 0) { fprintf(stderr, "emu: block size %d not a multiple of 64\n", nthreads); abort(); }
     const long nblocks = (long)grid.x * grid.y * grid.z;
     int nworkers = (int)std::min<long>(nblocks, std::max(1u, std::thread::hardware_concurrency()));
     if (const char* e = getenv("VAME_EMU_THREADS")) nworkers = std::max(1, std::min(nworkers, atoi(e)));
+    if (g_coop) nworkers = (int)nblocks;
     std::atomic<long> next{0};
     auto worker = [&]() {
         BlockCtx b;

@@ -56,6 +56,7 @@ struct BlockCtx {
     std::vector<char> dyn_smem;
 };
 extern thread_local BlockCtx* g_blk;
+extern bool g_coop;
 }  // namespace emu
 extern thread_local uint3 threadIdx, blockIdx;
 extern thread_local dim3 blockDim, gridDim;

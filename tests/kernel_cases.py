@@ -74,8 +74,9 @@ def _pack(dev, W_hh, b_ih, b_hh, H):
     return wpf, wpb, bgi, bhn
 
 
-def run_gru_fwd(dev, H, B, T, seed=0):
-    """Two streams (forward + reverse dir, with h0) in one launch; returns everything needed for bwd."""
+def run_gru_fwd(dev, H, B, T, seed=0, coop=None):
+    """Two streams (forward + reverse dir, with h0) in one launch; returns everything needed for bwd.
+    coop: an ops.CoopState -> the column-split small-batch kernel instead of the batch-tile-persistent one."""
     rng = np.random.default_rng(seed)
     I = 7
     x = rng.standard_normal((B, T, I)).astype(np.float32)
@@ -96,8 +97,36 @@ def run_gru_fwd(dev, H, B, T, seed=0):
                      GF["HN"]: ops.addr(hN, d * H), GF["HN_ROW"]: 2 * H, GF["STASH"]: ops.addr(stash), GF["T"]: T,
                      GF["REVERSE"]: d, GF["PAD"]: 1})
         st.append(dict(W_ih=W_ih, W_hh=W_hh, b_ih=b_ih, b_hh=b_hh, h0=h0, wpb=wpb, stash=stash, keep=(gi, wpf, bhn, h0t)))
-    ops.gru_seq_fwd(rows, B, H)
+    if coop is not None:
+        ops.gru_coop_fwd(rows, B, H, coop)
+    else:
+        ops.gru_seq_fwd(rows, B, H)
     return x, st, Y, hN
+
+
+def check_gru_coop_fwd(dev, H, B, T, launches=2):
+    """Column-split kernel = batch-tile-persistent kernel bit for bit (outputs, final state, stash), over repeated launches that
+    reuse the flag words (epoch logic), and it agrees with the oracle."""
+    assert ops.gru_coop_supported(2, B, H) and not ops.gru_coop_supported(2, 8192, H)
+    state = ops.CoopState(torch.device(dev))
+    x, st0, Y0, hN0 = run_gru_fwd(dev, H, B, T)
+    for it in range(launches):
+        x, st, Y, hN = run_gru_fwd(dev, H, B, T, coop=state)
+        np.testing.assert_array_equal(N_(Y), N_(Y0))
+        np.testing.assert_array_equal(N_(hN), N_(hN0))
+        # stash entries of rows past the batch (last tile) are don't-cares of both kernels: compare the valid rows
+        ntiles, NW = (B + 31) // 32, H // 32
+        q, lane, e = np.meshgrid(np.arange(4), np.arange(64), np.arange(4), indexing="ij")
+        r = 4 * q + e
+        row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)                                   # CR(r) + 4 * (lane >> 5)
+        valid = (np.arange(ntiles)[:, None, None, None] * 32 + row[None]) < B              # (ntiles, 4, 64, 4)
+        valid = np.broadcast_to(valid[:, None, None, None], (ntiles, T, NW, 5, 4, 64, 4)).reshape(-1)
+        for a, b in zip(st, st0):
+            sa, sb = N_(a["stash"]), N_(b["stash"])
+            np.testing.assert_array_equal(sa[valid], sb[valid])
+            assert np.isfinite(sa).all()
+    assert int(state.status.item()) == 0
+    check_gru_fwd(dev, H, B, T)
 
 
 def check_gru_fwd(dev, H, B, T):

@@ -1,0 +1,254 @@
+// Column-split ("cooperative") GRU sequence kernels for SMALL batches.
+//
+// gru_seq.hip gives one workgroup a whole 32-row batch tile: at batch 256 that is 8 tiles x 2 directions = 16 workgroups on a
+// 256-CU chip, and a time step costs what one CU needs for 32 x 3H x H MACs (~29 us at H = 256) no matter how idle the rest
+// is.  Here a tile is shared by S = H/32 workgroups (a "group", all on one XCD): member s owns hidden columns
+// [32s, 32s+32) of all three gates, keeps ITS 3 x 32 x H slice of W_hh in LDS for the whole sequence (98 KB at H = 256,
+// nothing is re-streamed), and after every step the members exchange their 32 x 32 slices of h_t through the output
+// sequence tensor itself (it has to be written anyway): write-through (sc1) 16-byte stores -> drained -> one relaxed agent-scope
+// flag per member; consumers poll the S flags, then read the 32 x H tile with sc1 loads (the R1 hand-off form of
+// MI355X_MICROARCH.md: no fences, L1 bypassed, L2-served inside the XCD).  I/O contract (descriptor table, stash layout, padded
+// sequence layout) is identical to vame_gru_seq_fwd_f32, and so are the results, bit for bit: same MFMA k-order, same gate
+// arithmetic.
+//
+// Residency: the spin wait needs every member of a group running.  The launcher refuses grids above one workgroup per CU
+// (<= 256 workgroups, LDS forces 1 per CU), every poll loop is bounded and reports through `status` instead of hanging.
+#include "vame_common.h"
+#include "gru_desc.h"
+
+#ifdef VAME_EMU
+#include <thread>
+#define COOP_STORE16(ptr, v) (*reinterpret_cast<f32x4*>(ptr) = (v))
+#define COOP_LOAD16(dst, ptr) ((dst) = *reinterpret_cast<const f32x4*>(ptr))
+#define COOP_WAIT_LOADS8(a, b, c, d, e, f, g, h)
+#define COOP_DRAIN()
+#define COOP_FLAG_STORE(p, v) __atomic_store_n((p), (v), __ATOMIC_RELEASE)
+#define COOP_FLAG_LOAD(p) __atomic_load_n((p), __ATOMIC_ACQUIRE)
+#define COOP_BACKOFF() std::this_thread::yield()
+#else
+// 16-byte write-through store / L1-bypassing load (sc1); asm because HIP has no 16-byte agent-scope access
+#define COOP_STORE16(ptr, v) asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(ptr), "v"(v) : "memory")
+#define COOP_LOAD16(dst, ptr) asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(dst) : "v"(ptr) : "memory")
+#define COOP_WAIT_LOADS8(a, b, c, d, e, f, g, h) \
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f), "+v"(g), "+v"(h))
+#define COOP_DRAIN() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+#define COOP_FLAG_STORE(p, v) __hip_atomic_store((p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+#define COOP_FLAG_LOAD(p) __hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+#define COOP_BACKOFF() __builtin_amdgcn_s_sleep(2)
+#endif
+
+constexpr int COOP_MAX_POLLS = 1 << 22;       // ~ seconds: a stuck group reports instead of hanging the queue
+
+// block -> (group, member).  Workgroup b runs on XCD b % 8 (observed; speed only): all members of a group share b % 8.
+template <int NM>
+__device__ __forceinline__ bool coop_map(int ngroups, int& g, int& m) {
+    const int b = blockIdx.x, xcd = b & 7, q = b >> 3;
+    m = q % NM;
+    g = (q / NM) * 8 + xcd;
+    return g < ngroups;
+}
+template <int NM>
+static int coop_grid(int ngroups) { return (int)cdiv64(ngroups, 8) * 8 * NM; }
+
+template <int H>
+__global__ __launch_bounds__(256) void gru_coop_fwd_kernel(GruFwdParams P, int* __restrict__ flags, int base, int* __restrict__ status) {
+    constexpr int NM = H / 32, LDH = H + 4, KC = H / 8, LDE = 33, LDX = 36;
+    VAME_DYN_SMEM(smem_raw);
+    f32x4* wl = reinterpret_cast<f32x4*>(smem_raw);                         // [KC][3][64] B fragments of this member's W_hh slice
+    float* hs = reinterpret_cast<float*>(wl + KC * 3 * 64);                // [32][LDH] h_{t-1} (A operand)
+    float* ex = hs + 32 * LDH;                                             // [2][32][LDE] sigmoid(r), sigmoid(u)
+    float* hx = ex + 2 * 32 * LDE;                                         // [32][LDX] this member's h_t slice, row-major
+    int g, m;
+    if (!coop_map<NM>(P.nstreams * P.ntiles, g, m)) return;
+    const int sidx = g % P.nstreams, tile = g / P.nstreams;
+    const GruFwdStream& S = P.s[sidx];
+    const int B = P.B, T = (int)S.T;
+    const int tid = threadIdx.x, lane = tid & 63, li = lane & 31, hh = lane >> 5;
+    const int w = UNIFORM(tid >> 6);                                       // 0,1,2 = gates r,u,n; 3 = helper
+    const int row0 = tile * 32, col0 = 32 * m, lrow = 4 * hh;
+    const int nvalid = B - row0;
+    int* gflags = flags + (int64_t)g * NM;
+
+    // ---- prologue: W slice -> LDS, initial state -> LDS (+ padded slot of the sequence), first gi
+    {
+        const f32x4* src = reinterpret_cast<const f32x4*>(S.wp) + (int64_t)m * KC * 3 * 64;
+        for (int i = tid; i < KC * 3 * 64; i += 256) wl[i] = src[i];
+    }
+    for (int i = tid; i < 32 * (H / 4); i += 256) {
+        const int r = i / (H / 4), c4 = i % (H / 4);
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (S.h0 && r < nvalid) v = *reinterpret_cast<const float4*>(S.h0 + (int64_t)(row0 + r) * S.h0_row + 4 * c4);
+        *reinterpret_cast<float4*>(&hs[r * LDH + 4 * c4]) = v;
+    }
+    __syncthreads();
+    const int prow = tid >> 3, pc4 = tid & 7;                              // publish / pad pass: 32 rows x 8 float4 of the slice
+    float* y_pub = S.y + (int64_t)(row0 + prow) * S.y_row + col0 + 4 * pc4;
+    if (S.pad && prow < nvalid)
+        *reinterpret_cast<float4*>(y_pub + (int64_t)(S.reverse ? T : -1) * S.y_t) = *reinterpret_cast<const float4*>(&hs[prow * LDH + col0 + 4 * pc4]);
+    f32x16 hprev, gcur, gnext;
+    float bhn = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { hprev[r] = hs[(CR(r) + lrow) * LDH + col0 + li]; gcur[r] = 0.f; gnext[r] = 0.f; }
+    const float* gi_lane = S.gi + (int64_t)(row0 + lrow) * S.gi_row + (w < 3 ? w : 0) * H + col0 + li;
+    auto load_gi = [&](int t, f32x16& dst) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            dst[r] = (CR(r) + lrow < nvalid) ? gi_lane[(int64_t)CR(r) * S.gi_row + (int64_t)t * S.gi_t] : 0.f;
+    };
+    if (w < 3) load_gi(S.reverse ? T - 1 : 0, gcur);
+    if (w == 2) bhn = S.bhn[col0 + li];
+    const float* hrow = &hs[li * LDH + 4 * hh];
+    const f32x4* wrow = wl + w * 64 + lane;
+    float4* stash = S.stash ? reinterpret_cast<float4*>(S.stash) : nullptr;
+
+    for (int step = 0; step < T; ++step) {
+        const int t = S.reverse ? T - 1 - step : step;
+        f32x16 acc;
+        if (w < 3) {
+            const bool more = step + 1 < T && S.gi_t != 0;
+            if (more) load_gi(S.reverse ? t - 1 : t + 1, gnext);           // lands during the MFMA loop
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = (w == 2) ? bhn : gcur[r];
+#pragma unroll 4
+            for (int c = 0; c < KC; ++c) {
+                const float4 a = *reinterpret_cast<const float4*>(hrow + 8 * c);
+                const f32x4 b = wrow[c * 3 * 64];
+                acc = MFMA_32x32x2(a.x, b[0], acc); acc = MFMA_32x32x2(a.y, b[1], acc);
+                acc = MFMA_32x32x2(a.z, b[2], acc); acc = MFMA_32x32x2(a.w, b[3], acc);
+            }
+            if (w < 2) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) ex[w * 32 * LDE + (CR(r) + lrow) * LDE + li] = fast_sigmoid(acc[r]);
+            }
+        }
+        __syncthreads();
+        if (w == 2) {
+            f32x16 ca, cb, us, rs;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float rr = ex[(CR(r) + lrow) * LDE + li], uu = ex[32 * LDE + (CR(r) + lrow) * LDE + li];
+                const float nn = fast_tanh(gcur[r] + rr * acc[r]);
+                const float hp = hprev[r];
+                const float hv = nn + uu * (hp - nn);
+                const float omu = 1.0f - uu;
+                ca[r] = omu * (1.0f - nn * nn);
+                cb[r] = (hp - nn) * uu * omu;
+                us[r] = uu; rs[r] = rr;
+                hprev[r] = hv;
+                hx[(CR(r) + lrow) * LDX + li] = hv;
+            }
+            if (stash) {
+                float4* sp = stash + ((((int64_t)tile * T + t) * NM + m) * 20) * 64 + lane;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    sp[(0 * 4 + q) * 64] = make_float4(ca[4 * q], ca[4 * q + 1], ca[4 * q + 2], ca[4 * q + 3]);
+                    sp[(1 * 4 + q) * 64] = make_float4(cb[4 * q], cb[4 * q + 1], cb[4 * q + 2], cb[4 * q + 3]);
+                    sp[(2 * 4 + q) * 64] = make_float4(us[4 * q], us[4 * q + 1], us[4 * q + 2], us[4 * q + 3]);
+                    sp[(3 * 4 + q) * 64] = make_float4(rs[4 * q], rs[4 * q + 1], rs[4 * q + 2], rs[4 * q + 3]);
+                    sp[(4 * 4 + q) * 64] = make_float4(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]);
+                }
+            }
+        }
+        if (w < 3 && step + 1 < T && S.gi_t != 0) gcur = gnext;
+        __syncthreads();
+        // ---- publish this member's 32 x 32 slice of h_t into the sequence tensor (write-through), then raise the flag
+        if (prow < nvalid) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(&hx[prow * LDX + 4 * pc4]);
+            COOP_STORE16(y_pub + (int64_t)t * S.y_t, v);
+        }
+        COOP_DRAIN();
+        __syncthreads();
+        if (step + 1 == T) break;
+        if (tid == 0) COOP_FLAG_STORE(&gflags[m], base + step + 1);
+        // ---- wait for all members' slices of h_t, then rebuild the full 32 x H tile in LDS
+        if (tid < NM) {
+            int polls = 0;
+            while (COOP_FLAG_LOAD(&gflags[tid]) - (base + step + 1) < 0) {
+                COOP_BACKOFF();
+                if (++polls > COOP_MAX_POLLS) { atomicAdd(status, 1); break; }
+            }
+        }
+        __syncthreads();
+        {
+            constexpr int PER = 32 * (H / 4) / 256;                       // float4 per thread (8 at H = 256)
+            static_assert(PER == 8 || PER == 4, "tile copy is written for H = 128 / 256");
+            f32x4 v[8];
+            const float* yt = S.y + (int64_t)t * S.y_t;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int idx = tid + (i % PER) * 256, r = idx / (H / 4), c4 = idx % (H / 4);
+                const int rr = r < nvalid ? r : 0;                        // rows past the batch re-read a valid row (unused)
+                if (i < PER) COOP_LOAD16(v[i], yt + (int64_t)(row0 + rr) * S.y_row + 4 * c4); else v[i] = v[0];
+            }
+            COOP_WAIT_LOADS8(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]);
+#pragma unroll
+            for (int i = 0; i < PER; ++i) {
+                const int idx = tid + i * 256, r = idx / (H / 4), c4 = idx % (H / 4);
+                *reinterpret_cast<f32x4*>(&hs[r * LDH + 4 * c4]) = v[i];
+            }
+        }
+        __syncthreads();
+    }
+    if (S.hn && w == 2) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int grow = row0 + CR(r) + lrow;
+            if (grow < B) S.hn[(int64_t)grow * S.hn_row + col0 + li] = hprev[r];
+        }
+    }
+}
+
+#ifdef VAME_EMU
+#define COOP_ALLOW_LDS(kernel, bytes)
+#else      // > 64 KiB of dynamic LDS must be granted per kernel
+#define COOP_ALLOW_LDS(kernel, bytes) \
+    VAME_CHECK_ARG(hipFuncSetAttribute(reinterpret_cast<const void*>(&kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(bytes)) == hipSuccess, \
+                   VAME_E_HIP, "gru_coop: cannot reserve %d bytes of LDS", (int)(bytes))
+#endif
+
+template <int H>
+static size_t coop_fwd_lds() {
+    constexpr int KC = H / 8, LDH = H + 4;
+    return (size_t)KC * 3 * 64 * 16 + (size_t)(32 * LDH + 2 * 32 * 33 + 32 * 36) * 4;
+}
+
+extern "C" int64_t vame_gru_coop_flag_ints(int nstreams, int B, int H) { return (int64_t)nstreams * cdiv64(B, 32) * (H / 32) + 16; }
+
+// 1 if (nstreams, B, H) can run cooperatively: every workgroup of the grid must be resident at once (one per CU)
+extern "C" int vame_gru_coop_supported(int nstreams, int B, int H) {
+    if (H != 128 && H != 256) return 0;
+    const int64_t groups = (int64_t)nstreams * cdiv64(B, 32);
+    return cdiv64(groups, 8) * 8 * (H / 32) <= 256;
+}
+
+extern "C" int vame_gru_coop_fwd_f32(const int64_t* desc, int nstreams, int B, int H, int* flags, int epoch_base, int* status,
+                                     void* stream) {
+    VAME_CHECK_ARG(desc && flags && status && nstreams >= 1 && nstreams <= 8 && B >= 1, VAME_E_BADARG, "gru_coop_fwd: bad arguments");
+    VAME_CHECK_ARG(vame_gru_coop_supported(nstreams, B, H), VAME_E_UNSUPPORTED,
+                   "gru_coop_fwd: nstreams=%d B=%d H=%d does not fit one workgroup per CU (or H not 128/256)", nstreams, B, H);
+    GruFwdParams P;
+    if (int rc = gru_parse_fwd(desc, nstreams, B, P)) return rc;
+    for (int i = 0; i < nstreams; ++i) {
+        VAME_CHECK_ARG(P.s[i].xf == 0 && P.s[i].y, VAME_E_UNSUPPORTED, "gru_coop_fwd: stream %d needs a precomputed gi and an output sequence", i);
+        VAME_CHECK_ARG((uintptr_t)P.s[i].y % 16 == 0 && P.s[i].y_row % 4 == 0 && P.s[i].y_t % 4 == 0 &&
+                       (!P.s[i].h0 || ((uintptr_t)P.s[i].h0 % 16 == 0 && P.s[i].h0_row % 4 == 0)), VAME_E_SHAPE,
+                       "gru_coop_fwd: stream %d: sequence / initial-state rows must be 16-byte aligned", i);
+    }
+    hipStream_t st = (hipStream_t)stream;
+    const int ngroups = nstreams * P.ntiles;
+#ifdef VAME_EMU
+    emu::g_coop = true;
+#endif
+    if (H == 256) {
+        COOP_ALLOW_LDS(gru_coop_fwd_kernel<256>, coop_fwd_lds<256>());
+        hipLaunchKernelGGL((gru_coop_fwd_kernel<256>), dim3(coop_grid<8>(ngroups)), dim3(256), coop_fwd_lds<256>(), st, P, flags, epoch_base, status);
+    } else {
+        COOP_ALLOW_LDS(gru_coop_fwd_kernel<128>, coop_fwd_lds<128>());
+        hipLaunchKernelGGL((gru_coop_fwd_kernel<128>), dim3(coop_grid<4>(ngroups)), dim3(256), coop_fwd_lds<128>(), st, P, flags, epoch_base, status);
+    }
+#ifdef VAME_EMU
+    emu::g_coop = false;
+#endif
+    VAME_LAUNCH_CHECK("gru_coop_fwd");
+    return VAME_OK;
+}

@@ -12,6 +12,7 @@
 //
 // Reference semantics: torch.nn.GRU as instantiated at vame/model/rnn_model.py:34-35,91-92,125-126.
 #include "vame_common.h"
+#include "gru_desc.h"
 
 #ifdef VAME_PROBE   // tuning build (make probe): per-workgroup begin/end stamps, s_memtime (shader clock) vs s_memrealtime (100 MHz)
 __device__ long long* g_gru_probe;
@@ -41,31 +42,6 @@ extern "C" int vame_probe_set_gru(long long* p) { return (int)hipMemcpyToSymbol(
 #define GRU_PHASE_DYN(i)
 #define GRU_PHASE_END()
 #endif
-
-struct GruFwdStream {
-    const float* gi; int64_t gi_row, gi_t;
-    const float* wp; const float* bhn;
-    const float* h0; int64_t h0_row;
-    float* y; int64_t y_row, y_t;
-    float* hn; int64_t hn_row;
-    float* stash;
-    int64_t T, reverse, pad;
-    const float* wpx; const float* bgi; int64_t xf;      // fused input projection (xf = features, 0 = gi is precomputed)
-};
-struct GruFwdParams { GruFwdStream s[8]; int nstreams; int B; int ntiles; };
-
-struct GruBwdStream {
-    const float* stash; const float* y; int64_t y_row, y_t;
-    const float* h0; int64_t h0_row;
-    const float* wpt;
-    const float* dy; int64_t dy_row, dy_t;
-    const float* dhn; int64_t dhn_row;
-    float* dg;
-    float* dh0; int64_t dh0_row;
-    float* dbias;
-    int64_t T, reverse, pad;
-};
-struct GruBwdParams { GruBwdStream s[8]; int nstreams; int B; int ntiles; };
 
 // blockIdx -> (stream, tile).  Workgroup b is dispatched to XCD b%8 (observed, speed only).  Streams are dealt to
 // XCD parity classes so that one XCD's 4 MiB L2 keeps at most two streams' W_hh, and -- for 4 streams ordered
@@ -158,14 +134,6 @@ extern "C" int64_t vame_gru_stash_floats(int B, int T, int H) {
 // Addressing: in the 32x32 accumulator layout register r of lane l holds row CR(r) + 4*(l>>5), column l&31.
 // Every row-major operand is therefore addressed as  uniform_row_pointer(r) [ lane_offset ]  with
 // lane_offset = 4*(l>>5)*row_stride + (l&31): one VGPR per array, row pointers stay in SGPRs.
-#define CR(r) (((r) & 3) + 8 * ((r) >> 2))
-
-#ifdef VAME_EMU
-#define UNIFORM(x) (x)
-#else
-#define UNIFORM(x) __builtin_amdgcn_readfirstlane(x)
-#endif
-
 // Backward stash, written in the accumulator-fragment order it is read back in (opaque to the host):
 //   float4 index ((((tile*T + t)*NW + w)*5 + k)*4 + rq)*64 + lane,  k = cA, cB, u, r, gh_n  with
 //   cA = (1-u)(1-n^2) (d a_n / d h'),  cB = (h_prev - n) u (1-u) (d a_z / d h'):  every BPTT gate gradient is
@@ -582,25 +550,7 @@ extern "C" int vame_gru_seq_fwd_f32(const int64_t* desc, int nstreams, int B, in
     VAME_CHECK_ARG(desc && nstreams >= 1 && nstreams <= 8, VAME_E_BADARG, "gru_seq_fwd: nstreams=%d not in 1..8", nstreams);
     VAME_CHECK_ARG(B >= 1, VAME_E_SHAPE, "gru_seq_fwd: empty batch");
     GruFwdParams P;
-    P.nstreams = nstreams; P.B = B; P.ntiles = (int)cdiv64(B, 32);
-    for (int i = 0; i < nstreams; ++i) {
-        const int64_t* d = desc + (int64_t)i * VAME_GRU_FWD_FIELDS;
-        GruFwdStream& s = P.s[i];
-        s.gi = (const float*)d[GF_GI]; s.gi_row = d[GF_GI_ROW]; s.gi_t = d[GF_GI_T];
-        s.wp = (const float*)d[GF_WP]; s.bhn = (const float*)d[GF_BHN];
-        s.h0 = (const float*)d[GF_H0]; s.h0_row = d[GF_H0_ROW];
-        s.y = (float*)d[GF_Y]; s.y_row = d[GF_Y_ROW]; s.y_t = d[GF_Y_T];
-        s.hn = (float*)d[GF_HN]; s.hn_row = d[GF_HN_ROW];
-        s.stash = (float*)d[GF_STASH];
-        s.T = d[GF_T]; s.reverse = d[GF_REVERSE]; s.pad = d[GF_PAD];
-        s.wpx = (const float*)d[GF_WPX]; s.bgi = (const float*)d[GF_BGI]; s.xf = d[GF_XF];
-        VAME_CHECK_ARG(s.gi && s.wp && s.bhn, VAME_E_BADARG, "gru_seq_fwd: stream %d: gi/wp/bhn null", i);
-        VAME_CHECK_ARG((s.xf > 0) == (P.s[0].xf > 0), VAME_E_BADARG, "gru_seq_fwd: fused-input and gi streams cannot share a launch");
-        VAME_CHECK_ARG(s.xf == 0 || (s.wpx && s.bgi && s.xf <= 32 && s.xf % 4 == 0 && s.gi_row % 4 == 0 && s.gi_t % 4 == 0 &&
-                                     (uintptr_t)s.gi % 16 == 0), VAME_E_SHAPE,
-                       "gru_seq_fwd: stream %d: fused input needs F <= 32, F %% 4 == 0 and 16-byte aligned rows", i);
-        VAME_CHECK_ARG(s.T >= 1, VAME_E_SHAPE, "gru_seq_fwd: stream %d: T=%lld", i, (long long)s.T);
-    }
+    if (int rc = gru_parse_fwd(desc, nstreams, B, P)) return rc;
     hipStream_t st = (hipStream_t)stream;
     switch (H) {
         case 32: launch_fwd<32>(P, st); break;
@@ -617,22 +567,7 @@ extern "C" int vame_gru_seq_bwd_f32(const int64_t* desc, int nstreams, int B, in
     VAME_CHECK_ARG(desc && nstreams >= 1 && nstreams <= 8, VAME_E_BADARG, "gru_seq_bwd: nstreams=%d not in 1..8", nstreams);
     VAME_CHECK_ARG(B >= 1, VAME_E_SHAPE, "gru_seq_bwd: empty batch");
     GruBwdParams P;
-    P.nstreams = nstreams; P.B = B; P.ntiles = (int)cdiv64(B, 32);
-    for (int i = 0; i < nstreams; ++i) {
-        const int64_t* d = desc + (int64_t)i * VAME_GRU_BWD_FIELDS;
-        GruBwdStream& s = P.s[i];
-        s.stash = (const float*)d[GB_STASH]; s.y = (const float*)d[GB_Y]; s.y_row = d[GB_Y_ROW]; s.y_t = d[GB_Y_T];
-        s.h0 = (const float*)d[GB_H0]; s.h0_row = d[GB_H0_ROW];
-        s.wpt = (const float*)d[GB_WPT];
-        s.dy = (const float*)d[GB_DY]; s.dy_row = d[GB_DY_ROW]; s.dy_t = d[GB_DY_T];
-        s.dhn = (const float*)d[GB_DHN]; s.dhn_row = d[GB_DHN_ROW];
-        s.dg = (float*)d[GB_DG];
-        s.dh0 = (float*)d[GB_DH0]; s.dh0_row = d[GB_DH0_ROW];
-        s.dbias = (float*)d[GB_DBIAS];
-        s.T = d[GB_T]; s.reverse = d[GB_REVERSE]; s.pad = d[GB_PAD];
-        VAME_CHECK_ARG(s.stash && s.y && s.wpt && s.dg, VAME_E_BADARG, "gru_seq_bwd: stream %d: stash/y/wpt/dg null", i);
-        VAME_CHECK_ARG(s.T >= 1, VAME_E_SHAPE, "gru_seq_bwd: stream %d: T=%lld", i, (long long)s.T);
-    }
+    if (int rc = gru_parse_bwd(desc, nstreams, B, P)) return rc;
     hipStream_t st = (hipStream_t)stream;
     switch (H) {
         case 32: launch_bwd<32>(P, st); break;

@@ -101,6 +101,35 @@ def gru_seq_fwd(streams, B, H):
     _lib.check(rc, "vame_gru_seq_fwd_f32")
 
 
+class CoopState:
+    """Flag words + launch epoch + poll-timeout counter shared by the cooperative (column-split) GRU launches of one device."""
+
+    def __init__(self, dev, ints=1 << 16):
+        self.flags = torch.zeros(ints, dtype=torch.int32, device=dev)
+        self.status = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.epoch = 1
+
+    def next_base(self, T):
+        b = self.epoch
+        self.epoch = (self.epoch + T + 2) & 0x3fffffff
+        return b
+
+
+def gru_coop_supported(nstreams, B, H):
+    return bool(_lib.lib().vame_gru_coop_supported(nstreams, B, H))
+
+
+def gru_coop_fwd(streams, B, H, state: CoopState):
+    """Column-split forward for small batches: same `streams` table and results as gru_seq_fwd."""
+    d = _desc_tensor(streams, GF["N"])
+    need = _lib.lib().vame_gru_coop_flag_ints(len(streams), B, H)
+    assert state.flags.numel() >= need, "cooperative flag buffer too small"
+    T = max(int(s[GF["T"]]) for s in streams)
+    rc = _lib.lib().vame_gru_coop_fwd_f32(d.data_ptr(), len(streams), B, H, _ptr(state.flags), state.next_base(T), _ptr(state.status),
+                                          _stream())
+    _lib.check(rc, "vame_gru_coop_fwd_f32")
+
+
 def gru_seq_bwd(streams, B, H):
     d = _desc_tensor(streams, GB["N"])
     rc = _lib.lib().vame_gru_seq_bwd_f32(d.data_ptr(), len(streams), B, H, _stream())
