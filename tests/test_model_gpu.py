@@ -169,3 +169,10 @@ def test_three_step_adam_trajectory_matches_reference(hip):
 def test_unaligned_feature_and_latent_dims(hip):
     check_odd_dims_vs_oracle("cuda")
     check_odd_dims_vs_oracle("cuda", F=12, Z=30, H=64, T=6, FS=3, B=33)
+
+
+@pytest.mark.parametrize("H,B,T,FS", [(128, 5, 4, 2), (256, 37, 6, 3)])
+def test_small_batch_cooperative_path_vs_oracle(hip, H, B, T, FS):
+    """Small batches run the column-split GRU kernels (engine._coop_ok): full train step vs the numpy oracle, and the same step
+    with the cooperative path switched off gives the same losses / latents."""
+    check_odd_dims_vs_oracle("cuda", F=10, Z=7, H=H, T=T, FS=FS, B=B)

@@ -10,16 +10,15 @@ import microbench as mb  # noqa: E402
 from vame_amd import ops  # noqa: E402
 
 state = ops.CoopState(torch.device("cuda"))
-orig = ops.gru_seq_fwd
+orig, orig_b = ops.gru_seq_fwd, ops.gru_seq_bwd
 for (H, B, T, ns) in ((256, 256, 30, 2), (256, 512, 30, 2), (256, 128, 30, 2), (256, 256, 30, 4), (256, 64, 30, 2)):
     if not ops.gru_coop_supported(ns, B, H):
         print(f"B={B} streams={ns}: not supported")
         continue
-    f0, _ = mb.bench_gru(H, B, T, ns, quiet=True)
+    f0, b0 = mb.bench_gru(H, B, T, ns, quiet=True)
     ops.gru_seq_fwd = lambda rows, B_, H_: ops.gru_coop_fwd(rows, B_, H_, state)
-    mb.ops.gru_seq_fwd = ops.gru_seq_fwd
-    f1, _ = mb.bench_gru(H, B, T, ns, quiet=True)
-    ops.gru_seq_fwd = orig
-    mb.ops.gru_seq_fwd = orig
-    print(f"H={H} B={B} T={T} streams={ns}: persistent {f0:8.1f} us ({f0/T:5.1f}/step)   cooperative {f1:8.1f} us ({f1/T:5.1f}/step)   x{f0/f1:.2f}   "
-          f"poll timeouts {int(state.status.item())}", flush=True)
+    ops.gru_seq_bwd = lambda rows, B_, H_: ops.gru_coop_bwd(rows, B_, H_, state)
+    f1, b1 = mb.bench_gru(H, B, T, ns, quiet=True)
+    ops.gru_seq_fwd, ops.gru_seq_bwd = orig, orig_b
+    print(f"H={H} B={B} T={T} streams={ns}: fwd persistent {f0:7.1f} us, cooperative {f1:7.1f} us ({f1/T:4.1f}/step) x{f0/f1:.2f} | "
+          f"bwd persistent {b0:7.1f} us, cooperative {b1:7.1f} us ({b1/T:4.1f}/step) x{b0/b1:.2f} | poll timeouts {int(state.status.item())}", flush=True)

@@ -252,3 +252,213 @@ extern "C" int vame_gru_coop_fwd_f32(const int64_t* desc, int nstreams, int B, i
     VAME_LAUNCH_CHECK("gru_coop_fwd");
     return VAME_OK;
 }
+
+// ------------------------------------------------------------------------------------------------------------- backward
+// BPTT with the same split: member m owns hidden columns C_m = [32m, 32m+32).  Per step it turns dh_t[:, C_m] (+ dy) into its
+// slice of dG (the BPTT coefficients of its columns come from its part of the forward stash), multiplies the 32 x 96 tile
+// [da_r | da_z | dgh_n] with its 96 x H slice of W_hh (LDS-resident, taken from the backward-packed weights) -- a partial
+// dh_{t-1} over ALL H columns -- and the members reduce-scatter those partials through a double-buffered exchange buffer:
+// write-through stores + flag, then every member sums the S partials of its own 32 columns in member order and adds the
+// u-gated carry.  Same descriptor table / dG / dbias / dh0 contract as vame_gru_seq_bwd_f32; results equal up to the
+// summation order of that K = 3H contraction (split by member here).
+template <int H>
+__global__ __launch_bounds__(256) void gru_coop_bwd_kernel(GruBwdParams P, float* __restrict__ xbuf, int* __restrict__ flags, int base,
+                                                           int* __restrict__ status) {
+    constexpr int NM = H / 32, LDG = 132, LDP = H + 4, LDC = 36, TPW = NM / 4;      // TPW: 32-column output tiles per wave
+    static_assert(NM == 8 || NM == 4, "written for H = 128 / 256");
+    VAME_DYN_SMEM(smem_raw);
+    f32x4* wl = reinterpret_cast<f32x4*>(smem_raw);                     // [NM col tiles][12 chunks][64] B fragments
+    float* gs = reinterpret_cast<float*>(wl + NM * 12 * 64);           // [32][LDG]  da_r | da_z | dgh_n | dgi_n of this member's columns
+    float* ps = gs + 32 * LDG;                                          // [32][LDP]  partial dh_{t-1} over all H columns
+    float* cd = ps + 32 * LDP;                                          // [32][LDC]  dh_t slice in, u-gated carry / reduced dh_{t-1} out
+    int g, m;
+    if (!coop_map<NM>(P.nstreams * P.ntiles, g, m)) return;
+    const int sidx = g % P.nstreams, tile = g / P.nstreams;
+    const GruBwdStream& S = P.s[sidx];
+    const int B = P.B, T = (int)S.T;
+    const int tid = threadIdx.x, lane = tid & 63, li = lane & 31, hh = lane >> 5;
+    const int w = UNIFORM(tid >> 6);
+    const int row0 = tile * 32, col0 = 32 * m, lrow = 4 * hh;
+    const int nvalid = B - row0;
+    const int prow = tid >> 3, pc4 = tid & 7;
+    int* gflags = flags + (int64_t)g * NM;
+
+    {   // W_hh rows {gate*H + C_m} x all columns, from the backward pack: wp_bwd[((ct*(3H/8) + c)*64 + l)*4 + e]
+        const f32x4* src = reinterpret_cast<const f32x4*>(S.wpt);
+        for (int i = tid; i < NM * 12 * 64; i += 256) {
+            const int ct = i / (12 * 64), rem = i % (12 * 64), gg = rem / 256, c64 = rem % 256;
+            wl[i] = src[((int64_t)ct * (3 * H / 8) + (gg * H + 32 * m) / 8) * 64 + c64];
+        }
+    }
+    {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (S.dhn && prow < nvalid) {
+            const float* p = S.dhn + (int64_t)(row0 + prow) * S.dhn_row + col0 + 4 * pc4;
+            v = make_float4(p[0], p[1], p[2], p[3]);
+        }
+        *reinterpret_cast<float4*>(&cd[prow * LDC + 4 * pc4]) = v;
+    }
+    const float4* stash = reinterpret_cast<const float4*>(S.stash);
+    float4 sa, sb, su, sr, sg;
+    float dyv[4];
+    auto load_step = [&](int step) {
+        const int fstep = T - 1 - step;
+        const int t = S.reverse ? T - 1 - fstep : fstep;
+        const float4* sp = stash + ((((int64_t)tile * T + t) * NM + m) * 20 + w) * 64 + lane;       // rq = w: rows CR(4w..4w+3)
+        sa = sp[0 * 4 * 64]; sb = sp[1 * 4 * 64]; su = sp[2 * 4 * 64]; sr = sp[3 * 4 * 64]; sg = sp[4 * 4 * 64];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int row = CR(4 * w + j) + lrow;
+            dyv[j] = (S.dy && row < nvalid) ? S.dy[(int64_t)(row0 + row) * S.dy_row + (int64_t)t * S.dy_t + col0 + li] : 0.f;
+        }
+    };
+    load_step(0);
+    float dbs0 = 0.f, dbs1 = 0.f, dbs2 = 0.f, dbs3 = 0.f;
+    __syncthreads();
+
+    for (int step = 0; step < T; ++step) {
+        const int fstep = T - 1 - step;
+        const int t = S.reverse ? T - 1 - fstep : fstep;
+        {
+            const float av[4] = {sa.x, sa.y, sa.z, sa.w}, bv[4] = {sb.x, sb.y, sb.z, sb.w}, uv[4] = {su.x, su.y, su.z, su.w},
+                        rv[4] = {sr.x, sr.y, sr.z, sr.w}, gv[4] = {sg.x, sg.y, sg.z, sg.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int row = CR(4 * w + j) + lrow;
+                const float d = cd[row * LDC + li] + dyv[j];
+                const float dan = d * av[j];
+                const float dau = d * bv[j];
+                const float dgh = dan * rv[j];
+                const float dar = dgh * gv[j] * (1.0f - rv[j]);
+                cd[row * LDC + li] = d * uv[j];                      // dh carried through the update gate
+                float* gw = &gs[row * LDG + li];
+                gw[0] = dar; gw[32] = dau; gw[64] = dgh; gw[96] = dan;
+                dbs0 += dar; dbs1 += dau; dbs2 += dan; dbs3 += dgh;
+            }
+        }
+        __syncthreads();
+        if (prow < nvalid) {    // dG[b][t][da_r | da_z | dgi_n | dgh_n] columns C_m: LDS blocks (r, z, gh_n, gi_n) -> global (r, z, gi_n, gh_n)
+            float* dgt = S.dg + ((int64_t)(row0 + prow) * T + t) * 4 * H + col0 + 4 * pc4;
+            const float* src = &gs[prow * LDG + 4 * pc4];
+            *reinterpret_cast<float4*>(dgt) = *reinterpret_cast<const float4*>(src);
+            *reinterpret_cast<float4*>(dgt + H) = *reinterpret_cast<const float4*>(src + 32);
+            *reinterpret_cast<float4*>(dgt + 3 * H) = *reinterpret_cast<const float4*>(src + 64);
+            *reinterpret_cast<float4*>(dgt + 2 * H) = *reinterpret_cast<const float4*>(src + 96);
+        }
+        if (step + 1 < T) load_step(step + 1);
+        {
+            f32x16 acc[TPW];
+#pragma unroll
+            for (int i = 0; i < TPW; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+            const float* arow = &gs[li * LDG + 4 * hh];
+#pragma unroll 4
+            for (int c = 0; c < 12; ++c) {
+                const float4 a = *reinterpret_cast<const float4*>(arow + 8 * c);
+#pragma unroll
+                for (int i = 0; i < TPW; ++i) {
+                    const f32x4 b = wl[((w * TPW + i) * 12 + c) * 64 + lane];
+                    acc[i] = MFMA_32x32x2(a.x, b[0], acc[i]); acc[i] = MFMA_32x32x2(a.y, b[1], acc[i]);
+                    acc[i] = MFMA_32x32x2(a.z, b[2], acc[i]); acc[i] = MFMA_32x32x2(a.w, b[3], acc[i]);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < TPW; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) ps[(CR(r) + lrow) * LDP + (w * TPW + i) * 32 + li] = acc[i][r];
+        }
+        __syncthreads();
+        // ---- publish the 32 x H partial (write-through), raise the flag, wait for everybody, sum this member's columns
+        float* xs = xbuf + ((int64_t)(g * 2 + (step & 1)) * NM) * 32 * H;
+        {
+            constexpr int PER = 32 * (H / 4) / 256;
+#pragma unroll
+            for (int i = 0; i < PER; ++i) {
+                const int idx = tid + i * 256, r = idx / (H / 4), c4 = idx % (H / 4);
+                const f32x4 v = *reinterpret_cast<const f32x4*>(&ps[r * LDP + 4 * c4]);
+                COOP_STORE16(xs + ((int64_t)m * 32 + r) * H + 4 * c4, v);
+            }
+        }
+        COOP_DRAIN();
+        __syncthreads();
+        if (tid == 0) COOP_FLAG_STORE(&gflags[m], base + step + 1);
+        if (tid < NM) {
+            int polls = 0;
+            while (COOP_FLAG_LOAD(&gflags[tid]) - (base + step + 1) < 0) {
+                COOP_BACKOFF();
+                if (++polls > COOP_MAX_POLLS) { atomicAdd(status, 1); break; }
+            }
+        }
+        __syncthreads();
+        {
+            f32x4 v[8];
+#pragma unroll
+            for (int mm = 0; mm < 8; ++mm) {
+                if (mm < NM) COOP_LOAD16(v[mm], xs + ((int64_t)mm * 32 + prow) * H + col0 + 4 * pc4); else v[mm] = v[0];
+            }
+            COOP_WAIT_LOADS8(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]);
+            f32x4 s = *reinterpret_cast<const f32x4*>(&cd[prow * LDC + 4 * pc4]);
+#pragma unroll
+            for (int mm = 0; mm < NM; ++mm) s += v[mm];
+            *reinterpret_cast<f32x4*>(&cd[prow * LDC + 4 * pc4]) = s;
+        }
+        __syncthreads();
+    }
+    if (S.dh0 && prow < nvalid) {
+        float* o = S.dh0 + (int64_t)(row0 + prow) * S.dh0_row + col0 + 4 * pc4;
+        const float* c = &cd[prow * LDC + 4 * pc4];
+        o[0] = c[0]; o[1] = c[1]; o[2] = c[2]; o[3] = c[3];
+    }
+    if (S.dbias) {      // per-column sums over the tile's rows and all steps: 2 half-waves x 4 waves of partials per column
+        float* red = ps;                                                 // [8][4][32]
+        const int slot = w * 2 + hh;
+        red[(slot * 4 + 0) * 32 + li] = dbs0; red[(slot * 4 + 1) * 32 + li] = dbs1;
+        red[(slot * 4 + 2) * 32 + li] = dbs2; red[(slot * 4 + 3) * 32 + li] = dbs3;
+        __syncthreads();
+        if (tid < 128) {
+            const int k = tid >> 5, c = tid & 31;
+            float s = 0.f;
+#pragma unroll
+            for (int sl = 0; sl < 8; ++sl) s += red[(sl * 4 + k) * 32 + c];
+            S.dbias[(int64_t)tile * 4 * H + k * H + col0 + c] = s;
+        }
+    }
+}
+
+template <int H>
+static size_t coop_bwd_lds() {
+    constexpr int NM = H / 32;
+    return (size_t)NM * 12 * 64 * 16 + (size_t)(32 * 132 + 32 * (H + 4) + 32 * 36) * 4;
+}
+
+extern "C" int64_t vame_gru_coop_xbuf_floats(int nstreams, int B, int H) { return (int64_t)nstreams * cdiv64(B, 32) * 2 * 32 * H * (H / 32); }
+
+extern "C" int vame_gru_coop_bwd_f32(const int64_t* desc, int nstreams, int B, int H, float* xbuf, int* flags, int epoch_base,
+                                     int* status, void* stream) {
+    VAME_CHECK_ARG(desc && xbuf && flags && status && nstreams >= 1 && nstreams <= 8 && B >= 1, VAME_E_BADARG, "gru_coop_bwd: bad arguments");
+    VAME_CHECK_ARG(vame_gru_coop_supported(nstreams, B, H), VAME_E_UNSUPPORTED,
+                   "gru_coop_bwd: nstreams=%d B=%d H=%d does not fit one workgroup per CU (or H not 128/256)", nstreams, B, H);
+    VAME_CHECK_ARG((uintptr_t)xbuf % 16 == 0, VAME_E_SHAPE, "gru_coop_bwd: exchange buffer must be 16-byte aligned");
+    GruBwdParams P;
+    if (int rc = gru_parse_bwd(desc, nstreams, B, P)) return rc;
+    for (int i = 0; i < nstreams; ++i)
+        VAME_CHECK_ARG((uintptr_t)P.s[i].dg % 16 == 0, VAME_E_SHAPE, "gru_coop_bwd: stream %d: dG must be 16-byte aligned", i);
+    hipStream_t st = (hipStream_t)stream;
+    const int ngroups = nstreams * P.ntiles;
+#ifdef VAME_EMU
+    emu::g_coop = true;
+#endif
+    if (H == 256) {
+        COOP_ALLOW_LDS(gru_coop_bwd_kernel<256>, coop_bwd_lds<256>());
+        hipLaunchKernelGGL((gru_coop_bwd_kernel<256>), dim3(coop_grid<8>(ngroups)), dim3(256), coop_bwd_lds<256>(), st, P, xbuf, flags, epoch_base, status);
+    } else {
+        COOP_ALLOW_LDS(gru_coop_bwd_kernel<128>, coop_bwd_lds<128>());
+        hipLaunchKernelGGL((gru_coop_bwd_kernel<128>), dim3(coop_grid<4>(ngroups)), dim3(256), coop_bwd_lds<128>(), st, P, xbuf, flags, epoch_base, status);
+    }
+#ifdef VAME_EMU
+    emu::g_coop = false;
+#endif
+    VAME_LAUNCH_CHECK("gru_coop_bwd");
+    return VAME_OK;
+}

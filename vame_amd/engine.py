@@ -105,6 +105,8 @@ class VAEEngine:
         self.fut = ([GruDir("decoder_future.rnn_pred", "_l0", H, Z, self.dev),
                      GruDir("decoder_future.rnn_pred", "_l0_reverse", H, Z, self.dev)] if spec.future else [])
         self.ws = Workspace()
+        self.coop = True              # column-split GRU kernels for batches that leave most CUs idle (see _coop_ok)
+        self._coop_state = None
         self._nuc_state = None
         self.packed_version = -1
         self.version = 0          # bumped by the owner whenever flat_p changes
@@ -158,14 +160,26 @@ class VAEEngine:
                  a_gap_at=gap_at, a_gap=gap)
 
     # ------------------------------------------------------------------ GRU sequence dispatch
+    def _coop_ok(self, nstreams, B):
+        """Small batches: the column-split kernels (gru_coop.hip) when the whole grid fits one workgroup per CU."""
+        return (not self.stepwise) and self.coop and ops.gru_coop_supported(nstreams, B, self.spec.H)
+
     def _gru_fwd(self, rows, B):
         if not self.stepwise:
+            if self._coop_ok(len(rows), B) and all(r[GF["Y"]] and not r.get(GF["WPX"]) for r in rows):
+                if self._coop_state is None:
+                    self._coop_state = ops.CoopState(self.dev)
+                return ops.gru_coop_fwd(rows, B, self.spec.H, self._coop_state)
             return ops.gru_seq_fwd(rows, B, self.spec.H)
         for r in rows:
             self._stepwise_fwd(r["_s"], B)
 
     def _gru_bwd(self, rows, B):
         if not self.stepwise:
+            if self._coop_ok(len(rows), B):
+                if self._coop_state is None:
+                    self._coop_state = ops.CoopState(self.dev)
+                return ops.gru_coop_bwd(rows, B, self.spec.H, self._coop_state)
             return ops.gru_seq_bwd(rows, B, self.spec.H)
         for r in rows:
             self._stepwise_bwd(r["_s"], B)
@@ -240,7 +254,8 @@ class VAEEngine:
         hn = self.buf("hn", B, 4 * H)
         rows = []
         # layer 0: F <= 32 features -> the input projection runs inside the sequence kernel on the window tile itself
-        fused = (not self.stepwise) and self.enc[0][0].wp_x is not None and win_row % 4 == 0 and win.data_ptr() % 16 == 0
+        coop = self._coop_ok(2, B)
+        fused = (not self.stepwise) and (not coop) and self.enc[0][0].wp_x is not None and win_row % 4 == 0 and win.data_ptr() % 16 == 0
         for dirn, d in enumerate(self.enc[0]):
             st = self.buf(f"st_e0_{dirn}", ops.gru_stash_floats(B, T, H)) if training else None
             if fused:
@@ -253,14 +268,14 @@ class VAEEngine:
             rows.append(row)
         self._gru_fwd(rows, B)
         y_op = Operand(Y0, 2 * H, off=2 * H, seg=T, seg_stride=(T + 2) * 2 * H)
-        Y1 = self.buf("Y1", B, T + 2, 2 * H) if training else None
+        Y1 = self.buf("Y1", B, T + 2, 2 * H) if (training or coop) else None
         rows = []
         for dirn, d in enumerate(self.enc[1]):
             gi = self.buf(f"gi_e1_{dirn}", B, T, 3 * H)
             ops.gemm(B * T, 3 * H, 2 * H, y_op, 0, self.P(d.w_ih, 2 * H), 0, gi, 3 * H, bias=d.bias_gi)
             st = self.buf(f"st_e1_{dirn}", ops.gru_stash_floats(B, T, H)) if training else None
             rows.append(self._gru_fwd_stream(d, gi, T * 3 * H, 3 * H, None, 0, Y1, 2 * H, T, dirn, hn, (2 + dirn) * H, 4 * H, st, T,
-                                             write_y=training))
+                                             write_y=training or coop))
         self._gru_fwd(rows, B)
         return hn
 

@@ -130,6 +130,17 @@ def gru_coop_fwd(streams, B, H, state: CoopState):
     _lib.check(rc, "vame_gru_coop_fwd_f32")
 
 
+def gru_coop_bwd(streams, B, H, state: CoopState):
+    d = _desc_tensor(streams, GB["N"])
+    need = _lib.lib().vame_gru_coop_xbuf_floats(len(streams), B, H)
+    if getattr(state, "xbuf", None) is None or state.xbuf.numel() < need:
+        state.xbuf = torch.empty(need, device=state.flags.device)
+    T = max(int(s[GB["T"]]) for s in streams)
+    rc = _lib.lib().vame_gru_coop_bwd_f32(d.data_ptr(), len(streams), B, H, _ptr(state.xbuf), _ptr(state.flags), state.next_base(T),
+                                          _ptr(state.status), _stream())
+    _lib.check(rc, "vame_gru_coop_bwd_f32")
+
+
 def gru_seq_bwd(streams, B, H):
     d = _desc_tensor(streams, GB["N"])
     rc = _lib.lib().vame_gru_seq_bwd_f32(d.data_ptr(), len(streams), B, H, _stream())
