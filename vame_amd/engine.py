@@ -164,22 +164,37 @@ class VAEEngine:
         """Small batches: the column-split kernels (gru_coop.hip) when the whole grid fits one workgroup per CU."""
         return (not self.stepwise) and self.coop and ops.gru_coop_supported(nstreams, B, self.spec.H)
 
+    def _coop_parts(self, rows, B):
+        """Split a launch into cooperative launches that each fit the chip ([] = use the persistent kernels)."""
+        if self._coop_ok(len(rows), B):
+            parts = [rows]
+        elif len(rows) > 2 and len(rows) % 2 == 0 and self._coop_ok(2, B):
+            parts = [rows[i:i + 2] for i in range(0, len(rows), 2)]      # decoder + future decoder: one pair of directions each
+        else:
+            return []
+        if self._coop_state is None:
+            self._coop_state = ops.CoopState(self.dev)
+        return parts
+
     def _gru_fwd(self, rows, B):
         if not self.stepwise:
-            if self._coop_ok(len(rows), B) and all(r[GF["Y"]] and not r.get(GF["WPX"]) for r in rows):
-                if self._coop_state is None:
-                    self._coop_state = ops.CoopState(self.dev)
-                return ops.gru_coop_fwd(rows, B, self.spec.H, self._coop_state)
+            if all(r[GF["Y"]] and not r.get(GF["WPX"]) for r in rows):
+                for part in self._coop_parts(rows, B):
+                    ops.gru_coop_fwd(part, B, self.spec.H, self._coop_state)
+                    rows = None
+                if rows is None:
+                    return
             return ops.gru_seq_fwd(rows, B, self.spec.H)
         for r in rows:
             self._stepwise_fwd(r["_s"], B)
 
     def _gru_bwd(self, rows, B):
         if not self.stepwise:
-            if self._coop_ok(len(rows), B):
-                if self._coop_state is None:
-                    self._coop_state = ops.CoopState(self.dev)
-                return ops.gru_coop_bwd(rows, B, self.spec.H, self._coop_state)
+            parts = self._coop_parts(rows, B)
+            for part in parts:
+                ops.gru_coop_bwd(part, B, self.spec.H, self._coop_state)
+            if parts:
+                return
             return ops.gru_seq_bwd(rows, B, self.spec.H)
         for r in rows:
             self._stepwise_bwd(r["_s"], B)
