@@ -37,7 +37,8 @@
 #define COOP_BACKOFF() __builtin_amdgcn_s_sleep(2)
 #endif
 
-constexpr int COOP_MAX_POLLS = 1 << 22;       // ~ seconds: a stuck group reports instead of hanging the queue
+constexpr int COOP_MAX_POLLS = 1 << 18;       // ~0.3 s: a stuck group reports instead of hanging the queue; once *status != 0 every
+                                              // later wait of the launch gives up at once (results undefined, the launch ends)
 
 // block -> (group, member).  Workgroup b runs on XCD b % 8 (observed; speed only): all members of a group share b % 8.
 template <int NM>
@@ -162,7 +163,7 @@ __global__ __launch_bounds__(256) void gru_coop_fwd_kernel(GruFwdParams P, int* 
         if (tid == 0) COOP_FLAG_STORE(&gflags[m], base + step + 1);
         // ---- wait for all members' slices of h_t, then rebuild the full 32 x H tile in LDS
         if (tid < NM) {
-            int polls = 0;
+            int polls = COOP_FLAG_LOAD(status) != 0 ? COOP_MAX_POLLS : 0;
             while (COOP_FLAG_LOAD(&gflags[tid]) - (base + step + 1) < 0) {
                 COOP_BACKOFF();
                 if (++polls > COOP_MAX_POLLS) { atomicAdd(status, 1); break; }
@@ -384,7 +385,7 @@ __global__ __launch_bounds__(256) void gru_coop_bwd_kernel(GruBwdParams P, float
         __syncthreads();
         if (tid == 0) COOP_FLAG_STORE(&gflags[m], base + step + 1);
         if (tid < NM) {
-            int polls = 0;
+            int polls = COOP_FLAG_LOAD(status) != 0 ? COOP_MAX_POLLS : 0;
             while (COOP_FLAG_LOAD(&gflags[tid]) - (base + step + 1) < 0) {
                 COOP_BACKOFF();
                 if (++polls > COOP_MAX_POLLS) { atomicAdd(status, 1); break; }

@@ -164,6 +164,11 @@ class VAEEngine:
         """Small batches: the column-split kernels (gru_coop.hip) when the whole grid fits one workgroup per CU."""
         return (not self.stepwise) and self.coop and ops.gru_coop_supported(nstreams, B, self.spec.H)
 
+    def check_async_errors(self):
+        """Called where the host synchronises anyway (once per epoch): surfaces device-side failures that cannot raise."""
+        if self._coop_state is not None:
+            self._coop_state.check()
+
     def _coop_parts(self, rows, B):
         """Split a launch into cooperative launches that each fit the chip ([] = use the persistent kernels)."""
         if self._coop_ok(len(rows), B):

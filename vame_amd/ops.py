@@ -114,6 +114,14 @@ class CoopState:
         self.epoch = (self.epoch + T + 2) & 0x3fffffff
         return b
 
+    def check(self):
+        """Host sync: raise if a cooperative launch ever gave up waiting for a group member (its results were undefined)."""
+        n = int(self.status.item())
+        if n:
+            self.status.zero_()
+            raise _lib.VameHipError(f"cooperative GRU kernel: {n} hand-off wait(s) timed out (workgroups of a group were not co-resident); "
+                                    "set engine.coop = False to use the batch-tile-persistent kernels")
+
 
 def gru_coop_supported(nstreams, B, H):
     return bool(_lib.lib().vame_gru_coop_supported(nstreams, B, H))
