@@ -109,6 +109,8 @@ def check_gru_coop_fwd(dev, H, B, T, launches=2):
     reuse the flag words (epoch logic), and it agrees with the oracle."""
     assert ops.gru_coop_supported(2, B, H) and not ops.gru_coop_supported(2, 8192, H)
     state = ops.CoopState(torch.device(dev))
+    state.epoch = (1 << 32) - T - 3                       # the second launch crosses the 2^32 wrap of the flag epoch
+    state.flags.fill_(-T - 4)                             # ... as left behind by a launch just before it
     x, st0, Y0, hN0 = run_gru_fwd(dev, H, B, T)
     for it in range(launches):
         x, st, Y, hN = run_gru_fwd(dev, H, B, T, coop=state)

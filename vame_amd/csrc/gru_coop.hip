@@ -160,11 +160,11 @@ __global__ __launch_bounds__(256) void gru_coop_fwd_kernel(GruFwdParams P, int* 
         COOP_DRAIN();
         __syncthreads();
         if (step + 1 == T) break;
-        if (tid == 0) COOP_FLAG_STORE(&gflags[m], base + step + 1);
+        if (tid == 0) COOP_FLAG_STORE(&gflags[m], (int)((unsigned)base + (unsigned)step + 1u));
         // ---- wait for all members' slices of h_t, then rebuild the full 32 x H tile in LDS
         if (tid < NM) {
             int polls = COOP_FLAG_LOAD(status) != 0 ? COOP_MAX_POLLS : 0;
-            while (COOP_FLAG_LOAD(&gflags[tid]) - (base + step + 1) < 0) {
+            while ((int)((unsigned)COOP_FLAG_LOAD(&gflags[tid]) - ((unsigned)base + (unsigned)step + 1u)) < 0) {   // wrap-safe
                 COOP_BACKOFF();
                 if (++polls > COOP_MAX_POLLS) { atomicAdd(status, 1); break; }
             }
@@ -383,10 +383,10 @@ __global__ __launch_bounds__(256) void gru_coop_bwd_kernel(GruBwdParams P, float
         }
         COOP_DRAIN();
         __syncthreads();
-        if (tid == 0) COOP_FLAG_STORE(&gflags[m], base + step + 1);
+        if (tid == 0) COOP_FLAG_STORE(&gflags[m], (int)((unsigned)base + (unsigned)step + 1u));
         if (tid < NM) {
             int polls = COOP_FLAG_LOAD(status) != 0 ? COOP_MAX_POLLS : 0;
-            while (COOP_FLAG_LOAD(&gflags[tid]) - (base + step + 1) < 0) {
+            while ((int)((unsigned)COOP_FLAG_LOAD(&gflags[tid]) - ((unsigned)base + (unsigned)step + 1u)) < 0) {   // wrap-safe
                 COOP_BACKOFF();
                 if (++polls > COOP_MAX_POLLS) { atomicAdd(status, 1); break; }
             }

@@ -110,9 +110,9 @@ class CoopState:
         self.epoch = 1
 
     def next_base(self, T):
-        b = self.epoch
-        self.epoch = (self.epoch + T + 2) & 0x3fffffff
-        return b
+        b = self.epoch                                       # compared modulo 2^32 on the device (signed difference)
+        self.epoch = (self.epoch + T + 2) & 0xffffffff
+        return b - (1 << 32) if b >= (1 << 31) else b
 
     def check(self):
         """Host sync: raise if a cooperative launch ever gave up waiting for a group member (its results were undefined)."""
