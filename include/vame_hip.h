@@ -161,12 +161,13 @@ int vame_axpy_f32(const float* x, float a, float* y, int64_t n, void* stream);
  * bounded poll ever expires (results are then undefined, the launch still terminates). */
 int64_t vame_gru_coop_flag_ints(int nstreams, int B, int H);
 int vame_gru_coop_supported(int nstreams, int B, int H);
-int vame_gru_coop_fwd_f32(const int64_t* desc, int nstreams, int B, int H, int* flags, int epoch_base, int* status, void* stream);
+int vame_gru_coop_fwd_f32(const int64_t* desc, int nstreams, int B, int H, int row0, int nrows, int* flags, int epoch_base, int* status,
+                          void* stream);   /* rows [row0, row0+nrows) of the batch, row0 % 32 == 0; nrows = 0: all rows */
 /* BPTT counterpart (contract of vame_gru_seq_bwd_f32; results equal up to the summation order of the K = 3H contraction, which is
  * split by member): xbuf = vame_gru_coop_xbuf_floats() floats of scratch for the per-step reduce-scatter of the dh partials. */
 int64_t vame_gru_coop_xbuf_floats(int nstreams, int B, int H);
-int vame_gru_coop_bwd_f32(const int64_t* desc, int nstreams, int B, int H, float* xbuf, int* flags, int epoch_base, int* status,
-                          void* stream);
+int vame_gru_coop_bwd_f32(const int64_t* desc, int nstreams, int B, int H, int row0, int nrows, float* xbuf, int* flags, int epoch_base,
+                          int* status, void* stream);
 
 /* ---- training-set preparation: the O(N*F) float64 passes of vame/model/create_training.py.
  * Arrays are (F, N) feature-major with a leading dimension (elements), like <file>-PE-seq.npy; results are bit-identical to

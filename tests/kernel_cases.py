@@ -74,7 +74,7 @@ def _pack(dev, W_hh, b_ih, b_hh, H):
     return wpf, wpb, bgi, bhn
 
 
-def run_gru_fwd(dev, H, B, T, seed=0, coop=None):
+def run_gru_fwd(dev, H, B, T, seed=0, coop=None, coop_chunks=None):
     """Two streams (forward + reverse dir, with h0) in one launch; returns everything needed for bwd.
     coop: an ops.CoopState -> the column-split small-batch kernel instead of the batch-tile-persistent one."""
     rng = np.random.default_rng(seed)
@@ -98,7 +98,8 @@ def run_gru_fwd(dev, H, B, T, seed=0, coop=None):
                      GF["REVERSE"]: d, GF["PAD"]: 1})
         st.append(dict(W_ih=W_ih, W_hh=W_hh, b_ih=b_ih, b_hh=b_hh, h0=h0, wpb=wpb, stash=stash, keep=(gi, wpf, bhn, h0t)))
     if coop is not None:
-        ops.gru_coop_fwd(rows, B, H, coop)
+        for chunk in (coop_chunks or [(0, 0)]):
+            ops.gru_coop_fwd(rows, B, H, coop, rows=chunk)
     else:
         ops.gru_seq_fwd(rows, B, H)
     return x, st, Y, hN
@@ -112,8 +113,9 @@ def check_gru_coop_fwd(dev, H, B, T, launches=2):
     state.epoch = (1 << 32) - T - 3                       # the second launch crosses the 2^32 wrap of the flag epoch
     state.flags.fill_(-T - 4)                             # ... as left behind by a launch just before it
     x, st0, Y0, hN0 = run_gru_fwd(dev, H, B, T)
+    chunks = [None, [(0, 32), (32, B - 32)]] if B > 32 else [None]       # whole batch, then two row-range launches
     for it in range(launches):
-        x, st, Y, hN = run_gru_fwd(dev, H, B, T, coop=state)
+        x, st, Y, hN = run_gru_fwd(dev, H, B, T, coop=state, coop_chunks=chunks[it % len(chunks)])
         np.testing.assert_array_equal(N_(Y), N_(Y0))
         np.testing.assert_array_equal(N_(hN), N_(hN0))
         # stash entries of rows past the batch (last tile) are don't-cares of both kernels: compare the valid rows
@@ -171,7 +173,7 @@ def check_gru_fwd_fused(dev, H, B, T, I=24):
         np.testing.assert_allclose(hNn[:, d * H:(d + 1) * H], hn, atol=2e-5)
 
 
-def _run_gru_bwd(dev, H, B, T, st, Y, dYt, dhNt, coop=None):
+def _run_gru_bwd(dev, H, B, T, st, Y, dYt, dhNt, coop=None, coop_chunks=None):
     ntiles = (B + 31) // 32
     rows, outs = [], []
     for d, s in enumerate(st):
@@ -186,7 +188,8 @@ def _run_gru_bwd(dev, H, B, T, st, Y, dYt, dhNt, coop=None):
                      GB["T"]: T, GB["REVERSE"]: d, GB["PAD"]: 1})
         outs.append((dG, dh0, dbias, dgsum))
     if coop is not None:
-        ops.gru_coop_bwd(rows, B, H, coop)
+        for chunk in (coop_chunks or [(0, 0)]):
+            ops.gru_coop_bwd(rows, B, H, coop, rows=chunk)
     else:
         ops.gru_seq_bwd(rows, B, H)
     return outs
@@ -201,8 +204,9 @@ def check_gru_coop_bwd(dev, H, B, T, launches=2):
     dhNt = T_(rng.standard_normal((B, 2 * H)).astype(np.float32), dev)
     ref = _run_gru_bwd(dev, H, B, T, st, Y, dYt, dhNt)
     state = ops.CoopState(torch.device(dev))
+    chunks = [None, [(0, 32), (32, B - 32)]] if B > 32 else [None]
     for it in range(launches):
-        got = _run_gru_bwd(dev, H, B, T, st, Y, dYt, dhNt, coop=state)
+        got = _run_gru_bwd(dev, H, B, T, st, Y, dYt, dhNt, coop=state, coop_chunks=chunks[it % len(chunks)])
         for (dG, dh0, dbias, _), (dGr, dh0r, dbiasr, _) in zip(got, ref):
             np.testing.assert_allclose(N_(dG), N_(dGr), atol=2e-5 * max(1.0, float(np.abs(N_(dGr)).max())))
             np.testing.assert_allclose(N_(dh0), N_(dh0r), atol=2e-5 * max(1.0, float(np.abs(N_(dh0r)).max())))

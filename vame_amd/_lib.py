@@ -50,9 +50,9 @@ _SIGS = {
     "vame_axpy_f32": (c_int, [c_void_p, c_float, c_void_p, c_int64, c_void_p]),
     "vame_gru_coop_flag_ints": (c_int64, [c_int, c_int, c_int]),
     "vame_gru_coop_supported": (c_int, [c_int, c_int, c_int]),
-    "vame_gru_coop_fwd_f32": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p]),
+    "vame_gru_coop_fwd_f32": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p]),
     "vame_gru_coop_xbuf_floats": (c_int64, [c_int, c_int, c_int]),
-    "vame_gru_coop_bwd_f32": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
+    "vame_gru_coop_bwd_f32": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
     "vame_prep_zscore_mask_f64": (c_int, [c_void_p, c_int, c_int64, c_int64, c_double, c_double, c_double, c_int, c_void_p, c_int64, c_void_p]),
     "vame_prep_ws_bytes": (c_int64, [c_int]),
     "vame_prep_fill_last_valid_f64": (c_int, [c_void_p, c_int, c_int64, c_int64, c_void_p, c_void_p, c_void_p]),

@@ -61,7 +61,7 @@ __global__ __launch_bounds__(256) void gru_coop_fwd_kernel(GruFwdParams P, int* 
     float* hx = ex + 2 * 32 * LDE;                                         // [32][LDX] this member's h_t slice, row-major
     int g, m;
     if (!coop_map<NM>(P.nstreams * P.ntiles, g, m)) return;
-    const int sidx = g % P.nstreams, tile = g / P.nstreams;
+    const int sidx = g % P.nstreams, tile = g / P.nstreams + P.tile_off;
     const GruFwdStream& S = P.s[sidx];
     const int B = P.B, T = (int)S.T;
     const int tid = threadIdx.x, lane = tid & 63, li = lane & 31, hh = lane >> 5;
@@ -221,14 +221,25 @@ extern "C" int vame_gru_coop_supported(int nstreams, int B, int H) {
     const int64_t groups = (int64_t)nstreams * cdiv64(B, 32);
     return cdiv64(groups, 8) * 8 * (H / 32) <= 256;
 }
+// rows [row0, row0 + nrows) of the batch (row0 a multiple of 32; nrows = 0: all of it)
+static int coop_row_range(int B, int row0, int nrows, int& tile_off, int& ntiles) {
+    if (nrows <= 0) { row0 = 0; nrows = B; }
+    if (row0 < 0 || row0 % 32 || row0 + nrows > B) return 0;
+    tile_off = row0 / 32;
+    ntiles = (int)cdiv64(nrows, 32);
+    return 1;
+}
 
-extern "C" int vame_gru_coop_fwd_f32(const int64_t* desc, int nstreams, int B, int H, int* flags, int epoch_base, int* status,
-                                     void* stream) {
+extern "C" int vame_gru_coop_fwd_f32(const int64_t* desc, int nstreams, int B, int H, int row0, int nrows, int* flags, int epoch_base,
+                                     int* status, void* stream) {
     VAME_CHECK_ARG(desc && flags && status && nstreams >= 1 && nstreams <= 8 && B >= 1, VAME_E_BADARG, "gru_coop_fwd: bad arguments");
-    VAME_CHECK_ARG(vame_gru_coop_supported(nstreams, B, H), VAME_E_UNSUPPORTED,
-                   "gru_coop_fwd: nstreams=%d B=%d H=%d does not fit one workgroup per CU (or H not 128/256)", nstreams, B, H);
+    int tile_off, ntiles;
+    VAME_CHECK_ARG(coop_row_range(B, row0, nrows, tile_off, ntiles), VAME_E_SHAPE, "gru_coop_fwd: bad row range %d+%d of %d", row0, nrows, B);
+    VAME_CHECK_ARG(vame_gru_coop_supported(nstreams, ntiles * 32, H), VAME_E_UNSUPPORTED,
+                   "gru_coop_fwd: nstreams=%d rows=%d H=%d does not fit one workgroup per CU (or H not 128/256)", nstreams, ntiles * 32, H);
     GruFwdParams P;
     if (int rc = gru_parse_fwd(desc, nstreams, B, P)) return rc;
+    P.ntiles = ntiles; P.tile_off = tile_off;
     for (int i = 0; i < nstreams; ++i) {
         VAME_CHECK_ARG(P.s[i].xf == 0 && P.s[i].y, VAME_E_UNSUPPORTED, "gru_coop_fwd: stream %d needs a precomputed gi and an output sequence", i);
         VAME_CHECK_ARG((uintptr_t)P.s[i].y % 16 == 0 && P.s[i].y_row % 4 == 0 && P.s[i].y_t % 4 == 0 &&
@@ -274,7 +285,7 @@ __global__ __launch_bounds__(256) void gru_coop_bwd_kernel(GruBwdParams P, float
     float* cd = ps + 32 * LDP;                                          // [32][LDC]  dh_t slice in, u-gated carry / reduced dh_{t-1} out
     int g, m;
     if (!coop_map<NM>(P.nstreams * P.ntiles, g, m)) return;
-    const int sidx = g % P.nstreams, tile = g / P.nstreams;
+    const int sidx = g % P.nstreams, tile = g / P.nstreams + P.tile_off;
     const GruBwdStream& S = P.s[sidx];
     const int B = P.B, T = (int)S.T;
     const int tid = threadIdx.x, lane = tid & 63, li = lane & 31, hh = lane >> 5;
@@ -435,14 +446,17 @@ static size_t coop_bwd_lds() {
 
 extern "C" int64_t vame_gru_coop_xbuf_floats(int nstreams, int B, int H) { return (int64_t)nstreams * cdiv64(B, 32) * 2 * 32 * H * (H / 32); }
 
-extern "C" int vame_gru_coop_bwd_f32(const int64_t* desc, int nstreams, int B, int H, float* xbuf, int* flags, int epoch_base,
-                                     int* status, void* stream) {
+extern "C" int vame_gru_coop_bwd_f32(const int64_t* desc, int nstreams, int B, int H, int row0, int nrows, float* xbuf, int* flags,
+                                     int epoch_base, int* status, void* stream) {
     VAME_CHECK_ARG(desc && xbuf && flags && status && nstreams >= 1 && nstreams <= 8 && B >= 1, VAME_E_BADARG, "gru_coop_bwd: bad arguments");
-    VAME_CHECK_ARG(vame_gru_coop_supported(nstreams, B, H), VAME_E_UNSUPPORTED,
-                   "gru_coop_bwd: nstreams=%d B=%d H=%d does not fit one workgroup per CU (or H not 128/256)", nstreams, B, H);
+    int tile_off, ntiles;
+    VAME_CHECK_ARG(coop_row_range(B, row0, nrows, tile_off, ntiles), VAME_E_SHAPE, "gru_coop_bwd: bad row range %d+%d of %d", row0, nrows, B);
+    VAME_CHECK_ARG(vame_gru_coop_supported(nstreams, ntiles * 32, H), VAME_E_UNSUPPORTED,
+                   "gru_coop_bwd: nstreams=%d rows=%d H=%d does not fit one workgroup per CU (or H not 128/256)", nstreams, ntiles * 32, H);
     VAME_CHECK_ARG((uintptr_t)xbuf % 16 == 0, VAME_E_SHAPE, "gru_coop_bwd: exchange buffer must be 16-byte aligned");
     GruBwdParams P;
     if (int rc = gru_parse_bwd(desc, nstreams, B, P)) return rc;
+    P.ntiles = ntiles; P.tile_off = tile_off;
     for (int i = 0; i < nstreams; ++i)
         VAME_CHECK_ARG((uintptr_t)P.s[i].dg % 16 == 0, VAME_E_SHAPE, "gru_coop_bwd: stream %d: dG must be 16-byte aligned", i);
     hipStream_t st = (hipStream_t)stream;

@@ -13,7 +13,7 @@ struct GruFwdStream {
     int64_t T, reverse, pad;
     const float* wpx; const float* bgi; int64_t xf;      // fused input projection (xf = features, 0 = gi is precomputed)
 };
-struct GruFwdParams { GruFwdStream s[8]; int nstreams; int B; int ntiles; };
+struct GruFwdParams { GruFwdStream s[8]; int nstreams; int B; int ntiles; int tile_off = 0; };   // tile_off: first 32-row tile of this launch (gru_coop)
 
 struct GruBwdStream {
     const float* stash; const float* y; int64_t y_row, y_t;
@@ -26,7 +26,7 @@ struct GruBwdStream {
     float* dbias;
     int64_t T, reverse, pad;
 };
-struct GruBwdParams { GruBwdStream s[8]; int nstreams; int B; int ntiles; };
+struct GruBwdParams { GruBwdStream s[8]; int nstreams; int B; int ntiles; int tile_off = 0; };
 
 // In the 32x32 accumulator layout register r of lane l holds row CR(r) + 4*(l>>5), column l&31.
 #define CR(r) (((r) & 3) + 8 * ((r) >> 2))

@@ -105,7 +105,7 @@ class VAEEngine:
         self.fut = ([GruDir("decoder_future.rnn_pred", "_l0", H, Z, self.dev),
                      GruDir("decoder_future.rnn_pred", "_l0_reverse", H, Z, self.dev)] if spec.future else [])
         self.ws = Workspace()
-        self.coop = True              # column-split GRU kernels for batches that leave most CUs idle (see _coop_ok)
+        self.coop = True              # column-split GRU kernels for batches that leave most CUs idle (see _coop_parts)
         self._coop_state = None
         self._nuc_state = None
         self.packed_version = -1
@@ -160,34 +160,37 @@ class VAEEngine:
                  a_gap_at=gap_at, a_gap=gap)
 
     # ------------------------------------------------------------------ GRU sequence dispatch
-    def _coop_ok(self, nstreams, B):
-        """Small batches: the column-split kernels (gru_coop.hip) when the whole grid fits one workgroup per CU."""
-        return (not self.stepwise) and self.coop and ops.gru_coop_supported(nstreams, B, self.spec.H)
-
     def check_async_errors(self):
         """Called where the host synchronises anyway (once per epoch): surfaces device-side failures that cannot raise."""
         if self._coop_state is not None:
             self._coop_state.check()
 
-    def _coop_parts(self, rows, B):
-        """Split a launch into cooperative launches that each fit the chip ([] = use the persistent kernels)."""
-        if self._coop_ok(len(rows), B):
-            parts = [rows]
-        elif len(rows) > 2 and len(rows) % 2 == 0 and self._coop_ok(2, B):
-            parts = [rows[i:i + 2] for i in range(0, len(rows), 2)]      # decoder + future decoder: one pair of directions each
-        else:
+    def _coop_parts(self, rows, B, tkey=None):
+        """[(streams, (row0, nrows))] cooperative launches that cover this GRU launch, each fitting one workgroup per CU; at
+        most two per stream set (beyond that the persistent kernels win).  [] = use the persistent kernels."""
+        if self.stepwise or not self.coop:
             return []
+        H = self.spec.H
+        steps = lambda r: int(r[tkey]) if (r and tkey is not None) else 1                    # noqa: E731
+        options = [([rows], ops.coop_row_chunks(len(rows), B, H))]
+        if len(rows) > 2 and len(rows) % 2 == 0:                       # decoder + future decoder: one pair of directions each
+            options.append(([rows[i:i + 2] for i in range(0, len(rows), 2)], ops.coop_row_chunks(2, B, H)))
+        options = [(sets, ch) for sets, ch in options if ch]
+        if not options:
+            return []
+        # every launch lasts as long as its longest sequence: pick the cover with the fewest (launch x step) slots
+        sets, chunks = min(options, key=lambda o: len(o[1]) * sum(max(steps(r) for r in st) for st in o[0]))
         if self._coop_state is None:
             self._coop_state = ops.CoopState(self.dev)
-        return parts
+        return [(st, ch) for st in sets for ch in chunks]
 
     def _gru_fwd(self, rows, B):
         if not self.stepwise:
             if all(r[GF["Y"]] and not r.get(GF["WPX"]) for r in rows):
-                for part in self._coop_parts(rows, B):
-                    ops.gru_coop_fwd(part, B, self.spec.H, self._coop_state)
-                    rows = None
-                if rows is None:
+                parts = self._coop_parts(rows, B, GF["T"])
+                for part, chunk in parts:
+                    ops.gru_coop_fwd(part, B, self.spec.H, self._coop_state, rows=chunk)
+                if parts:
                     return
             return ops.gru_seq_fwd(rows, B, self.spec.H)
         for r in rows:
@@ -195,9 +198,9 @@ class VAEEngine:
 
     def _gru_bwd(self, rows, B):
         if not self.stepwise:
-            parts = self._coop_parts(rows, B)
-            for part in parts:
-                ops.gru_coop_bwd(part, B, self.spec.H, self._coop_state)
+            parts = self._coop_parts(rows, B, GB["T"])
+            for part, chunk in parts:
+                ops.gru_coop_bwd(part, B, self.spec.H, self._coop_state, rows=chunk)
             if parts:
                 return
             return ops.gru_seq_bwd(rows, B, self.spec.H)
@@ -274,7 +277,7 @@ class VAEEngine:
         hn = self.buf("hn", B, 4 * H)
         rows = []
         # layer 0: F <= 32 features -> the input projection runs inside the sequence kernel on the window tile itself
-        coop = self._coop_ok(2, B)
+        coop = bool(self._coop_parts([None, None], B)) if not self.stepwise else False
         fused = (not self.stepwise) and (not coop) and self.enc[0][0].wp_x is not None and win_row % 4 == 0 and win.data_ptr() % 16 == 0
         for dirn, d in enumerate(self.enc[0]):
             st = self.buf(f"st_e0_{dirn}", ops.gru_stash_floats(B, T, H)) if training else None

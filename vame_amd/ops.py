@@ -127,25 +127,38 @@ def gru_coop_supported(nstreams, B, H):
     return bool(_lib.lib().vame_gru_coop_supported(nstreams, B, H))
 
 
-def gru_coop_fwd(streams, B, H, state: CoopState):
-    """Column-split forward for small batches: same `streams` table and results as gru_seq_fwd."""
+def coop_row_chunks(nstreams, B, H, max_rounds=2):
+    """Row ranges [(row0, nrows)] that each fit one cooperative launch, or [] when that would take more than `max_rounds`
+    launches (then the batch-tile-persistent kernels are the better choice)."""
+    if H not in (128, 256):
+        return []
+    cap = (256 // (H // 32) // 8 * 8) // nstreams * 32           # rows per launch: groups are dealt to XCDs in eights
+    if cap <= 0:
+        return []
+    n = -(-B // cap)
+    return [(r, min(cap, B - r)) for r in range(0, B, cap)] if n <= max_rounds else []
+
+
+def gru_coop_fwd(streams, B, H, state: CoopState, rows=(0, 0)):
+    """Column-split forward for small batches: same `streams` table and results as gru_seq_fwd.  rows = (row0, nrows) restricts
+    the launch to a row range of the batch (multiple of 32; (0, 0) = everything)."""
     d = _desc_tensor(streams, GF["N"])
-    need = _lib.lib().vame_gru_coop_flag_ints(len(streams), B, H)
+    need = _lib.lib().vame_gru_coop_flag_ints(len(streams), rows[1] or B, H)
     assert state.flags.numel() >= need, "cooperative flag buffer too small"
     T = max(int(s[GF["T"]]) for s in streams)
-    rc = _lib.lib().vame_gru_coop_fwd_f32(d.data_ptr(), len(streams), B, H, _ptr(state.flags), state.next_base(T), _ptr(state.status),
-                                          _stream())
+    rc = _lib.lib().vame_gru_coop_fwd_f32(d.data_ptr(), len(streams), B, H, rows[0], rows[1], _ptr(state.flags), state.next_base(T),
+                                          _ptr(state.status), _stream())
     _lib.check(rc, "vame_gru_coop_fwd_f32")
 
 
-def gru_coop_bwd(streams, B, H, state: CoopState):
+def gru_coop_bwd(streams, B, H, state: CoopState, rows=(0, 0)):
     d = _desc_tensor(streams, GB["N"])
-    need = _lib.lib().vame_gru_coop_xbuf_floats(len(streams), B, H)
+    need = _lib.lib().vame_gru_coop_xbuf_floats(len(streams), rows[1] or B, H)
     if getattr(state, "xbuf", None) is None or state.xbuf.numel() < need:
         state.xbuf = torch.empty(need, device=state.flags.device)
     T = max(int(s[GB["T"]]) for s in streams)
-    rc = _lib.lib().vame_gru_coop_bwd_f32(d.data_ptr(), len(streams), B, H, _ptr(state.xbuf), _ptr(state.flags), state.next_base(T),
-                                          _ptr(state.status), _stream())
+    rc = _lib.lib().vame_gru_coop_bwd_f32(d.data_ptr(), len(streams), B, H, rows[0], rows[1], _ptr(state.xbuf), _ptr(state.flags),
+                                          state.next_base(T), _ptr(state.status), _stream())
     _lib.check(rc, "vame_gru_coop_bwd_f32")
 
 
