@@ -1,3 +1,5 @@
+"""Host enqueue time vs total time of one fused train step (forward + loss + backward) at a given batch size.
+usage: python tools/host_time.py [batch]"""
 import sys, time, os
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 import numpy as np, torch
