@@ -4,7 +4,9 @@ timed beside vame_gemm_f32 on the same operands.  usage: python tools/torch_mm_r
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
-from vame_amd import ops
+from vame_amd import _lib, ops
+if os.environ.get("VAME_LIB"):
+    _lib._lib = _lib._bind(os.environ["VAME_LIB"])
 from vame_amd.ops import Operand
 
 torch.backends.cuda.matmul.allow_tf32 = False
