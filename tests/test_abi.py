@@ -46,6 +46,21 @@ def test_error_codes_and_messages(emu):
     assert rc == -2 and b"bad shape" in L.vame_last_error()
     with pytest.raises(emu.VameHipError):
         emu.check(rc, "vame_window_gather_f32")
+    # cooperative GRU kernels: refuse what cannot be resident at once / bad row ranges / unsupported hidden sizes
+    assert L.vame_gru_coop_supported(2, 256, 256) == 1 and L.vame_gru_coop_supported(2, 512, 256) == 1
+    assert L.vame_gru_coop_supported(2, 513, 256) == 0 and L.vame_gru_coop_supported(4, 257, 256) == 0
+    assert L.vame_gru_coop_supported(2, 64, 64) == 0 and L.vame_gru_coop_supported(2, 1024, 128) == 1
+    flags = torch.zeros(64, dtype=torch.int32)
+    rc = L.vame_gru_coop_fwd_f32(d.data_ptr(), 2, 4096, 256, 0, 0, flags.data_ptr(), 1, flags.data_ptr(), None)
+    assert rc == -4 and b"one workgroup per CU" in L.vame_last_error()
+    rc = L.vame_gru_coop_fwd_f32(d.data_ptr(), 1, 64, 256, 16, 32, flags.data_ptr(), 1, flags.data_ptr(), None)
+    assert rc == -2 and b"row range" in L.vame_last_error()
+    # training-set preparation: shape checks
+    xd = torch.zeros(16, dtype=torch.float64)
+    rc = L.vame_prep_savgol_f64(xd.data_ptr(), 1, 3, 3, xd.data_ptr(), 5, xd.data_ptr() + 64, 3, None)
+    assert rc == -2 and b"odd window" in L.vame_last_error()
+    rc = L.vame_prep_savgol_f64(xd.data_ptr(), 1, 8, 8, xd.data_ptr(), 5, xd.data_ptr(), 8, None)
+    assert rc == -1                                            # in-place filtering is refused
 
 
 def test_no_cpu_fallback_without_library(monkeypatch):
