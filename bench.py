@@ -161,16 +161,19 @@ def pmc_traffic(dom_key):
 
 def cpu_baseline():
     """Reference-equivalent torch-CPU train step (oracle/torch_ref.py) on this box's host cores, in a
-    subprocess with a hard time limit (a bounded sample: <= 12 steps of B=256 or 25 s)."""
+    subprocess with a hard time limit (a bounded sample: 32 steps of B=256, about 10 s of CPU work, at the better of two
+    thread counts; the other count is only probed with 4 steps)."""
     import subprocess
     avail = len(os.sched_getaffinity(0))
     code = ("import json,sys; sys.path.insert(0, %r); from oracle.torch_ref import time_train_steps; "
             "print('CPUBASE ' + json.dumps(time_train_steps(B=256, steps=12, warmup=2, threads=int(sys.argv[1]))))" % ROOT)
     best, tried = None, []
-    for threads in sorted({min(avail, 16), min(avail, 64)}):        # torch-CPU GRUs stop scaling early: report the better count
+    for threads, steps in ((min(avail, 16), 32), (min(avail, 64), 4)):   # torch-CPU GRUs stop scaling early: report the better count
+        if any(t == threads for t, _ in tried):
+            continue
         try:
-            r = subprocess.run([sys.executable, "-c", code.replace("steps=12", "steps=8"), str(threads)], capture_output=True, text=True,
-                               timeout=120)
+            r = subprocess.run([sys.executable, "-c", code.replace("steps=12", f"steps={steps}"), str(threads)], capture_output=True,
+                               text=True, timeout=120)
             for line in r.stdout.splitlines():
                 if line.startswith("CPUBASE "):
                     d = json.loads(line[8:])
