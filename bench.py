@@ -209,13 +209,23 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X (no CPU fallback for the measured path)")
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
+    emu = os.environ.get("VAME_BENCH_EMU_LIB")       # CPU test-suite only (tests/test_distributed_cpu.py): the torchrun /
+    if emu:                                          # rank / JSON plumbing of this script over gloo on the host emulator build;
+        from vame_amd import _lib                    # nothing it prints is a measurement
+        _lib._load_for_tests(emu)
+        dev = torch.device("cpu")
+        torch.cuda.synchronize = lambda *a, **k: None
+    else:
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs an MI355X (no CPU fallback for the measured path)")
+        torch.cuda.set_device(local)
+        dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if emu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
     assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     from vame_amd.model.dataloader import DeviceWindowLoader
@@ -273,6 +283,13 @@ def main():
 
     if rank == 0:
         value = B_LOCAL * world * args.steps / dt
+        if emu:
+            print(json.dumps(dict(metric="plumbing check only (host emulator)", value=round(value, 3), unit="windows/s", n_gpus=world,
+                                  steps=args.steps, warmup=args.warmup, data="synthetic", last_loss_terms=last)))
+            if world > 1:
+                dist.barrier()
+                dist.destroy_process_group()
+            return
         agg = profile_kernels(model, loader)
         total_ms = sum(d["ms"] for d in agg.values())
         if args.dump_kernels:

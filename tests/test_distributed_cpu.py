@@ -85,3 +85,22 @@ def test_two_rank_gradient_allreduce_and_sharded_embedding(emu, tmp_path):
         rows.append((lo, hi, e[2:].reshape(hi - lo, -1)))
     assert rows[0][0] == 0 and rows[0][1] == rows[1][0] and rows[1][1] == 70 - 30
     np.testing.assert_allclose(np.concatenate([rows[0][2], rows[1][2]]), emb["latent"][:40], atol=1e-5)
+
+
+def test_bench_script_under_torchrun_two_ranks(emu):
+    """The driver's multi-GPU invocation of bench.py (`python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`):
+    rank / barrier / max-over-ranks / rank-0 JSON plumbing, here with 2 gloo ranks on the host emulator build and a tiny model."""
+    import json
+    import subprocess
+    env = dict(os.environ, VAME_BENCH_EMU_LIB=os.path.join(ROOT, "tests", "emu", "libvame_emu.so"), VAME_EMU_THREADS="2",
+               OMP_NUM_THREADS="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--batch", "8", "--hidden", "32", "--time-window", "4"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout                                         # rank 0 prints exactly one JSON line
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 2 and out["warmup"] == 1 and out["value"] > 0
+    assert all(np.isfinite(out["last_loss_terms"]))
