@@ -110,6 +110,7 @@ __global__ __launch_bounds__(256) void gru_coop_fwd_kernel(GruFwdParams P, int* 
             if (more) load_gi(S.reverse ? t - 1 : t + 1, gnext);           // lands during the MFMA loop
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] = (w == 2) ? bhn : gcur[r];
+            if (!(step == 0 && S.h0 == nullptr))                           // zero initial state: no recurrent term in the first step
 #pragma unroll 4
             for (int c = 0; c < KC; ++c) {
                 const float4 a = *reinterpret_cast<const float4*>(hrow + 8 * c);
@@ -358,6 +359,7 @@ __global__ __launch_bounds__(256) void gru_coop_bwd_kernel(GruBwdParams P, float
             *reinterpret_cast<float4*>(dgt + 2 * H) = *reinterpret_cast<const float4*>(src + 96);
         }
         if (step + 1 < T) load_step(step + 1);
+        if (step + 1 == T && S.dh0 == nullptr) break;                     // nobody asks for dh before the first step
         {
             f32x16 acc[TPW];
 #pragma unroll

@@ -247,6 +247,8 @@ __global__ __launch_bounds__(H / 32 * 64) void gru_seq_fwd_kernel(GruFwdParams P
     GRU_PHASE_DECL();
     for (int step = 0; step < T; ++step) {
         const int t = S.reverse ? T - 1 - step : step;
+        const bool skip_first = step == 0 && S.h0 == nullptr && (XIN || S.gi_t == 0) && !(ABL & 63);   // (per-step gi streams keep
+                                                                                                  // the loop: it carries their gi prefetch)
         f32x16 ar, au, ani, anh;
         GRU_PHASE(0);
         if (XIN) {
@@ -265,7 +267,8 @@ __global__ __launch_bounds__(H / 32 * 64) void gru_seq_fwd_kernel(GruFwdParams P
                 ar = MFMA_32x32x2(a.z, b0[2], ar); au = MFMA_32x32x2(a.z, b1[2], au); ani = MFMA_32x32x2(a.z, b2[2], ani);
                 ar = MFMA_32x32x2(a.w, b0[3], ar); au = MFMA_32x32x2(a.w, b1[3], au); ani = MFMA_32x32x2(a.w, b2[3], ani);
                 RING_FENCE();                  // refill only after the slot's last use: see the note at the main loop
-                RING_LOAD(wq[j][0], wp, (j * 3 + 0) * 64); RING_LOAD(wq[j][1], wp, (j * 3 + 1) * 64); RING_LOAD(wq[j][2], wp, (j * 3 + 2) * 64);
+                const float4* nsrc = skip_first ? wpx : wp;      // no recurrent loop in a zero-state first step: keep the input chunks
+                RING_LOAD(wq[j][0], nsrc, (j * 3 + 0) * 64); RING_LOAD(wq[j][1], nsrc, (j * 3 + 1) * 64); RING_LOAD(wq[j][2], nsrc, (j * 3 + 2) * 64);
             }
         } else {
             ar = gr; au = gu; ani = gn;
@@ -273,6 +276,10 @@ __global__ __launch_bounds__(H / 32 * 64) void gru_seq_fwd_kernel(GruFwdParams P
             for (int r = 0; r < 16; ++r) anh[r] = bhn;
         }
         const float* hrow = &hs[cur][li * LDH + 4 * hh];
+        if (skip_first) {
+            // h_{-1} = 0 (no initial state given): h W_hh^T contributes nothing to the first step -- skip its 3H x H MACs; the
+            // ring keeps the chunks it holds for the next step
+        } else
         // software pipeline, distance PD chunks: W_hh fragments (L2) are requested PD x 12 MFMAs ahead of use; the
         // first PD chunks of a step were requested before the previous step's epilogue (they do not depend on h)
 #pragma unroll 1
@@ -471,6 +478,7 @@ __global__ __launch_bounds__(H / 32 * 64) void gru_seq_bwd_kernel(GruBwdParams P
         f32x16 acc1;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc1[r] = 0.f;
+        if (step + 1 == T && S.dh0 == nullptr && !(ABL & 63)) break;      // dh before the first step is not asked for: its 3H x H MACs are skipped
 #pragma unroll 1
         for (int c0 = 0; c0 < KC / 2; c0 += PD)
 #pragma unroll
