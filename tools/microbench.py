@@ -108,6 +108,27 @@ def gemm_tiles(rounds=4):
         print(f"M={M} N={N} K={K} akm={akm} bkm={bkm} sk={sk}: " + "  ".join(f"tile{v}: {statistics.median(t):6.1f}" for v, t in res.items()))
 
 
+def gemm_skinny(rounds=4):
+    """Tile configurations for the N <= 32 shapes of the step (tuning build): 0 = 128x32 / 4 waves (product), 3 = 64x32 / 2 waves,
+    4 = 256x32 / 8 waves."""
+    import statistics
+    BT = 4096 * 30
+    shapes = [(BT, 24, 512, 0, 0, 1), (BT // 2, 24, 512, 0, 0, 1), (768, 24, BT, 1, 1, 128), (4096, 30, 768, 0, 1, 1), (4096, 30, 1024, 0, 0, 1),
+              (768, 30, 4096, 1, 1, 8)]
+    for (M, N, K, akm, bkm, sk) in shapes:
+        A = torch.randn((K, M) if akm else (M, K), device=dev)
+        B = torch.randn((K, N) if bkm else (N, K), device=dev)
+        C = torch.empty(M, N, device=dev)
+        ws = torch.empty(sk * M * N, device=dev) if sk > 1 else None
+        res = {v: [] for v in (0, 3, 4)}
+        for r in range(rounds):
+            for v in res:
+                os.environ["VAME_GEMM_TILE"] = str(v)
+                ms = timeit(lambda: ops.gemm(M, N, K, Operand(A, A.shape[1]), akm, Operand(B, B.shape[1]), bkm, C, N, splitk=sk, ws=ws), reps=10)
+                res[v].append(ms * 1e3)
+        print(f"M={M} N={N} K={K} akm={akm} bkm={bkm} sk={sk}: " + "  ".join(f"tile{v}: {statistics.median(t):7.1f} us" for v, t in res.items()), flush=True)
+
+
 def gemm_ab(rounds=4):
     """Interleaved A/B of the GEMM kernel variants (library built with `make ab`)."""
     BT = 4096 * 30
@@ -130,6 +151,9 @@ def gemm_ab(rounds=4):
 if __name__ == "__main__":
     if len(sys.argv) > 2 and sys.argv[2] == "gemm_tiles":
         gemm_tiles()
+        sys.exit(0)
+    if len(sys.argv) > 2 and sys.argv[2] == "gemm_skinny":
+        gemm_skinny()
         sys.exit(0)
     if len(sys.argv) > 2 and sys.argv[2] == "gemm_ab":
         gemm_ab()

@@ -346,6 +346,10 @@ extern "C" int vame_gemm_f32(int M, int N, int K, const float* A, int64_t lda, i
         rc = launch_gemm<256, 128, 2, 2>(p, a_kmajor, b_kmajor, st);                          // 128x64 per wave (A/B tuning build only)
     else if (N > 64 && getenv("VAME_GEMM_TILE") && atoi(getenv("VAME_GEMM_TILE")) == 2 && M >= 256)
         rc = launch_gemm<256, 128, 4, 2>(p, a_kmajor, b_kmajor, st);                          // 8 waves, 64x64 per wave
+    else if (N <= 32 && getenv("VAME_GEMM_TILE") && atoi(getenv("VAME_GEMM_TILE")) == 3)
+        rc = launch_gemm<64, 32, 2, 1>(p, a_kmajor, b_kmajor, st);                            // skinny N, more workgroups in flight (A/B)
+    else if (N <= 32 && getenv("VAME_GEMM_TILE") && atoi(getenv("VAME_GEMM_TILE")) == 4)
+        rc = launch_gemm<256, 32, 8, 1>(p, a_kmajor, b_kmajor, st);
 #endif
     else if (N > 64) rc = launch_gemm<128, 128, 2, 2>(p, a_kmajor, b_kmajor, st);
     else if (N > 32) rc = launch_gemm<128, 64, 4, 1>(p, a_kmajor, b_kmajor, st);
