@@ -14,6 +14,7 @@ All buffers are fp32 and live in a per-batch-size workspace (no allocation insid
 Sequences are stored as (B, T+2, 2H): slot 0 / T+1 hold the initial state of the forward /
 reverse direction so h_{t-1} is a plain strided view for the BPTT kernels and the dW_hh GEMMs.
 """
+import os
 from dataclasses import dataclass
 from types import SimpleNamespace
 
@@ -105,7 +106,8 @@ class VAEEngine:
         self.fut = ([GruDir("decoder_future.rnn_pred", "_l0", H, Z, self.dev),
                      GruDir("decoder_future.rnn_pred", "_l0_reverse", H, Z, self.dev)] if spec.future else [])
         self.ws = Workspace()
-        self.coop = True              # column-split GRU kernels for batches that leave most CUs idle (see _coop_parts)
+        # column-split GRU kernels for batches that leave most CUs idle (see _coop_parts); VAME_AMD_COOP=0 keeps the persistent ones
+        self.coop = os.environ.get("VAME_AMD_COOP", "1") != "0"
         self._coop_state = None
         self._nuc_state = None
         self.packed_version = -1
