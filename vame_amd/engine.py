@@ -106,6 +106,10 @@ class VAEEngine:
         self.fut = ([GruDir("decoder_future.rnn_pred", "_l0", H, Z, self.dev),
                      GruDir("decoder_future.rnn_pred", "_l0_reverse", H, Z, self.dev)] if spec.future else [])
         self.ws = Workspace()
+        self._wgrad_queue = None
+        self._B_bwd = None
+        self._side_streams = []
+        self.wgrad_streams = int(os.environ.get("VAME_AMD_WGRAD_STREAMS", "0"))   # 0 = auto (2; 4 for small batches), 1 = caller's stream only
         # column-split GRU kernels for batches that leave most CUs idle (see _coop_parts); VAME_AMD_COOP=0 keeps the persistent ones
         self.coop = os.environ.get("VAME_AMD_COOP", "1") != "0"
         self._coop_state = None
@@ -154,12 +158,49 @@ class VAEEngine:
             sk = sk // 8 * 8
         return sk
 
-    def _gemm_wgrad(self, M, N, K, A, B, gname, row_off=0, gap_at=0, gap=0):
-        """flat_g[gname][row_off:row_off+M, :N] = A^T B with split-K over K = batch x time."""
+    def _gemm_wgrad(self, M, N, K, A, B, gname, row_off=0, gap_at=0, gap=0, lane=0):
+        """flat_g[gname][row_off:row_off+M, :N] = A^T B with split-K over K = batch x time.  Inside backward() the call is
+        queued (nothing reads flat_g before the optimizer) and issued by _flush_wgrads(); `lane` picks the split-K scratch."""
+        if self._wgrad_queue is not None:
+            self._wgrad_queue.append((M, N, K, A, B, gname, row_off, gap_at, gap))
+            return
         sk = self._splitk(M, N, K)
-        ws = self.ws.get("splitk", max(sk * M * N, 1), self.dev) if sk > 1 else None
+        ws = self.ws.get(f"splitk{lane}", max(sk * M * N, 1), self.dev) if sk > 1 else None
         ops.gemm(M, N, K, A, 1, B, 1, self.g, N, c_off=self.table.off(gname) + row_off * N, splitk=sk, ws=ws,
                  a_gap_at=gap_at, a_gap=gap)
+
+    def _flush_wgrads(self):
+        """Issue the queued weight-gradient GEMMs.  They are independent of each other, so on the GPU they go out on
+        `wgrad_streams` (2) streams, largest first: the tail of one (workgroups finish up to 5 % apart) and its split-K reduction overlap the next
+        one's body instead of idling the chip at ~20 kernel boundaries.  They run after the last GRU launch of the backward
+        pass on purpose -- next to a GRU launch they would take LDS from workgroups that need a whole CU."""
+        jobs, self._wgrad_queue = self._wgrad_queue, None
+        if not jobs:
+            return
+        n = (self.wgrad_streams or (4 if (self._B_bwd or 0) <= 512 else 2)) if self.dev.type == "cuda" else 1     # measured: 2 / 4
+        if n < 2 or len(jobs) < 2:
+            for j in jobs:
+                self._gemm_wgrad(*j)
+            return
+        while len(self._side_streams) < n - 1:
+            self._side_streams.append(torch.cuda.Stream(device=self.dev))
+        main = torch.cuda.current_stream(self.dev)
+        jobs.sort(key=lambda j: -j[0] * j[1] * j[2])
+        lanes, load = [[] for _ in range(n)], [0] * n
+        for j in jobs:                                   # greedy balance by flops
+            k = load.index(min(load))
+            lanes[k].append(j)
+            load[k] += j[0] * j[1] * j[2]
+        for side in self._side_streams[:n - 1]:
+            side.wait_stream(main)
+        for j in lanes[0]:
+            self._gemm_wgrad(*j, lane=0)
+        for k, side in enumerate(self._side_streams[:n - 1], start=1):
+            with torch.cuda.stream(side):
+                for j in lanes[k]:
+                    self._gemm_wgrad(*j, lane=k)
+        for side in self._side_streams[:n - 1]:
+            main.wait_stream(side)
 
     # ------------------------------------------------------------------ GRU sequence dispatch
     def check_async_errors(self):
@@ -460,6 +501,8 @@ class VAEEngine:
         s, H, F, Z, T, FS, t = self.spec, self.spec.H, self.spec.F, self.spec.Z, self.spec.T, self.spec.FS, self.table
         ntiles = (B + 31) // 32
         self._colsum_jobs = []
+        self._wgrad_queue = []
+        self._B_bwd = B
         z = self.buf("z", B, Z)
         dz = self.buf("dz", B, Z)
         # ---- decoders (one BPTT launch for all 2 or 4 streams)
@@ -528,6 +571,7 @@ class VAEEngine:
         xrows = Operand(self._win, F, seg=T, seg_stride=self._win_row)
         for dirn, (d, dG, dbias) in enumerate(per):
             self._gru_param_grads(d, dG, dbias, ntiles, B, T, Y0, dirn, xrows, F)
+        self._flush_wgrads()
         ops.colsum_batch(self._colsum_jobs)
         self._colsum_jobs = []
 
