@@ -109,6 +109,7 @@ class VAEEngine:
         self._wgrad_queue = None
         self._B_bwd = None
         self._side_streams = []
+        self.small_streams = int(os.environ.get("VAME_AMD_SMALL_STREAMS", "3"))   # independent small GEMMs before the decoder launch
         self.wgrad_streams = int(os.environ.get("VAME_AMD_WGRAD_STREAMS", "0"))   # 0 = auto (2; 4 for small batches), 1 = caller's stream only
         # column-split GRU kernels for batches that leave most CUs idle (see _coop_parts); VAME_AMD_COOP=0 keeps the persistent ones
         self.coop = os.environ.get("VAME_AMD_COOP", "1") != "0"
@@ -168,6 +169,30 @@ class VAEEngine:
         ws = self.ws.get(f"splitk{lane}", max(sk * M * N, 1), self.dev) if sk > 1 else None
         ops.gemm(M, N, K, A, 1, B, 1, self.g, N, c_off=self.table.off(gname) + row_off * N, splitk=sk, ws=ws,
                  a_gap_at=gap_at, a_gap=gap)
+
+    def _parallel(self, jobs, n):
+        """Run independent launch closures on up to n streams (round-robin), joined before returning.  Only for groups of
+        kernels that are not next to a GRU launch (see _flush_wgrads) and share no scratch."""
+        if self.dev.type != "cuda" or n < 2 or len(jobs) < 2:
+            for j in jobs:
+                j()
+            return
+        n = min(n, len(jobs))
+        while len(self._side_streams) < n - 1:
+            self._side_streams.append(torch.cuda.Stream(device=self.dev))
+        main = torch.cuda.current_stream(self.dev)
+        sides = self._side_streams[:n - 1]
+        for sd in sides:
+            sd.wait_stream(main)
+        for i, j in enumerate(jobs):
+            k = i % n
+            if k == 0:
+                j()
+            else:
+                with torch.cuda.stream(sides[k - 1]):
+                    j()
+        for sd in sides:
+            main.wait_stream(sd)
 
     def _flush_wgrads(self):
         """Issue the queued weight-gradient GEMMs.  They are independent of each other, so on the GPU they go out on
@@ -359,17 +384,17 @@ class VAEEngine:
         ops.latent_fwd(mu, lvr, eps, B, Z, s.softplus, training, logvar, z, losses[LOSS_KLSUM:] if want_kl else None)
         return z, mu, logvar
 
-    def _decode_one(self, tag, name, dirs, steps, z, B, training, rows):
+    def _decode_one(self, tag, name, dirs, steps, z, B, training, rows, jobs):
         H, Z = self.spec.H, self.spec.Z
         hid = None
         if self.h0_from_z:
             hid = self.buf(f"hid_{tag}", B, 2 * H)
-            ops.gemm(B, 2 * H, Z, Operand(z, Z), 0, self.P(f"{name}.latent_to_hidden.weight", Z), 0, hid, 2 * H,
-                     bias=self._pv(f"{name}.latent_to_hidden.bias"))
+            jobs.append(lambda: ops.gemm(B, 2 * H, Z, Operand(z, Z), 0, self.P(f"{name}.latent_to_hidden.weight", Z), 0, hid, 2 * H,
+                                         bias=self._pv(f"{name}.latent_to_hidden.bias")))
         Y = self.buf(f"Y_{tag}", B, steps + 2, 2 * H)
         for dirn, d in enumerate(dirs):
             gi = self.buf(f"gi_{tag}_{dirn}", B, 3 * H)
-            ops.gemm(B, 3 * H, Z, Operand(z, Z), 0, self.P(d.w_ih, Z), 0, gi, 3 * H, bias=d.bias_gi)
+            jobs.append(lambda d=d, gi=gi: ops.gemm(B, 3 * H, Z, Operand(z, Z), 0, self.P(d.w_ih, Z), 0, gi, 3 * H, bias=d.bias_gi))
             st = self.buf(f"st_{tag}_{dirn}", ops.gru_stash_floats(B, steps, H)) if training else None
             # hidden.view(2,B,H) (rnn_model.py:104,137): direction d, row b lives at flat offset (d*B+b)*H
             rows.append(self._gru_fwd_stream(d, gi, 3 * H, 0, hid, dirn * B * H, Y, 2 * H, steps, dirn, None, 0, 0, st, steps))
@@ -378,9 +403,10 @@ class VAEEngine:
     def decode(self, z, B, training):
         s, H, F, T, FS = self.spec, self.spec.H, self.spec.F, self.spec.T, self.spec.FS
         self.repack()
-        rows = []
-        Yd = self._decode_one("dec", "decoder", self.dec, T, z, B, training, rows)
-        Yf = self._decode_one("fut", "decoder_future", self.fut, FS, z, B, training, rows) if s.future else None
+        rows, jobs = [], []
+        Yd = self._decode_one("dec", "decoder", self.dec, T, z, B, training, rows, jobs)
+        Yf = self._decode_one("fut", "decoder_future", self.fut, FS, z, B, training, rows, jobs) if s.future else None
+        self._parallel(jobs, self.small_streams)      # <= 6 independent (B x 3H|2H x Z) projections of z
         self._gru_fwd(rows, B)
         pred = self.buf("pred", B, T, F)
         Kd = len(self.dec) * H                 # H for the uni-directional legacy decoder: only the first half of each Y row
