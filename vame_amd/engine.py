@@ -360,13 +360,14 @@ class VAEEngine:
         self._gru_fwd(rows, B)
         y_op = Operand(Y0, 2 * H, off=2 * H, seg=T, seg_stride=(T + 2) * 2 * H)
         Y1 = self.buf("Y1", B, T + 2, 2 * H) if (training or coop) else None
-        rows = []
+        rows, jobs = [], []
         for dirn, d in enumerate(self.enc[1]):
             gi = self.buf(f"gi_e1_{dirn}", B, T, 3 * H)
-            ops.gemm(B * T, 3 * H, 2 * H, y_op, 0, self.P(d.w_ih, 2 * H), 0, gi, 3 * H, bias=d.bias_gi)
+            jobs.append(lambda d=d, gi=gi: ops.gemm(B * T, 3 * H, 2 * H, y_op, 0, self.P(d.w_ih, 2 * H), 0, gi, 3 * H, bias=d.bias_gi))
             st = self.buf(f"st_e1_{dirn}", ops.gru_stash_floats(B, T, H)) if training else None
             rows.append(self._gru_fwd_stream(d, gi, T * 3 * H, 3 * H, None, 0, Y1, 2 * H, T, dirn, hn, (2 + dirn) * H, 4 * H, st, T,
                                              write_y=training or coop))
+        self._parallel(jobs, min(2, self.small_streams))      # the two directions' input projections fill each other's tails
         self._gru_fwd(rows, B)
         return hn
 
