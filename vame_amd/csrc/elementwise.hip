@@ -445,6 +445,9 @@ extern "C" int vame_kmeans_assign_f32(const float* X, int64_t N, int D, const fl
 // round-robin schedule gives Z/2 disjoint rotations per round, applied as a column pass and a row
 // pass.  One 256-thread workgroup; latency ~0.1 ms, run beside the decoder kernels.
 #define NUC_MAXZ 64
+#ifndef NUC_TOL
+#define NUC_TOL 1e-13   /* off-diagonal mass / diagonal mass at which the sweeps stop: eigenvalues to ~1e-13, eigenvectors to ~3e-7 relative -- below the fp32 Gram it starts from; 1e-20 costs one more sweep (+35 us) for the same loss */
+#endif
 // vstate (optional, Z'xZ' doubles with Z' = Z rounded up to even, zero-initialised by the caller): eigenvectors of the
 // previous call.  G changes little between optimizer steps, so rotating into the previous eigenbasis first (A = V^T G V)
 // leaves an almost diagonal matrix and the Jacobi iteration converges in 1-2 sweeps instead of 6-8.
@@ -505,7 +508,7 @@ __global__ __launch_bounds__(256) void nuclear_kernel(const float* __restrict__ 
             if (tid < s) { ro[tid] += ro[tid + s]; rd[tid] += rd[tid + s]; }
             __syncthreads();
         }
-        const bool done = ro[0] <= 1e-20 * rd[0] || rd[0] == 0.0;      // |off| <= 1e-10 |diag|: eigenvalue error ~ off^2 / gap
+        const bool done = ro[0] <= NUC_TOL * rd[0] || rd[0] == 0.0;      // |off| <= sqrt(NUC_TOL) |diag|: eigenvalue error ~ off^2 / gap
         __syncthreads();
         if (done) break;
         for (int round = 0; round < n - 1; ++round) {
