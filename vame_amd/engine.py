@@ -110,7 +110,10 @@ class VAEEngine:
         self._B_bwd = None
         self._side_streams = []
         self.small_streams = int(os.environ.get("VAME_AMD_SMALL_STREAMS", "3"))   # independent small GEMMs before the decoder launch
-        self.wgrad_streams = int(os.environ.get("VAME_AMD_WGRAD_STREAMS", "0"))   # 0 = auto (2; 4 for small batches), 1 = caller's stream only
+        # 0 = auto: 4 streams up to batch 1024, ONE above (two streams give +1.5 % at batch 4096, but two large GEMMs sharing the
+        # chip each take twice as long, which makes per-kernel durations -- bench.py's roofline block, rocprofv3 --stats --
+        # unreadable; set 2 to take that 1.5 %); 1 = caller's stream only
+        self.wgrad_streams = int(os.environ.get("VAME_AMD_WGRAD_STREAMS", "0"))
         # column-split GRU kernels for batches that leave most CUs idle (see _coop_parts); VAME_AMD_COOP=0 keeps the persistent ones
         self.coop = os.environ.get("VAME_AMD_COOP", "1") != "0"
         self._coop_state = None
@@ -196,13 +199,13 @@ class VAEEngine:
 
     def _flush_wgrads(self):
         """Issue the queued weight-gradient GEMMs.  They are independent of each other, so on the GPU they go out on
-        `wgrad_streams` (2) streams, largest first: the tail of one (workgroups finish up to 5 % apart) and its split-K reduction overlap the next
+        several streams (see `wgrad_streams`), largest first: the tail of one (workgroups finish up to 5 % apart) and its split-K reduction overlap the next
         one's body instead of idling the chip at ~20 kernel boundaries.  They run after the last GRU launch of the backward
         pass on purpose -- next to a GRU launch they would take LDS from workgroups that need a whole CU."""
         jobs, self._wgrad_queue = self._wgrad_queue, None
         if not jobs:
             return
-        n = (self.wgrad_streams or (4 if (self._B_bwd or 0) <= 512 else 2)) if self.dev.type == "cuda" else 1     # measured: 2 / 4
+        n = (self.wgrad_streams or (4 if (self._B_bwd or 0) <= 1024 else 1)) if self.dev.type == "cuda" else 1
         if n < 2 or len(jobs) < 2:
             for j in jobs:
                 self._gemm_wgrad(*j)
@@ -367,7 +370,8 @@ class VAEEngine:
             st = self.buf(f"st_e1_{dirn}", ops.gru_stash_floats(B, T, H)) if training else None
             rows.append(self._gru_fwd_stream(d, gi, T * 3 * H, 3 * H, None, 0, Y1, 2 * H, T, dirn, hn, (2 + dirn) * H, 4 * H, st, T,
                                              write_y=training or coop))
-        self._parallel(jobs, min(2, self.small_streams))      # the two directions' input projections fill each other's tails
+        # the two directions' input projections fill each other's tails (small batches only: see wgrad_streams)
+        self._parallel(jobs, min(2, self.small_streams) if B <= 1024 else 1)
         self._gru_fwd(rows, B)
         return hn
 
