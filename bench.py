@@ -86,8 +86,11 @@ def profile_kernels(model, loader, steps=3):
     def gemm_flops(M, N, K, A, akm, Bm, bkm, *a, **k):
         kind = "NT" if (not akm and not bkm) else ("NN" if not akm else "TN")
         return (f"gemm_kernel {kind} M={M} N={N} K={K}", 2.0 * M * N * K)
+    def group_flops(M, N, K, As, akm, Bs, bkm, *a, **k):
+        kind = "NT" if (not akm and not bkm) else ("NN" if not akm else "TN")
+        return (f"gemm_kernel {kind} M={M} N={N} K={K} x{len(As)} grouped", 2.0 * M * N * K * len(As))
     saved = {n: kt.wrap(ops, n, fn) for n, fn in (("gru_seq_fwd", gru_flops("fwd")), ("gru_seq_bwd", gru_flops("bwd")),
-                                                  ("gemm", gemm_flops))}
+                                                  ("gemm", gemm_flops), ("gemm_group", group_flops))}
     try:
         for _ in range(steps):
             win = loader.gather(loader.draw_starts())
@@ -149,7 +152,10 @@ def pmc_traffic(dom_key):
     with open(path) as f:
         j = json.load(f)
     if dom_key.startswith("gemm_kernel TN M=768 N=256 K=122880"):
-        return j.get("gemm_TN_M768_N256_K122880_sk64", {}).get("hbm_bytes_per_launch_corrected")
+        per = j.get("gemm_TN_M768_N256_K122880_sk64", {}).get("hbm_bytes_per_launch_corrected")
+        if per is not None and " x" in dom_key and dom_key.endswith("grouped"):      # grouped launch: that many problems' operands
+            per *= int(dom_key.split(" x")[1].split()[0])
+        return per
     if dom_key.startswith("gru_seq_"):
         kind = "fwd" if "fwd" in dom_key else "bwd"
         grid = 262144 if "x4" in dom_key else 131072

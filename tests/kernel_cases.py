@@ -15,6 +15,35 @@ def N_(t):
     return t.detach().cpu().numpy()
 
 
+def check_gemm_group(dev, small=True):
+    """vame_gemm_group_f32: several TN / NN problems of one shape in one launch = the single-problem GEMM on each of them, bit
+    for bit when the split-K factor is the same (same per-tile k order, same partial-sum order), incl. the column gap of the
+    dW_hh form and accumulation into C."""
+    rng = np.random.default_rng(3)
+    for (M, Nn, K, akm, bkm, sk, n, gap, acc) in ([(96, 136, 512, 1, 1, 8, 3, 0, False), (70, 72, 512, 0, 1, 8, 2, 0, True), (64, 100, 640, 1, 1, 16, 5, 32, False)]
+                                                    + ([] if small else [(768, 256, 8192, 1, 1, 32, 6, 256, False)])):
+        Mw = M + (gap or 0)                                    # stored width of a k-major A with a skipped column block
+        As = [rng.standard_normal((K, Mw) if akm else (M, K)).astype(np.float32) for _ in range(n)]
+        Bs = [rng.standard_normal((K, Nn) if bkm else (Nn, K)).astype(np.float32) for _ in range(n)]
+        C0 = rng.standard_normal((n, M, Nn)).astype(np.float32)
+        At, Bt = [T_(a, dev) for a in As], [T_(b, dev) for b in Bs]
+        Cg, Cs = T_(C0, dev), T_(C0, dev)
+        ws = torch.zeros(n * sk * M * Nn, device=dev)
+        gap_at = (M // 2) // 4 * 4 if gap else 0
+        ops.gemm_group(M, Nn, K, [Operand(a, a.shape[1]) for a in At], akm, [Operand(b, b.shape[1]) for b in Bt], bkm, Cg,
+                       [g * M * Nn for g in range(n)], Nn, sk, ws, accumulate=acc, a_gap_at=gap_at, a_gap=gap)
+        for g in range(n):
+            ops.gemm(M, Nn, K, Operand(At[g], At[g].shape[1]), akm, Operand(Bt[g], Bt[g].shape[1]), bkm, Cs, Nn, c_off=g * M * Nn,
+                     accumulate=acc, splitk=sk, ws=ws, a_gap_at=gap_at, a_gap=gap)
+        np.testing.assert_array_equal(N_(Cg), N_(Cs), err_msg=str((M, Nn, K, akm, bkm, sk, n, gap)))
+        a0 = As[0]
+        if akm:
+            cols = np.r_[0:gap_at, gap_at + gap:Mw] if gap else np.arange(M)
+            a0 = a0[:, cols].T
+        ref = a0.astype(np.float64) @ (Bs[0] if bkm else Bs[0].T).astype(np.float64) + (C0[0] if acc else 0)
+        np.testing.assert_allclose(N_(Cg)[0], ref, atol=2e-4 * np.sqrt(K))
+
+
 def check_gemm_cases(dev, small=True):
     rng = np.random.default_rng(0)
     cases = [  # M, N, K, akm, bkm, splitk, bias, acc

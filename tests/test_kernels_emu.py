@@ -5,7 +5,7 @@ the CPU; the same checks run on the real GPU in test_kernels_gpu.py.
 """
 import pytest
 
-from kernel_cases import (check_adam, check_colsum, check_colsum_batch, check_kmeans, check_gather, check_gemm_cases, check_gru_bwd, check_gru_coop_bwd, check_gru_coop_fwd, check_gru_fwd, check_gru_fwd_fused,
+from kernel_cases import (check_adam, check_colsum, check_colsum_batch, check_kmeans, check_gather, check_gemm_cases, check_gemm_group, check_gru_bwd, check_gru_coop_bwd, check_gru_coop_fwd, check_gru_fwd, check_gru_fwd_fused,
                           check_latent, check_mse, check_nuclear, check_prep_fill_rules, check_prepare_series_golden,
                           check_prepare_series_vs_oracle)
 
@@ -69,3 +69,7 @@ def test_gru_coop_fwd(emu, H, B, T):
 @pytest.mark.parametrize("H,B,T", [(128, 40, 3), (256, 37, 4)])
 def test_gru_coop_bwd(emu, H, B, T):
     check_gru_coop_bwd("cpu", H, B, T)
+
+
+def test_gemm_group(emu):
+    check_gemm_group("cpu")

@@ -1,7 +1,7 @@
 """The kernel checks of test_kernels_emu.py on the real MI355X through libvame_hip.so (C ABI)."""
 import pytest
 
-from kernel_cases import (check_adam, check_colsum, check_colsum_batch, check_kmeans, check_gather, check_gemm_cases, check_gru_bwd, check_gru_coop_bwd, check_gru_coop_fwd, check_gru_fwd, check_gru_fwd_fused,
+from kernel_cases import (check_adam, check_colsum, check_colsum_batch, check_kmeans, check_gather, check_gemm_cases, check_gemm_group, check_gru_bwd, check_gru_coop_bwd, check_gru_coop_fwd, check_gru_fwd, check_gru_fwd_fused,
                           check_latent, check_mse, check_nuclear, check_prep_fill_rules, check_prepare_series_golden,
                           check_prepare_series_vs_oracle)
 
@@ -67,3 +67,7 @@ def test_gru_coop_fwd(hip, H, B, T):
 @pytest.mark.parametrize("H,B,T", [(128, 40, 3), (256, 37, 4), (256, 256, 30), (256, 500, 30), (128, 1000, 7)])
 def test_gru_coop_bwd(hip, H, B, T):
     check_gru_coop_bwd(DEV, H, B, T)
+
+
+def test_gemm_group(hip):
+    check_gemm_group(DEV, small=False)

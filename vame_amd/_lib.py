@@ -25,6 +25,8 @@ _SIGS = {
     "vame_window_gather_f32": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p]),
     "vame_gemm_f32": (c_int, [c_int, c_int, c_int, c_void_p, c_int64, c_int, c_int64, c_int64, c_void_p, c_int64, c_int,
                               c_int64, c_int64, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p, c_int, c_int, c_void_p]),
+    "vame_gemm_group_f32": (c_int, [c_int, c_int, c_int, c_int, c_void_p, c_int64, c_int, c_int64, c_int64, c_void_p, c_int64, c_int,
+                                    c_int64, c_int64, c_void_p, c_int64, c_int, c_int, c_void_p, c_int, c_int, c_void_p]),
     "vame_gru_pack_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "vame_gru_pack_x_f32": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "vame_gru_stash_floats": (c_int64, [c_int, c_int, c_int]),

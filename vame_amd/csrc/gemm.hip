@@ -19,6 +19,9 @@ struct GemmParams {
     float* ws;
     int M, N, K, kper, splitk, accumulate;
     int tiles_m, tiles_n, by_z;      // XCD-aware block->tile mapping (see map_tile)
+    int group;                       // > 1: that many problems of identical shape / layout in one launch (split-K >= 8 only):
+    const float* gA[8];              //      per-problem operand bases; partial sums of problem g go to ws + g * splitk * M * N
+    const float* gB[8];
 };
 
 __device__ __forceinline__ int64_t op_row(const GemmOperand& o, int64_t i) {
@@ -29,13 +32,14 @@ __device__ __forceinline__ int64_t op_row(const GemmOperand& o, int64_t i) {
 // has a private 4 MiB L2, so tiles that stream the same operand panel are kept on ONE XCD: with
 // split-K >= 8 a whole k-slab (all its m,n tiles) is a unit, otherwise an (k-split, m-panel) row of n-tiles.
 // Units are dealt round-robin to XCDs; inside an XCD consecutive workgroups walk one unit's tiles.
-__device__ __forceinline__ bool map_tile(const GemmParams& p, int& tm, int& tn, int& z) {
+__device__ __forceinline__ bool map_tile(const GemmParams& p, int& tm, int& tn, int& z, int& g) {
     const int L = blockIdx.x, xcd = L & 7, slot = L >> 3;
     const int per_unit = p.by_z ? p.tiles_m * p.tiles_n : p.tiles_n;
-    const int nunits = p.by_z ? p.splitk : p.splitk * p.tiles_m;
+    const int nunits = p.by_z ? p.splitk * p.group : p.splitk * p.tiles_m;
     const int u = (slot / per_unit) * 8 + xcd, w = slot % per_unit;
+    g = 0;
     if (u >= nunits) return false;
-    if (p.by_z) { z = u; tm = w / p.tiles_n; tn = w % p.tiles_n; }
+    if (p.by_z) { z = u / p.group; g = u - z * p.group; tm = w / p.tiles_n; tn = w % p.tiles_n; }   // consecutive units cycle over the problems
     else { z = u / p.tiles_m; tm = u % p.tiles_m; tn = w; }
     return true;
 }
@@ -185,8 +189,11 @@ __global__ __launch_bounds__(WM * WN * 64, (BM / WM) * (BN / WN) > 64 * 64 ? 2 :
     typedef TileIO<BK, BN, NT, BKM, false> TB;
     __shared__ __attribute__((aligned(16))) float As[TA::LDS_FLOATS];
     __shared__ __attribute__((aligned(16))) float Bs[TB::LDS_FLOATS];
-    int tm_, tn_, z;
-    if (!map_tile(p, tm_, tn_, z)) return;
+    int tm_, tn_, z, g;
+    if (!map_tile(p, tm_, tn_, z, g)) return;
+    GemmOperand opA = p.A, opB = p.B;
+    float* ws = p.ws;
+    if (p.group > 1) { opA.p = p.gA[g]; opB.p = p.gB[g]; ws += (int64_t)g * p.splitk * p.M * p.N; }
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, li = lane & 31, hh = lane >> 5;
     const int wm = wv / WN, wn = wv % WN;
     const int m0 = tm_ * BM, n0 = tn_ * BN;
@@ -202,9 +209,9 @@ __global__ __launch_bounds__(WM * WN * 64, (BM / WM) * (BN / WN) > 64 * 64 ? 2 :
 
     TA ta;
     TB tb;
-    ta.init(p.A, m0, p.M, kb, tid);
-    tb.init(p.B, n0, p.N, kb, tid);
-    if (kb < ke) { ta.template fetch<(VAR & 1) != 0>(p.A, m0, p.M, kb, ke, tid); tb.template fetch<(VAR & 1) != 0>(p.B, n0, p.N, kb, ke, tid); }
+    ta.init(opA, m0, p.M, kb, tid);
+    tb.init(opB, n0, p.N, kb, tid);
+    if (kb < ke) { ta.template fetch<(VAR & 1) != 0>(opA, m0, p.M, kb, ke, tid); tb.template fetch<(VAR & 1) != 0>(opB, n0, p.N, kb, ke, tid); }
     PROBE_DECL;
     for (int k0 = kb; k0 < ke; k0 += BK) {
         ta.store(As, tid);
@@ -212,7 +219,7 @@ __global__ __launch_bounds__(WM * WN * 64, (BM / WM) * (BN / WN) > 64 * 64 ? 2 :
         PROBE_ADD(ps);
         __syncthreads();
         PROBE_ADD(pb1);
-        if (k0 + BK < ke) { ta.template fetch<(VAR & 1) != 0>(p.A, m0, p.M, k0 + BK, ke, tid); tb.template fetch<(VAR & 1) != 0>(p.B, n0, p.N, k0 + BK, ke, tid); }   // in flight during the MFMAs
+        if (k0 + BK < ke) { ta.template fetch<(VAR & 1) != 0>(opA, m0, p.M, k0 + BK, ke, tid); tb.template fetch<(VAR & 1) != 0>(opB, n0, p.N, k0 + BK, ke, tid); }   // in flight during the MFMAs
         if (VAR & 4) SETPRIO(1);
         // MFMA step (c, e) contracts k = {8c + e, 8c + 4 + e}: any k order is valid as long as A and B agree
 #pragma unroll
@@ -254,7 +261,7 @@ __global__ __launch_bounds__(WM * WN * 64, (BM / WM) * (BN / WN) > 64 * 64 ? 2 :
                 if (row >= p.M) continue;
                 float v = acc[i][j][r];
                 if (p.splitk > 1) {
-                    p.ws[((int64_t)z * p.M + row) * p.N + col] = v;
+                    ws[((int64_t)z * p.M + row) * p.N + col] = v;
                 } else {
                     float* c = p.C + (int64_t)row * p.ldc + col;
                     v += bv;
@@ -280,6 +287,21 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
     }
 }
 
+struct GemmGroupOut { float* C[8]; };
+__global__ __launch_bounds__(256) void splitk_reduce_group_kernel(const float* __restrict__ ws, int splitk, int M, int N, GemmGroupOut out,
+                                                                  int64_t ldc, int accumulate) {
+    const int64_t n = (int64_t)M * N;
+    const float* w = ws + (int64_t)blockIdx.y * splitk * n;
+    float* C = out.C[blockIdx.y];
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        float v = 0.f;
+        for (int z = 0; z < splitk; ++z) v += w[(int64_t)z * n + i];
+        float* c = C + (i / N) * ldc + (i % N);
+        if (accumulate) v += *c;
+        *c = v;
+    }
+}
+
 #include <stdlib.h>
 template <int BM, int BN, int WM, int WN, int VAR>
 static int launch_gemm_var(const GemmParams& p, int akm, int bkm, dim3 grid, dim3 block, hipStream_t st) {
@@ -294,7 +316,7 @@ static int launch_gemm(GemmParams p, int akm, int bkm, hipStream_t st) {
     p.tiles_m = (int)cdiv64(p.M, BM); p.tiles_n = (int)cdiv64(p.N, BN);
     p.by_z = p.splitk >= 8;
     const int64_t per_unit = p.by_z ? (int64_t)p.tiles_m * p.tiles_n : p.tiles_n;
-    const int64_t nunits = p.by_z ? p.splitk : (int64_t)p.splitk * p.tiles_m;
+    const int64_t nunits = p.by_z ? (int64_t)p.splitk * p.group : (int64_t)p.splitk * p.tiles_m;
     dim3 grid((unsigned)(cdiv64(nunits, 8) * per_unit * 8)), block(WM * WN * 64);
 #if !defined(VAME_EMU) && defined(VAME_GEMM_AB)
     if (BM == 128 && BN == 128) {            // A/B tuning build only (make ab): variant chosen per call from the environment
@@ -334,7 +356,7 @@ extern "C" int vame_gemm_f32(int M, int N, int K, const float* A, int64_t lda, i
     p.A = {A, lda, a_seg, a_seg_stride, operand_vec(A, lda, a_seg, a_seg_stride), a_gap ? a_gap_at : 0x7fffffff, a_gap};
     p.B = {B, ldb, b_seg, b_seg_stride, operand_vec(B, ldb, b_seg, b_seg_stride), 0x7fffffff, 0};
     p.bias = bias; p.C = C; p.ldc = ldc; p.ws = ws;
-    p.M = M; p.N = N; p.K = K; p.accumulate = accumulate;
+    p.M = M; p.N = N; p.K = K; p.accumulate = accumulate; p.group = 1;
     int kper = (int)(cdiv64(cdiv64(K, splitk), 32) * 32);
     p.kper = kper;
     p.splitk = (int)cdiv64(K, kper);
@@ -363,5 +385,47 @@ extern "C" int vame_gemm_f32(int M, int N, int K, const float* A, int64_t lda, i
                            ldc, accumulate);
         VAME_LAUNCH_CHECK("gemm splitk reduce");
     }
+    return VAME_OK;
+}
+
+// Several weight-gradient style problems of one shape and layout in ONE launch: C_g = A_g^T B_g (or any supported layout) with
+// split-K >= 8.  The k-slabs of all problems are dealt to the XCDs together, so the launch has count x as many workgroups as a
+// single problem: fewer partial sums per problem for the same occupancy, no kernel boundary (and no idle tail) between the
+// problems, one reduction launch.  Only the operand base pointers differ between the problems.
+extern "C" int vame_gemm_group_f32(int count, int M, int N, int K, const float* const* A, int64_t lda, int a_kmajor, int64_t a_seg,
+                                   int64_t a_seg_stride, const float* const* B, int64_t ldb, int b_kmajor, int64_t b_seg,
+                                   int64_t b_seg_stride, float* const* C, int64_t ldc, int accumulate, int splitk, float* ws,
+                                   int a_gap_at, int a_gap, void* stream) {
+    VAME_CHECK_ARG(count >= 1 && count <= 8 && A && B && C && ws, VAME_E_BADARG, "gemm_group: count=%d (1..8) / null table", count);
+    VAME_CHECK_ARG(M >= 1 && N > 64 && K >= 1, VAME_E_SHAPE, "gemm_group: M=%d N=%d K=%d (needs N > 64)", M, N, K);
+    VAME_CHECK_ARG(!(a_kmajor && !b_kmajor), VAME_E_UNSUPPORTED, "gemm_group: A k-major with B n-major is not provided");
+    VAME_CHECK_ARG(a_gap == 0 || (a_kmajor && a_gap_at % 4 == 0 && a_gap % 4 == 0), VAME_E_BADARG,
+                   "gemm_group: a column gap needs a k-major A and multiples of 4");
+    GemmParams p;
+    int vecA = 1, vecB = 1;
+    for (int g = 0; g < count; ++g) {
+        VAME_CHECK_ARG(A[g] && B[g] && C[g], VAME_E_BADARG, "gemm_group: problem %d has a null operand", g);
+        p.gA[g] = A[g]; p.gB[g] = B[g];
+        vecA &= operand_vec(A[g], lda, a_seg, a_seg_stride);
+        vecB &= operand_vec(B[g], ldb, b_seg, b_seg_stride);
+    }
+    for (int g = count; g < 8; ++g) { p.gA[g] = A[0]; p.gB[g] = B[0]; }
+    p.A = {A[0], lda, a_seg, a_seg_stride, vecA, a_gap ? a_gap_at : 0x7fffffff, a_gap};
+    p.B = {B[0], ldb, b_seg, b_seg_stride, vecB, 0x7fffffff, 0};
+    p.bias = nullptr; p.C = C[0]; p.ldc = ldc; p.ws = ws;
+    p.M = M; p.N = N; p.K = K; p.accumulate = accumulate; p.group = count;
+    p.kper = (int)(cdiv64(cdiv64(K, splitk), 32) * 32);
+    p.splitk = (int)cdiv64(K, p.kper);
+    VAME_CHECK_ARG(p.splitk >= 8, VAME_E_SHAPE, "gemm_group: split-K %d < 8 (grouping is for large-K contractions)", p.splitk);
+    hipStream_t st = (hipStream_t)stream;
+    const int rc = launch_gemm<128, 128, 2, 2>(p, a_kmajor, b_kmajor, st);
+    VAME_CHECK_ARG(rc == VAME_OK, rc, "gemm_group: unsupported layout");
+    VAME_LAUNCH_CHECK("gemm_group");
+    GemmGroupOut out;
+    for (int g = 0; g < 8; ++g) out.C[g] = C[g < count ? g : 0];
+    const int64_t n = (int64_t)M * N;
+    const int blocks = (int)(cdiv64(n, 256) < 1024 ? cdiv64(n, 256) : 1024);
+    hipLaunchKernelGGL(splitk_reduce_group_kernel, dim3(blocks, count), dim3(256), 0, st, (const float*)ws, p.splitk, M, N, out, ldc, accumulate);
+    VAME_LAUNCH_CHECK("gemm_group reduce");
     return VAME_OK;
 }

@@ -107,6 +107,7 @@ class VAEEngine:
                      GruDir("decoder_future.rnn_pred", "_l0_reverse", H, Z, self.dev)] if spec.future else [])
         self.ws = Workspace()
         self._wgrad_queue = None
+        self.group_wgrads = os.environ.get("VAME_AMD_GROUP_WGRADS", "1") != "0"
         self._B_bwd = None
         self._side_streams = []
         self.small_streams = int(os.environ.get("VAME_AMD_SMALL_STREAMS", "3"))   # independent small GEMMs before the decoder launch
@@ -152,6 +153,42 @@ class VAEEngine:
         for s in shape:
             n *= s
         return self.ws.get(name, n, self.dev, zero=zero)
+
+    def _group_wgrads(self, jobs):
+        """Single-stream flush (large batches): weight-gradient GEMMs of one shape and operand layout -- the dW_hh of the six
+        T-step (layer, direction) streams, the two layer-1 dW_ih, the future decoder's two dW_hh -- go out as ONE grouped launch
+        each (vame_gemm_group_f32): all their k-slabs are dealt to the XCDs together, so nothing idles at the boundary between
+        them and each problem needs fewer partial sums for the same occupancy.  Returns the jobs left for single launches."""
+        if not self.group_wgrads:
+            return jobs
+        groups, rest = {}, []
+        for j in jobs:
+            M, N, K, A, Bop, gname, row_off, gap_at, gap = j
+            if N > 64 and K >= 8 * 256 and row_off == 0:
+                key = (M, N, K, A.ld, A.seg, A.seg_stride, Bop.ld, Bop.seg, Bop.seg_stride, gap_at, gap)
+                groups.setdefault(key, []).append(j)
+            else:
+                rest.append(j)
+        for key, members in groups.items():
+            if len(members) < 2:
+                rest += members
+                continue
+            M, N, K = key[:3]
+            for i in range(0, len(members), 8):
+                part = members[i:i + 8]
+                if len(part) < 2:
+                    rest += part
+                    continue
+                tiles = ((M + 127) // 128) * ((N + 127) // 128) * len(part)
+                # whole rounds of 3 workgroups per CU: the smallest multiple of 8 with >= 2 rounds (dynamic balancing between
+                # rounds), capped so that a workgroup keeps >= 8 k-tiles
+                cands = [k for k in range(8, 129, 8) if k * 8 * 32 <= K]
+                full = [k for k in cands if tiles * k >= 2 * 768 and (tiles * k) % 768 == 0]
+                sk = full[0] if full else next((k for k in cands if tiles * k >= 2 * 768), cands[-1] if cands else 8)
+                ws = self.ws.get("splitk_group", len(part) * sk * M * N, self.dev)
+                ops.gemm_group(M, N, K, [m[3] for m in part], 1, [m[4] for m in part], 1, self.g, [self.table.off(m[5]) for m in part],
+                               N, sk, ws, a_gap_at=key[9], a_gap=key[10])
+        return rest
 
     def _splitk(self, M, N, K):
         # ~3 workgroups per CU on all 256 CUs; with split-K >= 8 a whole k-slab lives on one XCD (gemm.hip
@@ -207,7 +244,7 @@ class VAEEngine:
             return
         n = (self.wgrad_streams or (4 if (self._B_bwd or 0) <= 1024 else 1)) if self.dev.type == "cuda" else 1
         if n < 2 or len(jobs) < 2:
-            for j in jobs:
+            for j in self._group_wgrads(jobs):
                 self._gemm_wgrad(*j)
             return
         while len(self._side_streams) < n - 1:

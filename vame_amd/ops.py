@@ -65,6 +65,24 @@ def gemm(M, N, K, A, a_kmajor, B, b_kmajor, C, ldc, c_off=0, bias=None, accumula
     _lib.check(rc, "vame_gemm_f32")
 
 
+def gemm_group(M, N, K, As, a_kmajor, Bs, b_kmajor, C, c_offs, ldc, splitk, ws, accumulate=False, a_gap_at=0, a_gap=0):
+    """len(As) problems of one shape / layout in one launch: C[c_offs[g] ...] (+)= op(As[g]) op(Bs[g]) (vame_gemm_group_f32).
+    As / Bs: Operands that differ only in their base (tensor + offset)."""
+    import ctypes
+    n = len(As)
+    a0, b0 = As[0], Bs[0]
+    assert all((o.ld, o.seg, o.seg_stride) == (a0.ld, a0.seg, a0.seg_stride) for o in As)
+    assert all((o.ld, o.seg, o.seg_stride) == (b0.ld, b0.seg, b0.seg_stride) for o in Bs)
+    assert ws is not None and ws.numel() >= n * splitk * M * N, "split-K workspace too small"
+    arr = ctypes.c_void_p * n
+    pa = arr(*[_ptr(o.t, o.off) for o in As])
+    pb = arr(*[_ptr(o.t, o.off) for o in Bs])
+    pc = arr(*[_ptr(C, off) for off in c_offs])
+    rc = _lib.lib().vame_gemm_group_f32(n, M, N, K, pa, a0.ld, int(a_kmajor), a0.seg, a0.seg_stride, pb, b0.ld, int(b_kmajor), b0.seg,
+                                        b0.seg_stride, pc, ldc, int(accumulate), splitk, _ptr(ws), a_gap_at, a_gap, _stream())
+    _lib.check(rc, "vame_gemm_group_f32")
+
+
 def window_gather(X, N, F, starts, start0, B, L, out):
     rc = _lib.lib().vame_window_gather_f32(_ptr(X), N, F, _ptr(starts), start0, B, L, _ptr(out), _stream())
     _lib.check(rc, "vame_window_gather_f32")
