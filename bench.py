@@ -152,10 +152,11 @@ def pmc_traffic(dom_key):
     with open(path) as f:
         j = json.load(f)
     if dom_key.startswith("gemm_kernel TN M=768 N=256 K=122880"):
-        per = j.get("gemm_TN_M768_N256_K122880_sk64", {}).get("hbm_bytes_per_launch_corrected")
-        if per is not None and " x" in dom_key and dom_key.endswith("grouped"):      # grouped launch: that many problems' operands
-            per *= int(dom_key.split(" x")[1].split()[0])
-        return per
+        if dom_key.endswith("x6 grouped"):
+            return j.get("gemm_TN_M768_N256_K122880_x6_grouped_sk32", {}).get("hbm_bytes_per_launch_corrected")
+        if "grouped" in dom_key:
+            return None
+        return j.get("gemm_TN_M768_N256_K122880_sk64", {}).get("hbm_bytes_per_launch_corrected")
     if dom_key.startswith("gru_seq_"):
         kind = "fwd" if "fwd" in dom_key else "bwd"
         grid = 262144 if "x4" in dom_key else 131072
