@@ -155,7 +155,7 @@ class VAEEngine:
         return self.ws.get(name, n, self.dev, zero=zero)
 
     def _group_wgrads(self, jobs):
-        """Single-stream flush (large batches): weight-gradient GEMMs of one shape and operand layout -- the dW_hh of the six
+        """Weight-gradient GEMMs of one shape and operand layout -- the dW_hh of the six
         T-step (layer, direction) streams, the two layer-1 dW_ih, the future decoder's two dW_hh -- go out as ONE grouped launch
         each (vame_gemm_group_f32): all their k-slabs are dealt to the XCDs together, so nothing idles at the boundary between
         them and each problem needs fewer partial sums for the same occupancy.  Returns the jobs left for single launches."""
@@ -243,8 +243,9 @@ class VAEEngine:
         if not jobs:
             return
         n = (self.wgrad_streams or (4 if (self._B_bwd or 0) <= 1024 else 1)) if self.dev.type == "cuda" else 1
+        jobs = self._group_wgrads(jobs)                  # same-shape contractions leave as grouped launches first
         if n < 2 or len(jobs) < 2:
-            for j in self._group_wgrads(jobs):
+            for j in jobs:
                 self._gemm_wgrad(*j)
             return
         while len(self._side_streams) < n - 1:
