@@ -322,7 +322,8 @@ def main():
         out = dict(metric=f"temporal windows/sec (train) T={T},F={F},h={H}", value=round(value, 1), unit="windows/s", n_gpus=world,
                    steps=args.steps, warmup=args.warmup, ms_per_step=round(dt / args.steps * 1e3, 3), higher_is_better=True,
                    scaling="weak", vs_baseline=None, dtype="f32", data="synthetic",
-                   config=dict(workload=(("BASELINE.json configs[1]" if world == 1 else f"BASELINE.json configs[2] shape on {world} GPUs (data-parallel)")
+                   config=dict(workload=((("BASELINE.json configs[1]" if (H, T, B_LOCAL) == (256, 30, 4096) else "non-headline shape (BASELINE.json configs[3] is H=512,T=60,batch 8192)")
+                                          if world == 1 else f"BASELINE.json configs[2] shape on {world} GPUs (data-parallel)")
                                          + f": T={T},F={F},zdims={Z},hidden={H},FS={FS}, batch={B_LOCAL}/GPU fp32 train step "
                                          "(gather+fwd+loss+bwd+allreduce+Adam-amsgrad)"), global_batch=B_LOCAL * world,
                                parallelism=f"dp{world}", last_loss_terms=last),
