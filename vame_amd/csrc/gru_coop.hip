@@ -217,10 +217,28 @@ static size_t coop_fwd_lds() {
 extern "C" int64_t vame_gru_coop_flag_ints(int nstreams, int B, int H) { return (int64_t)nstreams * cdiv64(B, 32) * (H / 32) + 16; }
 
 // 1 if (nstreams, B, H) can run cooperatively: every workgroup of the grid must be resident at once (one per CU)
+// compute units of the current device: every workgroup of a cooperative grid needs its own (LDS allows one per CU)
+static int coop_cu_count() {
+#ifdef VAME_EMU
+    return 256;
+#else
+    static int cus[64] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 0;
+    if (!cus[dev]) {
+        int n = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
+        cus[dev] = n;
+    }
+    return cus[dev];
+#endif
+}
+
 extern "C" int vame_gru_coop_supported(int nstreams, int B, int H) {
     if (H != 128 && H != 256) return 0;
     const int64_t groups = (int64_t)nstreams * cdiv64(B, 32);
-    return cdiv64(groups, 8) * 8 * (H / 32) <= 256;
+    const int64_t grid = cdiv64(groups, 8) * 8 * (H / 32);
+    return grid <= 256 && grid <= coop_cu_count();
 }
 // rows [row0, row0 + nrows) of the batch (row0 a multiple of 32; nrows = 0: all of it)
 static int coop_row_range(int B, int row0, int nrows, int& tile_off, int& ntiles) {

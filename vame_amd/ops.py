@@ -151,7 +151,7 @@ def coop_row_chunks(nstreams, B, H, max_rounds=2):
     if H not in (128, 256):
         return []
     cap = (256 // (H // 32) // 8 * 8) // nstreams * 32           # rows per launch: groups are dealt to XCDs in eights
-    if cap <= 0:
+    if cap <= 0 or not gru_coop_supported(nstreams, min(cap, B), H):   # (also checks the device's CU count)
         return []
     n = -(-B // cap)
     return [(r, min(cap, B - r)) for r in range(0, B, cap)] if n <= max_rounds else []
