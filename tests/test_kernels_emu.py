@@ -35,7 +35,7 @@ def test_elementwise(emu):
     check_adam(DEV)
 
 
-@pytest.mark.parametrize("B,Z,k", [(64, 30, 30), (8, 30, 30), (50, 7, 4)])
+@pytest.mark.parametrize("B,Z,k", [(64, 30, 30), (8, 30, 30), (50, 7, 4), (128, 34, 34), (96, 48, 20), (200, 64, 64), (70, 63, 63)])
 def test_nuclear(emu, B, Z, k):
     check_nuclear(DEV, B, Z, k)
 

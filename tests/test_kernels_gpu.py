@@ -32,7 +32,7 @@ def test_elementwise(hip):
     check_adam(DEV)
 
 
-@pytest.mark.parametrize("B,Z,k", [(64, 30, 30), (8, 30, 30), (50, 7, 4), (4096, 30, 30)])
+@pytest.mark.parametrize("B,Z,k", [(64, 30, 30), (8, 30, 30), (50, 7, 4), (4096, 30, 30), (128, 34, 34), (96, 48, 20), (4096, 64, 64), (70, 63, 63)])
 def test_nuclear(hip, B, Z, k):
     check_nuclear(DEV, B, Z, k)
 

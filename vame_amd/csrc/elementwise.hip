@@ -445,6 +445,7 @@ extern "C" int vame_kmeans_assign_f32(const float* X, int64_t N, int D, const fl
 // round-robin schedule gives Z/2 disjoint rotations per round, applied as a column pass and a row
 // pass.  One 256-thread workgroup; latency ~0.1 ms, run beside the decoder kernels.
 #define NUC_MAXZ 64
+#define NUC_BLK ((NUC_MAXZ / 2) * (NUC_MAXZ / 2) / 256)   /* 2x2 rotation blocks per thread at Z = NUC_MAXZ */
 #ifndef NUC_TOL
 #define NUC_TOL 1e-13   /* off-diagonal mass / diagonal mass at which the sweeps stop: eigenvalues to ~1e-13, eigenvectors to ~3e-7 relative -- below the fp32 Gram it starts from; 1e-20 costs one more sweep (+35 us) for the same loss */
 #endif
@@ -530,18 +531,23 @@ __global__ __launch_bounds__(256) void nuclear_kernel(const float* __restrict__ 
             __syncthreads();
             // A <- J^T A J in ONE pass: the pairs are disjoint, so the 2x2 block (pair P, pair Q) of the result depends only on
             // the same block of A: thread (P,Q) loads it, rotates rows by J_P and columns by J_Q, and writes it back in place
-            double blk[4];
-            int bp0 = 0, bp1 = 0, bq0 = 0, bq1 = 0;
-            const bool has_blk = tid < np * np;
-            if (has_blk) {
-                const int P = tid / np, Q = tid % np;
-                bp0 = pq[P]; bp1 = pq[P + 32]; bq0 = pq[Q]; bq1 = pq[Q + 32];
-                const double cp = cs[P], sp = cs[P + 32], cq = cs[Q], sq = cs[Q + 32];
-                const double a00 = A[bp0 * n + bq0], a01 = A[bp0 * n + bq1], a10 = A[bp1 * n + bq0], a11 = A[bp1 * n + bq1];
-                const double r00 = cp * a00 - sp * a10, r01 = cp * a01 - sp * a11;       // rows: J_P^T
-                const double r10 = sp * a00 + cp * a10, r11 = sp * a01 + cp * a11;
-                blk[0] = cq * r00 - sq * r01; blk[1] = sq * r00 + cq * r01;               // columns: J_Q
-                blk[2] = cq * r10 - sq * r11; blk[3] = sq * r10 + cq * r11;
+            // (np * np <= 1024 blocks for Z <= 64: up to NUC_BLK per thread, all read before the barrier, all written after it)
+            double blk[NUC_BLK][4];
+            int bidx[NUC_BLK][4];
+#pragma unroll
+            for (int u = 0; u < NUC_BLK; ++u) {
+                const int b = tid + u * 256;
+                if (b < np * np) {
+                    const int P = b / np, Q = b % np;
+                    const int bp0 = pq[P], bp1 = pq[P + 32], bq0 = pq[Q], bq1 = pq[Q + 32];
+                    const double cp = cs[P], sp = cs[P + 32], cq = cs[Q], sq = cs[Q + 32];
+                    bidx[u][0] = bp0 * n + bq0; bidx[u][1] = bp0 * n + bq1; bidx[u][2] = bp1 * n + bq0; bidx[u][3] = bp1 * n + bq1;
+                    const double a00 = A[bidx[u][0]], a01 = A[bidx[u][1]], a10 = A[bidx[u][2]], a11 = A[bidx[u][3]];
+                    const double r00 = cp * a00 - sp * a10, r01 = cp * a01 - sp * a11;       // rows: J_P^T
+                    const double r10 = sp * a00 + cp * a10, r11 = sp * a01 + cp * a11;
+                    blk[u][0] = cq * r00 - sq * r01; blk[u][1] = sq * r00 + cq * r01;         // columns: J_Q
+                    blk[u][2] = cq * r10 - sq * r11; blk[u][3] = sq * r10 + cq * r11;
+                }
             }
             for (int i = tid; i < np * n; i += 256) {       // V <- V J (columns; disjoint pairs, in place)
                 const int k = i / n, r = i % n;
@@ -551,9 +557,11 @@ __global__ __launch_bounds__(256) void nuclear_kernel(const float* __restrict__ 
                 V[r * n + p] = c * vp - s * vq; V[r * n + q] = s * vp + c * vq;
             }
             __syncthreads();                                  // every block has been read before any is overwritten
-            if (has_blk) {
-                A[bp0 * n + bq0] = blk[0]; A[bp0 * n + bq1] = blk[1]; A[bp1 * n + bq0] = blk[2]; A[bp1 * n + bq1] = blk[3];
-            }
+#pragma unroll
+            for (int u = 0; u < NUC_BLK; ++u)
+                if (tid + u * 256 < np * np) {
+                    A[bidx[u][0]] = blk[u][0]; A[bidx[u][1]] = blk[u][1]; A[bidx[u][2]] = blk[u][2]; A[bidx[u][3]] = blk[u][3];
+                }
             __syncthreads();
         }
     }
