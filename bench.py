@@ -130,40 +130,60 @@ def bench_embed(args, dev, rank, world):
     assert torch.isfinite(out).all()
     if rank == 0:
         value = n_win / dt
-        print(json.dumps(dict(metric="latent-embedding windows/sec (encoder + Lambda mean) T=30,F=24,h=256", value=round(value, 1),
-                              unit="windows/s", n_gpus=world, higher_is_better=True, scaling="weak", dtype="f32", data="synthetic",
-                              seconds=round(dt, 3), includes="host->device upload of the series + window gather + encoder + mean",
-                              config=dict(workload=f"BASELINE.json configs[4] shape: {args.embed_windows} stride-1 windows per GPU, batch 16384",
-                                          parallelism=f"shard{world}"),
-                              roofline=dict(bound="mfma", unit="TFLOP/s", peak=PEAK_F32_MFMA_TFLOPS,
-                                            achieved=round(value / world * 96.707e6 / 1e12, 2),
-                                            frac=round(value / world * 96.707e6 / 1e12 / PEAK_F32_MFMA_TFLOPS, 4), traffic=None))))
+        out = dict(metric="latent-embedding windows/sec (encoder + Lambda mean) T=30,F=24,h=256", value=round(value, 1),
+                   unit="windows/s", n_gpus=world, higher_is_better=True, scaling="weak", dtype="f32", data="synthetic",
+                   seconds=round(dt, 3), includes="host->device upload of the series + window gather + encoder + mean",
+                   config=dict(workload=f"BASELINE.json configs[4] shape: {args.embed_windows} stride-1 windows per GPU, batch 16384",
+                               parallelism=f"shard{world}"),
+                   roofline=dict(bound="mfma", unit="TFLOP/s", peak=PEAK_F32_MFMA_TFLOPS,
+                                 achieved=round(value / world * 96.707e6 / 1e12, 2),
+                                 frac=round(value / world * 96.707e6 / 1e12 / PEAK_F32_MFMA_TFLOPS, 4), traffic=None))
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline_embed()
+        print(json.dumps(out))
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
 
 
+def lib_sha256():
+    import hashlib
+    from vame_amd import _lib
+    with open(_lib.LIB_PATH, "rb") as f:
+        return hashlib.sha256(f.read()).hexdigest()
+
+
 def pmc_traffic(dom_key):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC summary (FETCH_SIZE x2 + WRITE_SIZE,
-    corrected as MI355X_MICROARCH.md prescribes; collected in separate --pmc passes, see profiles/).  None if not profiled."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")
-    if not os.path.exists(path):
-        return None
-    with open(path) as f:
-        j = json.load(f)
-    if dom_key.startswith("gemm_kernel TN M=768 N=256 K=122880"):
-        if dom_key.endswith("x6 grouped"):
-            return j.get("gemm_TN_M768_N256_K122880_x6_grouped_sk32", {}).get("hbm_bytes_per_launch_corrected")
-        if "grouped" in dom_key:
-            return None
-        return j.get("gemm_TN_M768_N256_K122880_sk64", {}).get("hbm_bytes_per_launch_corrected")
-    if dom_key.startswith("gru_seq_"):
-        kind = "fwd" if "fwd" in dom_key else "bwd"
-        grid = 262144 if "x4" in dom_key else 131072
-        for k, v in j.get("kernels", {}).items():
-            if f"gru_seq_{kind}_kernel" in k and k.endswith(f"grid={grid}"):
-                return v["hbm_bytes_per_call_corrected"]
+    """HBM bytes per launch of the dominant kernel from a committed rocprofv3 PMC summary (tools/pmc_summary.py: FETCH_SIZE x2 +
+    WRITE_SIZE in separate --pmc passes, corrected as MI355X_MICROARCH.md prescribes) -- but only from a summary that was
+    collected with THIS build of libvame_hip.so (its sha256 is stored in the summary); None otherwise: a number measured on an
+    older kernel says nothing about the current one."""
+    import glob
+    sha = lib_sha256()
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_hbm_traffic*.json")), reverse=True):
+        try:
+            with open(path) as f:
+                j = json.load(f)
+        except (OSError, ValueError):
+            continue
+        if j.get("lib_sha256") != sha:
+            continue
+        hit = j.get("by_bench_key", {}).get(dom_key)
+        if hit is not None:
+            return hit.get("hbm_bytes_per_launch_corrected")
     return None
+
+
+def _cpu_subprocess(fn_call, threads, timeout):
+    """Run `oracle.torch_ref.<fn_call>` in a subprocess (own thread pool, hard time limit) and return its dict."""
+    import subprocess
+    code = ("import json,sys; sys.path.insert(0, %r); from oracle import torch_ref as R; "
+            "print('CPUBASE ' + json.dumps(R.%s))" % (ROOT, fn_call.replace("THREADS", str(threads))))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=timeout)
+    for line in r.stdout.splitlines():
+        if line.startswith("CPUBASE "):
+            return json.loads(line[8:])
+    raise RuntimeError(r.stderr[-500:])
 
 
 def cpu_baseline():
@@ -172,22 +192,16 @@ def cpu_baseline():
     thread counts; the other count is only probed with 4 steps)."""
     import subprocess
     avail = len(os.sched_getaffinity(0))
-    code = ("import json,sys; sys.path.insert(0, %r); from oracle.torch_ref import time_train_steps; "
-            "print('CPUBASE ' + json.dumps(time_train_steps(B=256, steps=12, warmup=2, threads=int(sys.argv[1]))))" % ROOT)
     best, tried = None, []
     for threads, steps in ((min(avail, 16), 32), (min(avail, 64), 4)):   # torch-CPU GRUs stop scaling early: report the better count
         if any(t == threads for t, _ in tried):
             continue
         try:
-            r = subprocess.run([sys.executable, "-c", code.replace("steps=12", f"steps={steps}"), str(threads)], capture_output=True,
-                               text=True, timeout=120)
-            for line in r.stdout.splitlines():
-                if line.startswith("CPUBASE "):
-                    d = json.loads(line[8:])
-                    d["value"] = round(d["value"], 1)
-                    tried.append((threads, d["value"]))
-                    if best is None or d["value"] > best["value"]:
-                        best = d
+            d = _cpu_subprocess(f"time_train_steps(B=256, steps={steps}, warmup=2, threads=THREADS)", threads, 120)
+            d["value"] = round(d["value"], 1)
+            tried.append((threads, d["value"]))
+            if best is None or d["value"] > best["value"]:
+                best = d
         except subprocess.TimeoutExpired:
             print(f"cpu baseline with {threads} threads exceeded 120 s", file=sys.stderr)
     if best is not None:
@@ -195,6 +209,29 @@ def cpu_baseline():
         best["thread_counts_tried"] = tried
         return best
     return dict(value=None, unit="windows/s", cores=0, kind="port", sample="timed out on this host")
+
+
+def cpu_baseline_embed():
+    """CPU baseline of the embedding leg: the reference's batch-1 loop AS WRITTEN (pose_segmentation.py:87-98:
+    one window per forward) and a batch-256 variant of the same model, both on a bounded sample (about 10 s each)."""
+    import subprocess
+    avail = len(os.sched_getaffinity(0))
+    threads = min(avail, 16)
+    out = {}
+    for key, call in (("as_written_batch1", "time_embed(batch=1, budget_s=10.0, threads=THREADS)"),
+                      ("batch256", "time_embed(batch=256, budget_s=10.0, threads=THREADS)")):
+        try:
+            d = _cpu_subprocess(call, threads, 120)
+            d["value"] = round(d["value"], 1)
+            out[key] = d
+        except (subprocess.TimeoutExpired, RuntimeError) as e:
+            out[key] = dict(value=None, sample=f"failed: {type(e).__name__}")
+    best = max((d for d in out.values() if d.get("value")), key=lambda d: d["value"], default=None)
+    return dict(value=best["value"] if best else None, unit="windows/s", cores=threads, kind="port",
+                sample="embedding loop of oracle/torch_ref.py (stock torch nn.GRU encoder + mean head, eval mode): "
+                       + "; ".join(f"{k}: {d.get('value')} windows/s ({d.get('sample')})" for k, d in out.items()),
+                as_written_batch1=out["as_written_batch1"].get("value"), batch256=out["batch256"].get("value"),
+                host_cpus_visible=avail)
 
 
 def main():
@@ -216,23 +253,14 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    emu = os.environ.get("VAME_BENCH_EMU_LIB")       # CPU test-suite only (tests/test_distributed_cpu.py): the torchrun /
-    if emu:                                          # rank / JSON plumbing of this script over gloo on the host emulator build;
-        from vame_amd import _lib                    # nothing it prints is a measurement
-        _lib._load_for_tests(emu)
-        dev = torch.device("cpu")
-        torch.cuda.synchronize = lambda *a, **k: None
-    else:
-        if not torch.cuda.is_available():
-            raise SystemExit("bench.py needs an MI355X (no CPU fallback for the measured path)")
-        torch.cuda.set_device(local)
-        dev = torch.device("cuda", local)
+    from vame_amd import _lib
+    from vame_amd.model.rnn_vae import _maybe_init_distributed
+    dev = _lib.device(local)                         # raises without an MI355X: the measured path has no CPU fallback
+    on_gpu = dev.type == "cuda"                      # (False only under the CPU test-suite's harness, tests/emu/harness.py, which
+    sync = torch.cuda.synchronize if on_gpu else (lambda: None)      # checks the rank / JSON plumbing and measures nothing)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if emu:
-            dist.init_process_group("gloo")
-        else:
-            dist.init_process_group("nccl", device_id=dev)
+        _maybe_init_distributed()                    # one process per GPU: backend nccl (= RCCL over xGMI)
     assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     from vame_amd.model.dataloader import DeviceWindowLoader
@@ -273,11 +301,11 @@ def main():
         terms = step()
     if world > 1:
         dist.barrier()
-    torch.cuda.synchronize()
+    sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         terms = step()
-    torch.cuda.synchronize()
+    sync()
     if world > 1:
         dist.barrier()
     dt = time.perf_counter() - t0
@@ -290,35 +318,30 @@ def main():
 
     if rank == 0:
         value = B_LOCAL * world * args.steps / dt
-        if emu:
-            print(json.dumps(dict(metric="plumbing check only (host emulator)", value=round(value, 3), unit="windows/s", n_gpus=world,
-                                  steps=args.steps, warmup=args.warmup, data="synthetic", last_loss_terms=last)))
-            if world > 1:
-                dist.barrier()
-                dist.destroy_process_group()
-            return
-        agg = profile_kernels(model, loader)
-        total_ms = sum(d["ms"] for d in agg.values())
-        if args.dump_kernels:
-            for k, d in sorted(agg.items(), key=lambda kv: -kv[1]["ms"]):
-                print(f"{k:60s} x{d['launches']:4.0f} {d['ms']*1e3:9.1f} us/step {d['flops']/max(d['ms'],1e-9)/1e9:7.1f} TF", file=sys.stderr)
-        dom_key = max(agg, key=lambda k: agg[k]["ms"])
-        dom = agg[dom_key]
-        per_launch_ms = dom["ms"] / dom["launches"]
-        achieved = dom["flops"] / dom["launches"] / (per_launch_ms * 1e-3) / 1e12
-        classes = {}
-        for k, d in agg.items():
-            c = k.split(" ")[0] + (" " + k.split(" ")[1] if k.startswith("gemm") else "")
-            e = classes.setdefault(c, dict(ms=0.0, flops=0.0))
-            e["ms"] += d["ms"]
-            e["flops"] += d["flops"]
-        roof = dict(bound="mfma", kernel=dom_key, achieved=round(achieved, 3), peak=PEAK_F32_MFMA_TFLOPS, unit="TFLOP/s",
-                    frac=round(achieved / PEAK_F32_MFMA_TFLOPS, 4), traffic=pmc_traffic(dom_key),
-                    launch_ms=round(per_launch_ms, 4), launches_per_step=dom["launches"],
-                    step_frac=round(value / world * MFLOP_PER_WINDOW_TRAIN * 1e6 / (PEAK_F32_MFMA_TFLOPS * 1e12), 4),
-                    by_class={c: dict(ms_per_step=round(e["ms"], 3), tflops=round(e["flops"] / (e["ms"] * 1e-3) / 1e12, 2))
-                              for c, e in classes.items()},
-                    timed_kernel_ms_per_step=round(total_ms, 3))
+        roof = None
+        if on_gpu:
+            agg = profile_kernels(model, loader)
+            total_ms = sum(d["ms"] for d in agg.values())
+            if args.dump_kernels:
+                for k, d in sorted(agg.items(), key=lambda kv: -kv[1]["ms"]):
+                    print(f"{k:60s} x{d['launches']:4.0f} {d['ms']*1e3:9.1f} us/step {d['flops']/max(d['ms'],1e-9)/1e9:7.1f} TF", file=sys.stderr)
+            dom_key = max(agg, key=lambda k: agg[k]["ms"])
+            dom = agg[dom_key]
+            per_launch_ms = dom["ms"] / dom["launches"]
+            achieved = dom["flops"] / dom["launches"] / (per_launch_ms * 1e-3) / 1e12
+            classes = {}
+            for k, d in agg.items():
+                c = k.split(" ")[0] + (" " + k.split(" ")[1] if k.startswith("gemm") else "")
+                e = classes.setdefault(c, dict(ms=0.0, flops=0.0))
+                e["ms"] += d["ms"]
+                e["flops"] += d["flops"]
+            roof = dict(bound="mfma", kernel=dom_key, achieved=round(achieved, 3), peak=PEAK_F32_MFMA_TFLOPS, unit="TFLOP/s",
+                        frac=round(achieved / PEAK_F32_MFMA_TFLOPS, 4), traffic=pmc_traffic(dom_key),
+                        launch_ms=round(per_launch_ms, 4), launches_per_step=dom["launches"],
+                        step_frac=round(value / world * MFLOP_PER_WINDOW_TRAIN * 1e6 / (PEAK_F32_MFMA_TFLOPS * 1e12), 4),
+                        by_class={c: dict(ms_per_step=round(e["ms"], 3), tflops=round(e["flops"] / (e["ms"] * 1e-3) / 1e12, 2))
+                                  for c, e in classes.items()},
+                        timed_kernel_ms_per_step=round(total_ms, 3))
         out = dict(metric=f"temporal windows/sec (train) T={T},F={F},h={H}", value=round(value, 1), unit="windows/s", n_gpus=world,
                    steps=args.steps, warmup=args.warmup, ms_per_step=round(dt / args.steps * 1e3, 3), higher_is_better=True,
                    scaling="weak", vs_baseline=None, dtype="f32", data="synthetic",
@@ -328,7 +351,7 @@ def main():
                                          "(gather+fwd+loss+bwd+allreduce+Adam-amsgrad)"), global_batch=B_LOCAL * world,
                                parallelism=f"dp{world}", last_loss_terms=last),
                    roofline=roof)
-        if not args.no_cpu_baseline and world == 1:
+        if not args.no_cpu_baseline and world == 1 and on_gpu:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out))
     if world > 1:

@@ -153,9 +153,17 @@ int vame_colsum_f32(const float* in, int64_t R, int C, int64_t ld, float* out, i
 int vame_colsum_batch_f32(const int64_t* desc, int njobs, void* stream);
 
 /* Fused Adam with AMSGrad over a flat parameter buffer (torch.optim.Adam(amsgrad=True), rnn_vae.py:332,143).
- * gscale multiplies the gradient first (1/world_size after an all-reduce SUM). */
+ * gscale multiplies the gradient first (1/world_size after an all-reduce SUM).  abort_flag (optional device word): when it is
+ * non-zero at execution time the launch changes nothing -- the status word of the cooperative GRU launches goes here, so a step
+ * whose gradients are undefined never reaches the weights (the host raises when it next reads the word). */
 int vame_adam_amsgrad_f32(float* p, const float* g, float* m, float* v, float* vmax, int64_t n, float lr,
-                          float beta1, float beta2, float eps, int step, float gscale, void* stream);
+                          float beta1, float beta2, float eps, int step, float gscale, const int* abort_flag, void* stream);
+
+/* Encoder inter-layer dropout (torch.nn.GRU(dropout=p) at rnn_model.py:34-35, training only): out[r][c] = x[row(r)][c] * mask[r][c] * scale
+ * over R x C, mask in {0,1}, scale = 1/(1-p).  x rows: seg = 0 -> r*ld + off, else (r/seg)*seg_stride + (r%seg)*ld + off (the padded
+ * sequence layout); mask / out dense (R, C); C % 4 == 0; in-place on a dense x is allowed (the backward of the same op). */
+int vame_mask_scale_f32(const float* x, int64_t off, int64_t ld, int64_t seg, int64_t seg_stride, const float* mask, float scale,
+                        float* out, int64_t R, int C, void* stream);
 
 /* y = a*x + y style helpers for the host orchestration */
 int vame_axpy_f32(const float* x, float a, float* y, int64_t n, void* stream);
@@ -167,7 +175,11 @@ int vame_axpy_f32(const float* x, float a, float* y, int64_t n, void* stream);
  * passed back; epoch_base: a value that grows by more than T between launches sharing `flags`; *status is incremented if a
  * bounded poll ever expires (results are then undefined, the launch still terminates). */
 int64_t vame_gru_coop_flag_ints(int nstreams, int B, int H);
-int vame_gru_coop_supported(int nstreams, int B, int H);
+int vame_gru_coop_supported(int nstreams, int B, int H);   /* grid <= CUs and the runtime's occupancy query admits each kernel */
+/* Poll budget of one hand-off wait (0 = default, about 0.3 s on the device); returns the previous value.  Process-wide;
+ * for diagnostics.  polls < 0 = fault injection: every cooperative launch reports one timeout through *status although its
+ * hand-offs complete (tests of the failure path: optimizer step dropped on the device, host exception). */
+int vame_gru_coop_set_poll_limit(int polls);
 int vame_gru_coop_fwd_f32(const int64_t* desc, int nstreams, int B, int H, int row0, int nrows, int* flags, int epoch_base, int* status,
                           void* stream);   /* rows [row0, row0+nrows) of the batch, row0 % 32 == 0; nrows = 0: all rows */
 /* BPTT counterpart (contract of vame_gru_seq_bwd_f32; results equal up to the summation order of the K = 3H contraction, which is

@@ -147,3 +147,37 @@ def time_train_steps(B=256, steps=10, warmup=3, threads=None, seed=19, budget_s=
     return dict(value=B * steps / dt, unit="windows/s", cores=threads, kind="port",
                 sample=f"{steps} train steps of B={B} (T=30,F=24,H=256,Z=30,FS=15, fp32, torch {torch.__version__} CPU nn.GRU + (B,B) svd "
                        f"+ Adam-amsgrad), {dt:.1f} s")
+
+
+def time_embed(batch=1, budget_s=10.0, threads=None, seed=19, n_frames=200_000):
+    """CPU baseline of the embedding leg: the reference's loop (vame/analysis/pose_segmentation.py:87-98) -- window i of the (F,N)
+    series -> (batch,T,F) float32 -> encoder -> mean head, eval mode -- with `batch` windows per forward (1 = as written).
+    Bounded: stops after `budget_s` seconds of timed work."""
+    import os
+    import time
+    import numpy as np
+    threads = threads or len(os.sched_getaffinity(0))
+    torch.set_num_threads(threads)
+    torch.manual_seed(seed)
+    m = TorchRef()
+    m.eval()
+    T = m.T
+    rng = np.random.default_rng(0)
+    data = rng.standard_normal((m.F, n_frames)).astype(np.float32)
+    done, t0 = 0, None
+    with torch.no_grad():
+        i = 0
+        for it in range(10 ** 9):
+            if it == 2:
+                t0, done = time.perf_counter(), 0
+            x = torch.from_numpy(np.stack([data[:, j:j + T].T for j in range(i, i + batch)]))
+            _, hn = m.rnn["enc"](x)
+            mu = m.lin["mean"](torch.cat([hn[0], hn[1], hn[2], hn[3]], 1))
+            mu.numpy()
+            i = (i + batch) % (n_frames - T - batch)
+            done += batch
+            if t0 is not None and time.perf_counter() - t0 > budget_s:
+                break
+    dt = time.perf_counter() - t0
+    return dict(value=done / dt, unit="windows/s", cores=threads, kind="port",
+                sample=f"{done} windows in {dt:.1f} s, batch {batch}, torch {torch.__version__} CPU nn.GRU")

@@ -114,6 +114,7 @@ class Spec:
     FS: int = 15
     future: bool = True
     softplus: bool = False
+    dropout: float = 0.0   # dropout_encoder: nn.GRU(dropout=p) between the two encoder layers, training only (rnn_model.py:34-35)
 
 
 @dataclass
@@ -121,16 +122,22 @@ class FwdCache:
     items: dict = field(default_factory=dict)
 
 
-def encoder_forward(p, x, cache=None):
-    """rnn_model.py:40-45 : 2-layer bi-GRU, returns cat(h_n[0..3]) = [l0f|l0b|l1f|l1b]."""
+def encoder_forward(p, x, cache=None, drop_mask=None, dropout=0.0):
+    """rnn_model.py:40-45 : 2-layer bi-GRU, returns cat(h_n[0..3]) = [l0f|l0b|l1f|l1b].
+    drop_mask (B,T,2H) in {0,1} with dropout = p: torch.nn.GRU's inter-layer dropout in training (rnn_model.py:34-35) -- layer 1
+    reads y0 * mask / (1-p); the final states of layer 0 are returned undropped."""
     pre = "encoder.encoder_rnn"
     o0f, h0f, c0f = gru_dir_forward(x, None, *_gru_params(p, pre, 0, False), reverse=False)
     o0b, h0b, c0b = gru_dir_forward(x, None, *_gru_params(p, pre, 0, True), reverse=True)
     y0 = np.concatenate([o0f, o0b], 2)
+    dscale = None
+    if drop_mask is not None and dropout > 0:
+        dscale = (_f32(drop_mask) / F32(1.0 - dropout)).astype(F32)
+        y0 = (y0 * dscale).astype(F32)
     o1f, h1f, c1f = gru_dir_forward(y0, None, *_gru_params(p, pre, 1, False), reverse=False)
     o1b, h1b, c1b = gru_dir_forward(y0, None, *_gru_params(p, pre, 1, True), reverse=True)
     if cache is not None:
-        cache.items.update(x=x, y0=y0, c0f=c0f, c0b=c0b, c1f=c1f, c1b=c1b)
+        cache.items.update(x=x, y0=y0, c0f=c0f, c0b=c0b, c1f=c1f, c1b=c1b, dscale=dscale)
     return np.concatenate([h0f, h0b, h1f, h1b], 1)
 
 
@@ -173,9 +180,9 @@ def decoder_forward(p, z, steps, name, rnn, cache=None):
     return pred
 
 
-def model_forward(p, x, eps, spec, training=True, cache=None):
+def model_forward(p, x, eps, spec, training=True, cache=None, drop_mask=None):
     """RNN_VAE.forward, rnn_model.py:162-179.  x (B,T,F) f32."""
-    h_n = encoder_forward(p, x, cache)
+    h_n = encoder_forward(p, x, cache, drop_mask if training else None, spec.dropout)
     z, mu, lv = lambda_forward(p, h_n, eps, spec, training, cache)
     pred = decoder_forward(p, z, spec.T, "decoder", "rnn_rec", cache)
     fut = decoder_forward(p, z, spec.FS, "decoder_future", "rnn_pred", cache) if spec.future else None
@@ -323,6 +330,8 @@ def model_backward(p, cache, spec, x, xfut, kl_weight, beta=1.0, kloss=None, klm
         g[f"{pre}.bias_ih{sfx}"] += dbi
         g[f"{pre}.bias_hh{sfx}"] += dbh
         dy0 += dx
+    if c.get("dscale") is not None:
+        dy0 = (dy0 * c["dscale"]).astype(F32)
     for rev, cc, off in ((False, c["c0f"], 0), (True, c["c0b"], H)):
         W_ih, W_hh, _, _ = _gru_params(p, pre, 0, rev)
         sl = slice(0, H) if not rev else slice(H, 2 * H)

@@ -28,21 +28,23 @@ def golden():
     return load_golden
 
 
+sys.path.insert(0, os.path.join(ROOT, "tests", "emu"))
+
+
 def _reset_lib():
+    import harness
     from vame_amd import _lib
+    harness.uninstall()
     _lib._lib = None
-    _lib._emulated = False
 
 
 @pytest.fixture(scope="module")
 def emu():
-    """Bind vame_amd to the host-emulated build of the kernel sources (tests/emu) for this module."""
-    import subprocess
-    from vame_amd import _lib
-    so = os.path.join(ROOT, "tests", "emu", "libvame_emu.so")
-    subprocess.run(["make", "-s", "tests/emu/libvame_emu.so"], cwd=ROOT, check=True)
-    _lib._load_for_tests(so)
-    yield _lib
+    """Run vame_amd on the host-emulated build of the kernel sources (tests/emu/harness.py) for this module."""
+    import harness
+    harness.build()
+    lib = harness.install()
+    yield lib
     _reset_lib()
 
 

@@ -1,0 +1,224 @@
+"""End-to-end checks of vame.train_model() / vame.pose_segmentation() (and the next-row drivers) on a synthetic project (config 1
+shape of BASELINE.json, tiny hidden size): file layout, loss arrays, checkpoint format, the embedding output contract -- compared
+with the run of the REFERENCE driver captured in tests/golden/train_model_run.npz.  Shared by test_train_driver_emu.py (host
+emulator) and test_train_driver_gpu.py (MI355X, -m gpu)."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+import yaml
+
+from conftest import load_golden
+
+
+def make_project(tmp_path_factory):
+    g = load_golden("train_model_run")
+    cfg = json.loads(str(g["cfg_json"]))
+    root = tmp_path_factory.mktemp("proj")
+    os.makedirs(root / "data" / "train")
+    os.makedirs(root / "model")
+    np.save(root / "data" / "train" / "train_seq.npy", g["train_seq"])
+    np.save(root / "data" / "train" / "test_seq.npy", g["test_seq"])
+    cfg.update(project_path=str(root), n_cluster=4, parameterization="kmeans", individual_parameterization=False,
+               video_sets=["vid1"], all_data="yes", hmm_trained=False, random_state_kmeans=42, n_init_kmeans=3)
+    os.makedirs(root / "data" / "vid1")
+    np.save(root / "data" / "vid1" / "vid1-PE-seq-clean.npy", g["train_seq"][:, :120])
+    os.makedirs(root / "results" / "vid1")
+    with open(root / "config.yaml", "w") as f:
+        yaml.safe_dump(cfg, f)
+    return root, cfg, g
+
+
+def check_train_model_files_and_losses(project):
+    import vame_amd as vame
+    root, cfg, g = project
+    np.random.seed(0)
+    vame.train_model(str(root / "config.yaml"))
+    ld = root / "model" / "model_losses"
+    names = sorted(os.listdir(ld))
+    assert names == sorted(k + ".npy" for k in g if k.endswith("_VAME"))
+    for n in names:
+        mine, ref = np.load(ld / n), g[n[:-4]]
+        assert mine.shape == ref.shape, n
+    # same annealing schedule; first-epoch losses are the untrained model on statistically identical batches
+    np.testing.assert_allclose(np.load(ld / "weight_values_VAME.npy"), g["weight_values_VAME"])
+    mine, ref = np.load(ld / "mse_train_losses_VAME.npy"), g["mse_train_losses_VAME"]
+    assert abs(mine[0] - ref[0]) / ref[0] < 0.1
+    assert mine[-1] < mine[0]                                   # it learns
+    assert sorted(os.listdir(root / "model" / "best_model")) == list(g["files_best"])
+    assert sorted(os.listdir(root / "model" / "best_model" / "snapshots")) == list(g["files_snap"])
+    sd = torch.load(root / "model" / "best_model" / "VAME_demo.pkl", map_location="cpu")
+    assert list(sd.keys()) == list(g["sd_keys"])
+    assert [str(tuple(v.shape)) for v in sd.values()] == list(g["sd_shapes"])
+    assert os.path.exists(root / "data" / "train" / "seq_mean.npy")
+
+
+def check_pose_segmentation_outputs(project):
+    import vame_amd as vame
+    root, cfg, g = project
+    vame.pose_segmentation(str(root / "config.yaml"))
+    out = root / "results" / "vid1" / "VAME" / "kmeans-4"
+    lat = np.load(out / "latent_vector_vid1.npy")
+    assert lat.shape == (120 - cfg["time_window"], cfg["zdims"]) and lat.dtype == np.float32     # N-T windows
+    lab = np.load(out / "4_km_label_vid1.npy")
+    assert lab.shape == (lat.shape[0],) and set(np.unique(lab)) <= set(range(4))
+    assert np.load(out / "cluster_center_vid1.npy").shape == (4, cfg["zdims"])
+    assert np.load(out / "motif_usage_vid1.npy").sum() == lat.shape[0]
+    # the embedding is the eval-mode mean of the trained model on un-normalised windows (pose_segmentation.py:84-96)
+    from oracle import vame_oracle as vo
+    sd = torch.load(root / "model" / "best_model" / "VAME_demo.pkl", map_location="cpu")
+    p = {k: v.numpy() for k, v in sd.items()}
+    H = cfg["hidden_size_layer_1"]
+    ref = vo.embed_series(p, np.load(root / "data" / "vid1" / "vid1-PE-seq-clean.npy"),
+                          vo.Spec(T=30, F=24, Z=30, H=H, FS=15), batch=64)
+    np.testing.assert_allclose(lat, ref, atol=2e-5)
+
+
+def _oracle_params(root, cfg):
+    from oracle import vame_oracle as vo
+    sd = torch.load(root / "model" / "best_model" / "VAME_demo.pkl", map_location="cpu")
+    return vo, {k: v.numpy() for k, v in sd.items()}, vo.Spec(T=30, F=24, Z=30, H=cfg["hidden_size_layer_1"], FS=15)
+
+
+def check_evaluate_model_outputs(project):
+    """vame.evaluate_model (evaluate.py:169-215): PNGs under model/evaluate/ and the plotted numbers = eval-mode forward
+    of 64 random z-scored test windows (mu feeds both decoders)."""
+    import vame_amd as vame
+    from vame_amd.model import evaluate as ev
+    root, cfg, g = project
+    vame.evaluate_model(str(root / "config.yaml"))
+    made = sorted(os.listdir(root / "model" / "evaluate"))
+    assert made == ["Future_Reconstruction.png", "MSE-and-KL-LossVAME.png"]
+    assert all(os.path.getsize(root / "model" / "evaluate" / m) > 2000 for m in made)
+    from vame_amd.util.auxiliary import read_config
+    np.random.seed(5)
+    r = ev.eval_temporal(read_config(str(root / "config.yaml")), False, "VAME", cfg["egocentric_data"])
+    assert r["data"].shape == (64, 30, 24) and r["fut"].shape == (64, 15, 24)
+    # the windows are the reference batcher's: z-scored with the TRAIN mean/std, starts from the global numpy stream
+    X = np.load(root / "data" / "train" / "test_seq.npy")
+    m, sdv = np.load(root / "data" / "train" / "seq_mean.npy"), np.load(root / "data" / "train" / "seq_std.npy")
+    np.random.seed(5)
+    st = np.random.randint(0, X.shape[1] - 60, size=64)
+    win = np.stack([((X[:, s:s + 60] - m) / sdv).T for s in st]).astype(np.float32)
+    np.testing.assert_array_equal(r["data"], win[:, :30])
+    np.testing.assert_array_equal(r["fut_orig"], win[:, 30:45])
+    vo, p, spec = _oracle_params(root, cfg)
+    pred, fut, z, mu, lv = vo.model_forward(p, win[:, :30], None, spec, training=False)
+    np.testing.assert_allclose(r["data_tilde"], pred, atol=2e-5)
+    np.testing.assert_allclose(r["fut"], fut, atol=2e-5)
+    np.testing.assert_allclose(r["mu"], mu, atol=2e-5)
+    np.testing.assert_array_equal(r["latent"], r["mu"])                     # eval: z = mu (rnn_model.py:75-76)
+    # snapshots: one PNG per snapshot file, named like the reference (suffix = 'snapshot' + last '_' token)
+    vame.evaluate_model(str(root / "config.yaml"), use_snapshots=True)
+    assert len(os.listdir(root / "model" / "evaluate")) == 2               # future-decoder runs overwrite one file
+
+
+def check_generative_model_modes(project):
+    """generative_functions.py: every mode ends in model.decoder(tiled z, z); check against the oracle decoder, incl. the
+    h0 .view mixing across the samples of one call (order matters)."""
+    from vame_amd.analysis import generative_functions as gf
+    root, cfg, g = project
+    cfg = dict(cfg, egocentric_data=False, num_features=26)               # the generative loader always drops 2 columns
+    import yaml as _y
+    with open(root / "config_gen.yaml", "w") as f:
+        _y.safe_dump(cfg, f)
+    os.replace(root / "config_gen.yaml", root / "config.yaml")
+    vo, p, spec = _oracle_params(root, cfg)
+    out = root / "results" / "vid1" / "VAME" / "kmeans-4"
+    centers = np.load(out / "cluster_center_vid1.npy")
+    res = gf.generative_model(str(root / "config.yaml"), mode="centers")["vid1"]
+    assert res.shape == (4, 30, 24)
+    np.testing.assert_allclose(res, vo.decoder_forward(p, centers.astype(np.float32), 30, "decoder", "rnn_rec"), atol=2e-5)
+    lat = np.load(out / "latent_vector_vid1.npy")
+    np.random.seed(3)
+    res = gf.generative_model(str(root / "config.yaml"), mode="reconstruction")["vid1"]
+    np.random.seed(3)
+    pick = np.random.choice(lat.shape[0], 10)
+    np.testing.assert_allclose(res, vo.decoder_forward(p, lat[pick], 30, "decoder", "rnn_rec"), atol=2e-5)
+    res = gf.generative_model(str(root / "config.yaml"), mode="sampling")["vid1"]
+    assert res.shape == (10, 30, 24) and np.isfinite(res).all()
+    model = gf.load_model(cfg, "VAME")
+    perm = gf.decode_latents(model, centers[::-1].copy(), 30)[::-1]
+    assert np.abs(perm - gf.decode_latents(model, centers, 30)).max() > 1e-4   # cross-sample h0 mixing is reproduced
+    import matplotlib.pyplot as plt
+    plt.close("all")
+
+
+def check_train_model_legacy_topology(project, tmp_path):
+    """cfg['legacy'] = True trains RNN_VAE_LEGACY (rnn_vae.py:294-297): checkpoint keys / shapes of the legacy model."""
+    import shutil
+    import vame_amd as vame
+    from vame_amd.model.rnn_model import RNN_VAE_LEGACY
+    root, cfg, g = project
+    lroot = tmp_path / "legacy"
+    shutil.copytree(root / "data", lroot / "data")
+    os.makedirs(lroot / "model")
+    lcfg = dict(cfg, project_path=str(lroot), legacy=True, max_epochs=3, model_snapshot=50, kl_start=0, annealtime=1)
+    with open(lroot / "config.yaml", "w") as f:
+        yaml.safe_dump(lcfg, f)
+    np.random.seed(1)
+    vame.train_model(str(lroot / "config.yaml"))
+    sd = torch.load(lroot / "model" / "best_model" / "VAME_demo.pkl", map_location="cpu")
+    H = cfg["hidden_size_layer_1"]
+    ref = RNN_VAE_LEGACY(60, 30, 24, 1, 15, H, H, H, H, 0, 0, 0, False).state_dict()
+    assert list(sd.keys()) == list(ref.keys()) and all(sd[k].shape == ref[k].shape for k in sd)
+    assert "decoder.rnn_rec.weight_ih_l0_reverse" not in sd and "lmbda.hidden_to_linear.weight" in sd
+    losses = np.load(lroot / "model" / "model_losses" / "train_losses_VAME.npy")
+    assert losses.shape == (2,) and np.isfinite(losses).all()
+    with pytest.raises(NotImplementedError):
+        vame.pose_segmentation(str(lroot / "config.yaml"))
+
+
+def check_create_trainset_files(tmp_path):
+    """vame.create_trainset (create_training.py:267-300): train/test split + per-video clean files, equal to the files the
+    REFERENCE wrote for the same inputs (tests/golden/prep_*.npz)."""
+    import vame_amd as vame
+    for name, fixed in (("prep_aligned", False), ("prep_fixed", True)):
+        g = load_golden(name)
+        root = tmp_path / name
+        for f, k in (("vidA", "in0"), ("vidB", "in1")):
+            os.makedirs(root / "data" / f)
+            np.save(root / "data" / f / (f + "-PE-seq.npy"), g[k])
+        cfg = dict(project_path=str(root), Project="demo", legacy=False, egocentric_data=fixed, all_data="yes", video_sets=["vidA", "vidB"],
+                   robust=True, iqr_factor=int(g["params"][0]), savgol_filter=True, savgol_length=int(g["params"][1]),
+                   savgol_order=int(g["params"][2]), test_fraction=float(g["params"][3]), num_features=26)
+        with open(root / "config.yaml", "w") as f:
+            yaml.safe_dump(cfg, f)
+        vame.create_trainset(str(root / "config.yaml"))
+        np.testing.assert_array_equal(np.load(root / "data" / "train" / "train_seq.npy"), g["train"])
+        np.testing.assert_array_equal(np.load(root / "data" / "train" / "test_seq.npy"), g["test"])
+        np.testing.assert_array_equal(np.load(root / "data" / "vidA" / "vidA-PE-seq-clean.npy"), g["clean0"])
+        np.testing.assert_array_equal(np.load(root / "data" / "vidB" / "vidB-PE-seq-clean.npy"), g["clean1"])
+        vame.create_trainset(str(root / "config.yaml"), check_parameter=True)          # plots only, writes nothing new
+    import matplotlib.pyplot as plt
+    plt.close("all")
+
+
+def check_read_config_contract(tmp_path):
+    from vame_amd.util.auxiliary import read_config
+    with pytest.raises(FileNotFoundError):
+        read_config(tmp_path / "missing.yaml")
+    p = tmp_path / "config.yaml"
+    with open(p, "w") as f:
+        yaml.safe_dump(dict(project_path="/somewhere/else", Project="x"), f)
+    cfg = read_config(str(p))
+    assert cfg["project_path"] == str(tmp_path)                 # rewritten when the folder moved (auxiliary.py:139-142)
+    assert yaml.safe_load(open(p))["project_path"] == str(tmp_path)
+
+
+def check_parameterization_with_gpu_kmeans_option():
+    """cfg['amd_gpu_kmeans'] routes same_/individual_parameterization through KMeansHIP with the same return contract."""
+    from vame_amd.analysis.pose_segmentation import individual_parameterization, same_parameterization
+    rng = np.random.default_rng(1)
+    cent = rng.standard_normal((4, 30)) * 5
+    lat = [(cent[rng.integers(0, 4, n)] + 0.3 * rng.standard_normal((n, 30))).astype(np.float32) for n in (90, 70)]
+    cfg = dict(amd_gpu_kmeans=True, random_state_kmeans=42, n_init_kmeans=2, project_path="/tmp")
+    for fn, args in ((same_parameterization, (cfg, ["a", "b"], lat, 4, "kmeans")), (individual_parameterization, (cfg, ["a", "b"], lat, 4))):
+        labels, centers, usage = fn(*args)
+        assert [len(l) for l in labels] == [90, 70] and all(c.shape == (4, 30) for c in centers)
+        assert all(u.sum() == n for u, n in zip(usage, (90, 70)))
+        ref, _, _ = fn(dict(cfg, amd_gpu_kmeans=False), *args[1:])
+        from sklearn.metrics import adjusted_rand_score
+        assert all(adjusted_rand_score(a, b) == 1.0 for a, b in zip(labels, ref))

@@ -335,7 +335,57 @@ def prep_fixture():
         np.savez_compressed(os.path.join(OUT, "prep_fixed.npz" if fixed else "prep_aligned.npz"), **out)
 
 
+def options_fixture(rnn_model, rnn_vae):
+    """Model options a stock config.yaml leaves at their defaults: encoder inter-layer dropout (dropout_encoder > 0,
+    rnn_model.py:31-35) and decoder hidden sizes that differ from the encoder's (hidden_size_rec / hidden_size_pred,
+    rnn_model.py:148-160).  One train step of the reference each: outputs, loss terms, every gradient.
+    The dropout keep-mask is reproduced from the torch CPU stream: nn.GRU draws `empty(T,B,2H).bernoulli_(1-p)` between its
+    layers (time-major even with batch_first), then Lambda draws randn_like -- checked below against the reference's own z."""
+    T, Z, F, FS, B = 30, 30, 24, 15, 8
+    X = synth_series(F, 400, seed=1)
+    Xn = (X - X.mean()) / X.std()
+    starts = np.random.RandomState(3).randint(0, 400 - 2 * T, size=B)
+    item = torch.from_numpy(np.stack([Xn[:, s:s + 2 * T] for s in starts])).permute(0, 2, 1)
+    data = item[:, :T, :].type("torch.FloatTensor")
+    fut_t = item[:, T:T + FS, :].type("torch.FloatTensor")
+    for name, (h1, h2, hrec, hpred, pdrop) in (("step_tiny_dropout", (32, 32, 32, 32, 0.25)), ("step_tiny_hsizes", (32, 64, 64, 96, 0.0))):
+        torch.manual_seed(19)
+        model = rnn_model.RNN_VAE(2 * T, Z, F, 1, FS, h1, h2, hrec, hpred, pdrop, 0, 0, False)
+        model.train()
+        out = {"w/" + k: v for k, v in sd_numpy(model).items()}
+        torch.manual_seed(4321)
+        if pdrop > 0:
+            mask_tb = torch.empty(T, B, 2 * h1).bernoulli_(1 - pdrop)
+            out["drop_mask"] = mask_tb.permute(1, 0, 2).contiguous().numpy()          # (B, T, 2H), keep = 1
+        eps = torch.randn(B, Z)
+        torch.manual_seed(4321)
+        pred, futp, z, mu, lv = model(data)
+        np.testing.assert_allclose(z.detach().numpy(), (eps * torch.exp(0.5 * lv) + mu).detach().numpy(), atol=1e-6)
+        kw = 0.5
+        rec = rnn_vae.reconstruction_loss(data, pred, "sum")
+        fl = rnn_vae.future_reconstruction_loss(fut_t, futp, "sum")
+        km = rnn_vae.cluster_loss(z.T, Z, 0.1, B)
+        kl = rnn_vae.kullback_leibler_loss(mu, lv)
+        (rec + fl + 1.0 * kw * kl + kw * km).backward()
+        out.update(x=data.numpy().copy(), xfut=fut_t.numpy().copy(), eps=eps.numpy(), pred=pred.detach().numpy(), fut=futp.detach().numpy(),
+                   z=z.detach().numpy(), mu=mu.detach().numpy(), logvar=lv.detach().numpy(),
+                   losses=np.array([rec.item(), fl.item(), kl.item(), km.item()]), kw=np.array([kw]),
+                   spec=np.array([T, F, Z, h1, FS, 1, 0, B, h2, hrec, hpred]), dropout=np.array([pdrop]))
+        for k, prm in model.named_parameters():
+            out["g/" + k] = prm.grad.numpy().copy()
+        model.eval()
+        with torch.no_grad():
+            ep, ef, ez, emu, elv = model(data)
+        out.update(eval_pred=ep.numpy(), eval_fut=ef.numpy(), eval_mu=emu.numpy())
+        np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+        print("wrote", name, out["losses"])
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "options":
+        rnn_model, dataloader, rnn_vae, pose = load_reference()
+        options_fixture(rnn_model, rnn_vae)
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "prep":
         load_reference()
         prep_fixture()
@@ -360,6 +410,7 @@ def main():
     anneal_fixture(rnn_vae)
     train_model_fixture(rnn_vae)
     legacy_fixture(rnn_model, rnn_vae)
+    options_fixture(rnn_model, rnn_vae)
     prep_fixture()
 
 

@@ -52,14 +52,15 @@ def check_gemm_cases(dev, small=True):
     ]
     if not small:
         cases += [(512, 768, 512, 0, 0, 1, True, False), (768, 256, 4096, 1, 1, 8, False, False), (1000, 512, 768, 0, 1, 1, False, True)]
-    for (M, Nn, K, akm, bkm, sk, hb, acc) in cases:
+    cases = [c + (3,) for c in cases] + [c + (4,) for c in cases]      # row pad 3: scalar stores; 4: 16-byte aligned rows (vector stores)
+    for (M, Nn, K, akm, bkm, sk, hb, acc, pad) in cases:
         A = rng.standard_normal((K, M) if akm else (M, K)).astype(np.float32)
         Bm = rng.standard_normal((K, Nn) if bkm else (Nn, K)).astype(np.float32)
         bias = rng.standard_normal(Nn).astype(np.float32) if hb else None
-        C0 = rng.standard_normal((M, Nn + 3)).astype(np.float32)
+        C0 = rng.standard_normal((M, Nn + pad)).astype(np.float32)
         At, Bt, Ct = T_(A, dev), T_(Bm, dev), T_(C0, dev)
         ws = torch.zeros(sk * M * Nn, device=dev) if sk > 1 else None
-        ops.gemm(M, Nn, K, Operand(At, A.shape[1]), akm, Operand(Bt, Bm.shape[1]), bkm, Ct, Nn + 3, bias=T_(bias, dev) if hb else None,
+        ops.gemm(M, Nn, K, Operand(At, A.shape[1]), akm, Operand(Bt, Bm.shape[1]), bkm, Ct, Nn + pad, bias=T_(bias, dev) if hb else None,
                  accumulate=acc, splitk=sk, ws=ws)
         ref = (A.T if akm else A).astype(np.float64) @ (Bm if bkm else Bm.T).astype(np.float64)
         if hb:
@@ -500,3 +501,29 @@ def check_prep_fill_rules(dev):
         assert np.isnan(fl.cpu().numpy()[empty]).all()
         _resolve_empty_features(t, fl)
         np.testing.assert_array_equal(t.cpu().numpy(), y)
+
+
+def check_adam_abort_and_mask_scale(dev):
+    """vame_adam_amsgrad_f32 leaves everything untouched when its abort word is set; vame_mask_scale_f32 (dropout) on the padded
+    sequence layout and in place."""
+    rng = np.random.default_rng(17)
+    n = 999
+    p0 = rng.standard_normal(n).astype(np.float32)
+    p, g = T_(p0, dev), T_(rng.standard_normal(n).astype(np.float32), dev)
+    m, v, vm = torch.zeros(n, device=dev), torch.zeros(n, device=dev), torch.zeros(n, device=dev)
+    flag = torch.ones(1, dtype=torch.int32, device=dev)
+    ops.adam_amsgrad(p, g, m, v, vm, n, 5e-4, 1, abort_flag=flag)
+    np.testing.assert_array_equal(N_(p), p0)
+    assert float(m.abs().sum()) == 0 and float(v.abs().sum()) == 0 and float(vm.abs().sum()) == 0
+    flag.zero_()
+    ops.adam_amsgrad(p, g, m, v, vm, n, 5e-4, 1, abort_flag=flag)
+    assert np.abs(N_(p) - p0).max() > 1e-5
+    B, T, C = 5, 7, 24
+    Y = rng.standard_normal((B, T + 2, C)).astype(np.float32)
+    mask = (rng.random((B, T, C)) > 0.25).astype(np.float32)
+    out = torch.empty(B, T, C, device=dev)
+    ops.mask_scale(T_(Y, dev), C, C, T, (T + 2) * C, T_(mask, dev), 1.0 / 0.75, out, B * T, C)
+    np.testing.assert_allclose(N_(out), Y[:, 1:T + 1] * mask * np.float32(1.0 / 0.75), rtol=1e-6)
+    d = T_(Y[:, 1:T + 1].copy(), dev)
+    ops.mask_scale(d, 0, C, 0, 0, T_(mask, dev), 2.0, d, B * T, C)
+    np.testing.assert_allclose(N_(d), Y[:, 1:T + 1] * mask * 2.0, rtol=1e-6)

@@ -217,3 +217,150 @@ def check_legacy_step(dev):
     np.testing.assert_allclose(model.decoder_future(ins).cpu().numpy(), g["eval_fut"], atol=3e-5)
     h = model.encoder(x)
     np.testing.assert_allclose(model.lmbda(h)[1].cpu().numpy(), g["eval_mu"], atol=1e-5)
+
+
+def check_model_options(dev, name):
+    """Reference options beyond the stock config (rnn_model.py:31-35 encoder inter-layer dropout; :148-160 decoder hidden sizes that
+    differ from the encoder's): one train step against the reference's own outputs, losses and all gradients
+    (tests/golden/step_tiny_dropout.npz, step_tiny_hsizes.npz), plus eval mode (dropout off)."""
+    g = load_golden(name)
+    T, F, Z, H, FS, fut, sp, B, h2, hrec, hpred = [int(v) for v in g["spec"]]
+    pdrop = float(g["dropout"][0])
+    model = RNN_VAE(2 * T, Z, F, fut, FS, H, h2, hrec, hpred, pdrop, 0, 0, False)
+    w = golden_weights(g)
+    assert list(model.state_dict().keys()) == list(w.keys())
+    assert all(tuple(model.state_dict()[k].shape) == w[k].shape for k in w)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in w.items()})
+    model = model.to(dev).train()
+    x, xfut, eps = [torch.from_numpy(g[k]).to(dev) for k in ("x", "xfut", "eps")]
+    mask = torch.from_numpy(g["drop_mask"]).to(dev) if "drop_mask" in g else None
+    win = torch.cat([x, xfut], 1).contiguous()
+    kw = float(g["kw"][0])
+    out = model.loss_step(win, kw, beta=1.0, kloss=Z, klmbda=0.1, bsize=B, eps=eps, drop_mask=mask).cpu().numpy()
+    for i in range(4):
+        assert abs(out[i] - g["losses"][i]) <= 1e-4 * max(1.0, abs(g["losses"][i])), (i, out[i], g["losses"][i])
+    eng = model._engine
+    for nm, ref_v in (("pred", g["pred"]), ("futp", g["fut"]), ("z", g["z"]), ("mu", g["mu"]), ("logvar", g["logvar"])):
+        got = eng.ws.t[nm][:ref_v.size].view(*ref_v.shape).cpu().numpy()
+        np.testing.assert_allclose(got, ref_v, atol=3e-5, err_msg=nm)
+    for k, p in model.named_parameters():
+        gr = g["g/" + k]
+        np.testing.assert_allclose(p.grad.cpu().numpy(), gr, atol=3e-4 * max(np.abs(gr).max(), 1e-3), err_msg=k)
+    # autograd path with the same injected draws
+    model.zero_grad(set_to_none=False)
+    res = model(x, eps=eps, drop_mask=mask)
+    np.testing.assert_allclose(res[0].detach().cpu().numpy(), g["pred"], atol=3e-5)
+    (res[0].sum() + res[1].sum()).backward()
+    if pdrop > 0:                                   # device-drawn mask: right keep rate, and training still runs
+        m = model._dropout_mask(64, None, torch.device(dev))
+        assert tuple(m.shape) == (64, T, 2 * H) and abs(float(m.mean()) - (1 - pdrop)) < 0.02 and set(m.unique().tolist()) <= {0.0, 1.0}
+        assert np.isfinite(model.loss_step(win, kw, beta=1.0, kloss=Z, klmbda=0.1, bsize=B).cpu().numpy()).all()
+    model.eval()
+    ep, ef, ez, emu, elv = model(x)
+    np.testing.assert_allclose(ep.cpu().numpy(), g["eval_pred"], atol=3e-5)
+    np.testing.assert_allclose(ef.cpu().numpy(), g["eval_fut"], atol=3e-5)
+    np.testing.assert_allclose(emu.cpu().numpy(), g["eval_mu"], atol=1e-5)
+
+
+def check_stale_backward_guard(dev):
+    """model(x) in training keeps one step's activations in the engine workspace: backward() after another forward must raise
+    instead of returning another batch's gradients."""
+    import pytest
+    g = load_golden("step_tiny")
+    model, (T, F, Z, H, FS, fut, sp) = build_model(g, dev)
+    model.train()
+    x = torch.from_numpy(g["x"]).to(dev)
+    out1 = model(x)
+    model(x)                                       # overwrites the stashes of the first forward
+    with pytest.raises(RuntimeError, match="overwritten"):
+        out1[0].sum().backward()
+    out2 = model(x)
+    out2[0].sum().backward()                       # the latest forward is fine
+
+
+def check_device_window_loader(dev, tmp_path):
+    """DeviceWindowLoader (the product batcher) against the reference's SEQUENCE_DATASET + DataLoader collate
+    (tests/golden/batcher.npz, dataloader.py:18-56): same window starts from the global numpy stream, and bit-identical
+    windows -- the series is z-scored once in float64 and cast, which equals the reference's per-window normalise-then-cast."""
+    import os
+    from vame_amd.model.dataloader import SEQUENCE_DATASET, DeviceWindowLoader
+    g = load_golden("batcher")
+    T2, B = int(g["T2"]), g["batch"].shape[0]
+    path = str(tmp_path) + os.sep
+    np.save(path + "train_seq.npy", g["X"])
+    ds = SEQUENCE_DATASET(path, data="train_seq.npy", train=True, temporal_window=T2)
+    assert float(ds.mean) == float(g["mean"]) and float(ds.std) == float(g["std"])
+    assert float(np.load(path + "seq_mean.npy")) == float(g["mean"])            # written for the test set / later runs
+    loader = DeviceWindowLoader(ds, B, T2, torch.device(dev))
+    assert len(loader) == g["X"].shape[1] // B
+    np.random.seed(11)
+    starts = loader.draw_starts()
+    np.testing.assert_array_equal(starts, g["starts"])
+    win = loader.gather(starts).cpu().numpy()                                    # (B, 2T, F) fp32
+    ref = np.transpose(g["batch"], (0, 2, 1)).astype(np.float32)                 # reference item (B,F,2T) f64 -> permute -> FloatTensor
+    np.testing.assert_array_equal(win, ref)
+    # the API-compatible __getitem__ (index ignored, float64 (F, 2T) item)
+    np.random.seed(11)
+    item = ds[123]
+    np.testing.assert_array_equal(item.numpy(), g["batch"][0])
+    # two ranks: disjoint slices of one draw
+    l0, l1 = DeviceWindowLoader(ds, B // 2, T2, torch.device(dev), 0, 2), DeviceWindowLoader(ds, B // 2, T2, torch.device(dev), 1, 2)
+    np.random.seed(11)
+    s0 = l0.draw_starts()
+    np.random.seed(11)
+    s1 = l1.draw_starts()
+    np.testing.assert_array_equal(np.concatenate([s0, s1]), g["starts"])
+
+
+def check_coop_failure_is_contained(dev):
+    """A cooperative (column-split) GRU launch that reports a hand-off timeout must not reach the weights and must raise
+    promptly: the optimizer kernel drops the step on the device (abort word), the host raises at the next step's enqueue
+    (asynchronous status snapshot) or at the next synchronising check -- not an epoch later.  Fault injection:
+    vame_gru_coop_set_poll_limit(-1)."""
+    import pytest
+    from vame_amd import _lib, ops
+    from vame_amd.model.rnn_vae import FusedAdamAMSGrad
+    F, Z, H, T, FS, B = 10, 7, 128, 4, 2, 5
+    torch.manual_seed(3)
+    model = RNN_VAE(2 * T, Z, F, 1, FS, H, H, H, H, 0, 0, 0, False).to(dev).train()
+    opt = FusedAdamAMSGrad(model, lr=5e-4)
+    rng = np.random.default_rng(9)
+    win = torch.from_numpy(rng.standard_normal((B, T + FS, F)).astype(np.float32)).to(dev)
+    model.loss_step(win, 1.0, beta=1.0, kloss=4, klmbda=0.3, bsize=B)
+    opt.step()
+    eng = model._engine
+    assert eng._coop_state is not None and eng._coop_state.dirty          # this shape runs the cooperative kernels
+    eng.check_async_errors()                                                # clean so far
+    w0 = model.flat_parameters()[0].clone()
+    old = ops.gru_coop_set_poll_limit(-1)
+    raised = False
+    try:
+        try:
+            model.loss_step(win, 1.0, beta=1.0, kloss=4, klmbda=0.3, bsize=B)          # every cooperative launch reports a timeout
+            opt.step()                                                                  # ... so this is dropped on the device
+            ops.gru_coop_set_poll_limit(0)
+            model.loss_step(win, 1.0, beta=1.0, kloss=4, klmbda=0.3, bsize=B)          # raises here, when the snapshot has arrived,
+            model.loss_step(win, 1.0, beta=1.0, kloss=4, klmbda=0.3, bsize=B)          # or at the latest one step later
+            eng.check_async_errors()
+        except _lib.VameHipError as e:
+            raised = "hand-off" in str(e)
+    finally:
+        ops.gru_coop_set_poll_limit(old if old > 0 else 0)
+    assert raised
+    if dev != "cpu":
+        torch.cuda.synchronize()
+    assert torch.equal(model.flat_parameters()[0], w0)                                  # the failed step never reached the weights
+    # after the exception the status word is clean again and training continues
+    model.loss_step(win, 1.0, beta=1.0, kloss=4, klmbda=0.3, bsize=B)
+    opt.step()
+    eng.check_async_errors()
+    assert not torch.equal(model.flat_parameters()[0], w0)
+    # inference entry points check too: a failed launch never hands out results
+    ops.gru_coop_set_poll_limit(-1)
+    try:
+        model.eval()
+        with pytest.raises(_lib.VameHipError, match="hand-off"):
+            model(win[:, :T].contiguous())
+    finally:
+        ops.gru_coop_set_poll_limit(0)
+    model(win[:, :T].contiguous())

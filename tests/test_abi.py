@@ -66,22 +66,29 @@ def test_error_codes_and_messages(emu):
 def test_no_cpu_fallback_without_library(monkeypatch):
     """The product binding refuses to run without libvame_hip.so instead of falling back."""
     from vame_amd import _lib
-    saved = (_lib._lib, _lib._emulated)
-    _lib._lib, _lib._emulated = None, False
+    saved = _lib._lib
+    _lib._lib = None
     monkeypatch.setattr(_lib, "LIB_PATH", os.path.join(ROOT, "vame_amd", "does_not_exist.so"))
     try:
         with pytest.raises(_lib.VameHipError):
             _lib.lib()
     finally:
-        _lib._lib, _lib._emulated = saved
+        _lib._lib = saved
 
 
 def test_cpu_tensors_rejected_by_product_path():
+    """Without the test harness the product refuses CPU tensors and refuses to start without a GPU (no CPU fallback)."""
+    import harness
     from vame_amd import _lib, ops
-    saved = (_lib._lib, _lib._emulated)
-    _lib._lib, _lib._emulated = None, False
+    was_installed = harness._saved is not None            # (this module's other tests run on the emulator harness)
+    harness.uninstall()
     try:
         with pytest.raises(_lib.VameHipError):
             ops.axpy(torch.zeros(4), 1.0, torch.zeros(4), 4)
+        if not torch.cuda.is_available():
+            with pytest.raises(_lib.VameHipError):         # the drivers (train_model, pose_segmentation, bench.py) start here
+                _lib.device()
     finally:
-        _lib._lib, _lib._emulated = saved
+        _lib._lib = None
+        if was_installed:
+            harness.install()

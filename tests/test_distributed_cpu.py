@@ -24,8 +24,9 @@ def _worker(rank, world, port, out_dir):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), VAME_EMU_THREADS="2")
     torch.set_num_threads(1)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    from vame_amd import _lib
-    _lib._load_for_tests(os.path.join(ROOT, "tests", "emu", "libvame_emu.so"))
+    sys.path.insert(0, os.path.join(ROOT, "tests", "emu"))
+    import harness
+    harness.install()
     from model_cases import build_model
     from vame_amd.model.rnn_vae import FusedAdamAMSGrad, allreduce_gradients
     from vame_amd.analysis.pose_segmentation import embed_series
@@ -92,10 +93,9 @@ def test_bench_script_under_torchrun_two_ranks(emu):
     rank / barrier / max-over-ranks / rank-0 JSON plumbing, here with 2 gloo ranks on the host emulator build and a tiny model."""
     import json
     import subprocess
-    env = dict(os.environ, VAME_BENCH_EMU_LIB=os.path.join(ROOT, "tests", "emu", "libvame_emu.so"), VAME_EMU_THREADS="2",
-               OMP_NUM_THREADS="1")
+    env = dict(os.environ, VAME_EMU_THREADS="2", OMP_NUM_THREADS="1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "emu", "harness.py"), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
            "--batch", "8", "--hidden", "32", "--time-window", "4"]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-2000:]
@@ -103,4 +103,5 @@ def test_bench_script_under_torchrun_two_ranks(emu):
     assert len(lines) == 1, r.stdout                                         # rank 0 prints exactly one JSON line
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["steps"] == 2 and out["warmup"] == 1 and out["value"] > 0
-    assert all(np.isfinite(out["last_loss_terms"]))
+    assert all(np.isfinite(out["config"]["last_loss_terms"]))
+    assert out["roofline"] is None and "cpu_baseline" not in out           # nothing measured off the GPU

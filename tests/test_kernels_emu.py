@@ -5,23 +5,27 @@ the CPU; the same checks run on the real GPU in test_kernels_gpu.py.
 """
 import pytest
 
-from kernel_cases import (check_adam, check_colsum, check_colsum_batch, check_kmeans, check_gather, check_gemm_cases, check_gemm_group, check_gru_bwd, check_gru_coop_bwd, check_gru_coop_fwd, check_gru_fwd, check_gru_fwd_fused,
+from kernel_cases import (check_adam, check_adam_abort_and_mask_scale, check_colsum, check_colsum_batch, check_kmeans, check_gather, check_gemm_cases, check_gemm_group, check_gru_bwd, check_gru_coop_bwd, check_gru_coop_fwd, check_gru_fwd, check_gru_fwd_fused,
                           check_latent, check_mse, check_nuclear, check_prep_fill_rules, check_prepare_series_golden,
                           check_prepare_series_vs_oracle)
 
 DEV = "cpu"
 
 
-def test_gemm(emu):
+@pytest.mark.parametrize("epi", ["0", "1", "2"])
+def test_gemm(emu, epi, monkeypatch):
+    """every epilogue form of gemm_kernel (the emulator build reads VAME_GEMM_EPI like the A/B tuning build)"""
+    monkeypatch.setenv("VAME_GEMM_EPI", epi)
     check_gemm_cases(DEV, small=True)
+    check_gemm_group(DEV)
 
 
-@pytest.mark.parametrize("H,B,T", [(32, 5, 4), (64, 40, 3)])
+@pytest.mark.parametrize("H,B,T", [(32, 5, 4), (64, 40, 3), (96, 5, 3)])
 def test_gru_fwd(emu, H, B, T):
     check_gru_fwd(DEV, H, B, T)
 
 
-@pytest.mark.parametrize("H,B,T", [(32, 5, 4), (64, 40, 3)])
+@pytest.mark.parametrize("H,B,T", [(32, 5, 4), (64, 40, 3), (96, 5, 3)])
 def test_gru_bwd(emu, H, B, T):
     check_gru_bwd(DEV, H, B, T)
 
@@ -33,6 +37,7 @@ def test_elementwise(emu):
     check_colsum(DEV)
     check_colsum_batch(DEV)
     check_adam(DEV)
+    check_adam_abort_and_mask_scale(DEV)
 
 
 @pytest.mark.parametrize("B,Z,k", [(64, 30, 30), (8, 30, 30), (50, 7, 4), (128, 34, 34), (96, 48, 20), (200, 64, 64), (70, 63, 63)])

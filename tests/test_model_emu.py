@@ -2,7 +2,7 @@
 reference's golden vectors (tiny model).  The same bodies run on the GPU in test_model_gpu.py."""
 import pytest
 
-from model_cases import check_adam_trajectory, check_odd_dims_vs_oracle, check_eval_and_submodules, check_evaluate_and_generative_cores, check_h0_view, check_legacy_step, check_noise_input, check_step
+from model_cases import check_adam_trajectory, check_coop_failure_is_contained, check_odd_dims_vs_oracle, check_eval_and_submodules, check_evaluate_and_generative_cores, check_h0_view, check_device_window_loader, check_legacy_step, check_model_options, check_noise_input, check_stale_backward_guard, check_step
 
 
 @pytest.mark.parametrize("name,kw,mse", [("step_tiny", 1.0, "sum"), ("step_tiny", 0.25, "sum"), ("step_tiny_oddB", 1.0, "sum"),
@@ -54,3 +54,20 @@ def test_unaligned_feature_and_latent_dims(emu):
 def test_small_batch_cooperative_path_vs_oracle(emu):
     """H = 128 with a tiny batch goes through the column-split GRU kernels (engine._coop_ok): full step vs the numpy oracle."""
     check_odd_dims_vs_oracle("cpu", F=10, Z=7, H=128, T=4, FS=2, B=5)
+
+
+@pytest.mark.parametrize("name", ["step_tiny_dropout", "step_tiny_hsizes"])
+def test_reference_model_options(emu, name):
+    check_model_options("cpu", name)
+
+
+def test_stale_backward_is_refused(emu):
+    check_stale_backward_guard("cpu")
+
+
+def test_device_window_loader_matches_reference_batcher(emu, tmp_path):
+    check_device_window_loader("cpu", tmp_path)
+
+
+def test_cooperative_launch_failure_is_contained(emu):
+    check_coop_failure_is_contained("cpu")

@@ -162,3 +162,29 @@ def test_torch_legacy_restatement_matches_reference():
         ref = g["g/" + k]
         got = p.grad.numpy() if p.grad is not None else np.zeros_like(ref)
         np.testing.assert_allclose(got, ref, atol=2e-4 * max(np.abs(ref).max(), 1e-3), err_msg=k)
+
+
+@pytest.mark.parametrize("name", ["step_tiny_dropout", "step_tiny_hsizes"])
+def test_model_options_dropout_and_hidden_sizes(name):
+    """Encoder inter-layer dropout (rnn_model.py:31-35) and decoder hidden sizes != encoder's (:148-160): the oracle against one
+    train step of the reference itself (mask reproduced from torch's CPU stream by tests/golden/make_golden.py)."""
+    g = load_golden(name)
+    T, F, Z, H, FS, fut, sp, B = [int(v) for v in g["spec"][:8]]
+    spec = vo.Spec(T=T, F=F, Z=Z, H=H, FS=FS, future=True, softplus=False, dropout=float(g["dropout"][0]))
+    p = golden_weights(g)
+    cache = vo.FwdCache()
+    mask = g["drop_mask"] if "drop_mask" in g else None
+    pred, futp, z, mu, lv = vo.model_forward(p, g["x"], g["eps"], spec, True, cache, drop_mask=mask)
+    for got, key in ((pred, "pred"), (futp, "fut"), (z, "z"), (mu, "mu"), (lv, "logvar")):
+        np.testing.assert_allclose(got, g[key], atol=2e-5, err_msg=key)
+    kw = float(g["kw"][0])
+    L = vo.total_loss(pred, futp, z, mu, lv, g["x"], g["xfut"], spec, kw)
+    for i, k in enumerate(["rec", "fut", "kl", "kmeans"]):
+        assert abs(L[k] - g["losses"][i]) <= 1e-4 * max(1.0, abs(g["losses"][i])), (k, L[k], g["losses"][i])
+    grads = vo.model_backward(p, cache, spec, g["x"], g["xfut"], kw)
+    for k, gv in grads.items():
+        r = g["g/" + k]
+        np.testing.assert_allclose(gv, r, atol=2e-4 * max(1.0, np.abs(r).max()), err_msg=k)
+    ep, ef, ez, emu, elv = vo.model_forward(p, g["x"], None, spec, training=False, drop_mask=mask)     # eval: no dropout
+    np.testing.assert_allclose(emu, g["eval_mu"], atol=1e-5)
+    np.testing.assert_allclose(ep, g["eval_pred"], atol=2e-5)

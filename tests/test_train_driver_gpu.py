@@ -1,12 +1,14 @@
-"""vame.train_model() / vame.pose_segmentation() / evaluate / generative / create_trainset end to end on a synthetic project -- through the host emulator build.
+"""vame.train_model() / vame.pose_segmentation() / evaluate / generative / create_trainset end to end on a synthetic project -- on the MI355X (the public entry points of the drop-in boundary).
 The checks live in driver_cases.py."""
 import pytest
 
 import driver_cases as dc
 
+pytestmark = pytest.mark.gpu
+
 
 @pytest.fixture(scope="module")
-def project(tmp_path_factory, emu):
+def project(tmp_path_factory, hip):
     return dc.make_project(tmp_path_factory)
 
 
@@ -30,14 +32,14 @@ def test_train_model_legacy_topology(project, tmp_path):
     dc.check_train_model_legacy_topology(project, tmp_path)
 
 
-def test_create_trainset_files(tmp_path, emu):
+def test_create_trainset_files(tmp_path, hip):
     dc.check_create_trainset_files(tmp_path)
 
 
-def test_read_config_contract(tmp_path, emu):
+def test_read_config_contract(tmp_path, hip):
     dc.check_read_config_contract(tmp_path)
 
 
-def test_parameterization_with_gpu_kmeans_option(emu):
+def test_parameterization_with_gpu_kmeans_option(hip):
     dc.check_parameterization_with_gpu_kmeans_option()
 

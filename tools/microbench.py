@@ -148,7 +148,31 @@ def gemm_ab(rounds=4):
         print(f"M={M} N={N} K={K} akm={akm} bkm={bkm} sk={sk}: " + "  ".join(f"v{v}: {statistics.median(t):6.1f} (max {max(t):6.1f})" for v, t in res.items()))
 
 
+def gemm_epi(rounds=4):
+    """Interleaved A/B of the GEMM epilogue forms (library built with `make ab`; VAME_GEMM_EPI): 0 = 16 dword stores per 32x32 tile
+    (lane = column), 1 = swapped MFMA operands, 4 dwordx4 stores (lane = row), 2 = LDS-transposed, 4 dwordx4 full-line stores."""
+    import statistics
+    BT = 4096 * 30
+    shapes = [(BT, 768, 512, 0, 0, 1), (BT, 512, 768, 0, 1, 1), (BT, 768, 24, 0, 0, 1), (BT, 24, 512, 0, 0, 1), (768, 512, BT, 1, 1, 32), (768, 256, BT, 1, 1, 64),
+              (8192, 1536, 512, 0, 0, 1), (4096, 4096, 4096, 0, 0, 1)]
+    for (M, N, K, akm, bkm, sk) in shapes:
+        A = torch.randn((K, M) if akm else (M, K), device=dev)
+        B = torch.randn((K, N) if bkm else (N, K), device=dev)
+        C = torch.empty(M, N, device=dev)
+        ws = torch.empty(sk * M * N, device=dev) if sk > 1 else None
+        res = {v: [] for v in (0, 1, 2)}
+        for r in range(rounds):
+            for v in res:
+                os.environ["VAME_GEMM_EPI"] = str(v)
+                ms = timeit(lambda: ops.gemm(M, N, K, Operand(A, A.shape[1]), akm, Operand(B, B.shape[1]), bkm, C, N, splitk=sk, ws=ws), reps=5)
+                res[v].append(2.0 * M * N * K / ms / 1e9)
+        print(f"M={M} N={N} K={K} akm={akm} bkm={bkm} sk={sk}: " + "  ".join(f"epi{v}: {statistics.median(t):6.1f} (max {max(t):6.1f})" for v, t in res.items()), flush=True)
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 2 and sys.argv[2] == "gemm_epi":
+        gemm_epi()
+        sys.exit(0)
     if len(sys.argv) > 2 and sys.argv[2] == "gemm_tiles":
         gemm_tiles()
         sys.exit(0)

@@ -1,9 +1,7 @@
 """ctypes binding of libvame_hip.so (the gfx950 kernels) -- fails loudly when the library is missing.
 
 There is no CPU fallback: every op in :mod:`vame_amd.ops` goes through this C ABI
-(``include/vame_hip.h``).  ``_load_for_tests`` exists so the CPU test-suite can point the very
-same bindings at the host emulation build of the kernel sources (tests/emu); nothing in the
-package calls it.
+(``include/vame_hip.h``), needs the library built for gfx950 and tensors in HIP device memory.
 """
 import ctypes
 import os
@@ -12,7 +10,6 @@ from ctypes import c_char_p, c_double, c_float, c_int, c_int64, c_void_p
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libvame_hip.so")
 _lib = None
-_emulated = False
 
 
 class VameHipError(RuntimeError):
@@ -48,10 +45,12 @@ _SIGS = {
     "vame_colsum_f32": (c_int, [c_void_p, c_int64, c_int, c_int64, c_void_p, c_int, c_void_p, c_void_p]),
     "vame_colsum_batch_f32": (c_int, [c_void_p, c_int, c_void_p]),
     "vame_adam_amsgrad_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, c_float,
-                                      c_float, c_int, c_float, c_void_p]),
+                                      c_float, c_int, c_float, c_void_p, c_void_p]),
+    "vame_mask_scale_f32": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_int64, c_void_p, c_float, c_void_p, c_int64, c_int, c_void_p]),
     "vame_axpy_f32": (c_int, [c_void_p, c_float, c_void_p, c_int64, c_void_p]),
     "vame_gru_coop_flag_ints": (c_int64, [c_int, c_int, c_int]),
     "vame_gru_coop_supported": (c_int, [c_int, c_int, c_int]),
+    "vame_gru_coop_set_poll_limit": (c_int, [c_int]),
     "vame_gru_coop_fwd_f32": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p]),
     "vame_gru_coop_xbuf_floats": (c_int64, [c_int, c_int, c_int]),
     "vame_gru_coop_bwd_f32": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
@@ -86,15 +85,25 @@ def lib():
     return _lib
 
 
-def _load_for_tests(path):
-    """Test-suite hook: bind the host-emulated build of the kernel sources (CPU tensors)."""
-    global _lib, _emulated
-    _lib = _bind(path)
-    _emulated = True
+def device(index=None):
+    """The HIP device the path runs on (current device, or `index`); raises when no MI355X is visible."""
+    import torch
+    if not torch.cuda.is_available():
+        raise VameHipError("vame_amd needs an MI355X (torch.cuda.is_available() is False); there is no CPU path")
+    if index is not None:
+        torch.cuda.set_device(index)
+    return torch.device("cuda", torch.cuda.current_device())
 
 
-def emulated():
-    return _emulated
+def require_device_tensor(t):
+    if not t.is_cuda:
+        raise VameHipError("vame_amd ops need CUDA(HIP) tensors; there is no CPU path")
+
+
+def stream_handle():
+    """hipStream_t of torch's current stream: every kernel of the path is launched on it."""
+    import torch
+    return torch.cuda.current_stream().cuda_stream
 
 
 def check(rc, what=""):

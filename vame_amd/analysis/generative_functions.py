@@ -47,13 +47,16 @@ def _grid(recon, rows, cols, title, titles=None):
 
 
 def random_generative_samples_motif(cfg, model, latent_vector, labels, n_cluster):
-    figs = []
+    """One GMM per motif over that motif's latents, 10 decoded samples each (generative_functions.py:22-47).  Returns the
+    decoded samples (n_cluster, N_SAMPLES, T, F)."""
+    out = []
     for j in range(n_cluster):
         motif_latents = latent_vector[np.where(labels == j)[0], :]
         gm = _gmm().fit(motif_latents)
         recon = decode_latents(model, gm.sample(N_SAMPLES)[0], cfg['time_window'])
-        figs.append(_grid(recon, 2, 5, 'Generated samples for motif ' + str(j)))
-    return figs
+        _grid(recon, 2, 5, 'Generated samples for motif ' + str(j))
+        out.append(recon)
+    return np.stack(out)
 
 
 def random_generative_samples(cfg, model, latent_vector):
@@ -101,7 +104,12 @@ def _select_files(cfg):
     return [all_flag]
 
 
+MODES = ("sampling", "reconstruction", "centers", "motifs")
+
+
 def generative_model(config, mode="sampling"):
+    if mode not in MODES:
+        raise ValueError(f"generative_model: mode must be one of {MODES}, got {mode!r}")
     cfg = read_config(Path(config).resolve())
     model_name, n_cluster = cfg['model_name'], cfg['n_cluster']
     files = _select_files(cfg)
@@ -115,4 +123,8 @@ def generative_model(config, mode="sampling"):
             results[file] = random_reconstruction_samples(cfg, model, np.load(os.path.join(path_to_file, 'latent_vector_' + file + '.npy')))
         if mode == "centers":
             results[file] = visualize_cluster_center(cfg, model, np.load(os.path.join(path_to_file, 'cluster_center_' + file + '.npy')))
+        if mode == "motifs":                                                                    # generative_functions.py:191-194
+            latent_vector = np.load(os.path.join(path_to_file, 'latent_vector_' + file + '.npy'))
+            labels = np.load(os.path.join(path_to_file, str(n_cluster) + '_km_label_' + file + '.npy'))
+            results[file] = random_generative_samples_motif(cfg, model, latent_vector, labels, n_cluster)
     return results

@@ -24,9 +24,7 @@ class KMeansHIP:
             t = X
         else:
             t = torch.from_numpy(np.ascontiguousarray(X, dtype=np.float32))
-        if not _lib.emulated():
-            t = t.cuda()
-        return t.to(torch.float32).contiguous()
+        return t.to(device=_lib.device(), dtype=torch.float32).contiguous()
 
     def _assign(self, X, C, want_onehot):
         N, D = X.shape

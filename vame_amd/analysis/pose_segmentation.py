@@ -24,11 +24,7 @@ EMBED_BATCH = 16384       # windows per launch group: ~1.2 GB of fp32 activation
 
 
 def _device():
-    if torch.cuda.is_available():
-        return torch.device("cuda", torch.cuda.current_device())
-    if _lib.emulated():
-        return torch.device("cpu")
-    raise _lib.VameHipError("vame_amd needs an MI355X (torch.cuda.is_available() is False); there is no CPU path")
+    return _lib.device()
 
 
 def load_model(cfg, model_name, fixed):
@@ -65,6 +61,7 @@ def embed_series(model, data, batch=EMBED_BATCH, rank=0, world=1):
             hn = eng.encode(win, s.T * F, b, training=False)
             _, mu, _ = eng.latent(hn, b, None, False, want_kl=False)
             out[i0 - lo:i0 - lo + b].copy_(mu[:b * s.Z].view(b, s.Z))
+    eng.check_async_errors()          # small tail batches run the cooperative kernels: never hand out latents of a failed launch
     return out, (lo, hi)
 
 
@@ -181,6 +178,9 @@ def pose_segmentation(config):
                                   "of the repository (pose_segmentation.py:205-207), so there is no behaviour to reproduce")
     ind_param = cfg['individual_parameterization']
     pp = cfg['project_path']
+    from ..model.rnn_vae import _maybe_init_distributed
+    rank, world = _maybe_init_distributed()          # several ranks: the embedding is sharded by window index; rank 0 alone
+    is_main = rank == 0                              # parameterises and writes the result files
     for folders in cfg['video_sets']:
         os.makedirs(os.path.join(pp, "results", folders, model_name, ""), exist_ok=True)
 
@@ -219,6 +219,9 @@ def pose_segmentation(config):
         else:
             print('No new parameterization has been calculated.')
             new = False
+    if new and not is_main:
+        dist.barrier()                               # rank 0 is writing; nothing to do here
+        return
     if new:
         if ind_param == False:  # noqa: E712
             print("For all animals the same parameterization of latent vectors is applied for %d cluster" % n_cluster)
@@ -234,4 +237,6 @@ def pose_segmentation(config):
                 np.save(os.path.join(save_data, 'cluster_center_' + f), cluster_center[idx])
             np.save(os.path.join(save_data, 'latent_vector_' + f), latent_vectors[idx])
             np.save(os.path.join(save_data, 'motif_usage_' + f), motif_usages[idx])
+        if world > 1:
+            dist.barrier()
         print("You succesfully extracted motifs with VAME! From here, you can proceed running vame.motif_videos() ")

@@ -269,7 +269,11 @@ extern "C" int vame_timesum_f32(const float* in, int B, int T, int C, int64_t ld
 // --------------------------------------------------------------------------------- Adam (AMSGrad)
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                    float* __restrict__ v, float* __restrict__ vmax, int64_t n, float step_size,
-                                                   float beta1, float beta2, float eps, float inv_sqrt_bc2, float gscale) {
+                                                   float beta1, float beta2, float eps, float inv_sqrt_bc2, float gscale,
+                                                   const int* __restrict__ abort_flag) {
+    // a device-side failure upstream (a cooperative GRU launch that gave up waiting: gru_coop.hip) must not reach the weights:
+    // the step is dropped here, on the device, and the host raises when it next looks at the same word
+    if (abort_flag && *abort_flag != 0) return;
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         const float gi = g[i] * gscale;
         const float mi = beta1 * m[i] + (1.0f - beta1) * gi;
@@ -282,11 +286,11 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
 }
 
 extern "C" int vame_adam_amsgrad_f32(float* p, const float* g, float* m, float* v, float* vmax, int64_t n, float lr,
-                                     float beta1, float beta2, float eps, int step, float gscale, void* stream) {
+                                     float beta1, float beta2, float eps, int step, float gscale, const int* abort_flag, void* stream) {
     VAME_CHECK_ARG(p && g && m && v && vmax && n >= 1 && step >= 1, VAME_E_BADARG, "adam: bad argument");
     const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
     hipLaunchKernelGGL(adam_kernel, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, vmax, n,
-                       (float)(lr / bc1), beta1, beta2, eps, (float)(1.0 / sqrt(bc2)), gscale);
+                       (float)(lr / bc1), beta1, beta2, eps, (float)(1.0 / sqrt(bc2)), gscale, abort_flag);
     VAME_LAUNCH_CHECK("adam");
     return VAME_OK;
 }
@@ -299,6 +303,35 @@ extern "C" int vame_axpy_f32(const float* x, float a, float* y, int64_t n, void*
     VAME_CHECK_ARG(x && y && n >= 1, VAME_E_BADARG, "axpy: bad argument");
     hipLaunchKernelGGL(axpy_kernel, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, x, a, y, n);
     VAME_LAUNCH_CHECK("axpy");
+    return VAME_OK;
+}
+
+// --------------------------------------------------------------------------------- dropout mask (encoder inter-layer dropout)
+// out[r][c] = x[row(r)][c] * mask[r][c] * scale over R x C (C % 4 == 0, 16-byte aligned rows); x rows are addressed in two
+// levels (r / seg) * seg_stride + (r % seg) * ld + off like the GEMM operands (the padded (B, T+2, 2H) sequence layout); seg = 0:
+// dense rows of ld elements.  In-place (out == x, dense) is allowed.  torch.nn.GRU(dropout=p) semantics (rnn_model.py:34-35):
+// mask in {0,1}, scale = 1/(1-p).
+__global__ __launch_bounds__(256) void mask_scale_kernel(const float* __restrict__ x, int64_t off, int64_t ld, int64_t seg, int64_t seg_stride,
+                                                         const float* __restrict__ mask, float scale, float* __restrict__ out, int64_t R, int C) {
+    const int cq = C / 4;
+    const int64_t n = R * cq;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / cq;
+        const int c = (int)(i % cq) * 4;
+        const int64_t xo = (seg ? (r / seg) * seg_stride + (r % seg) * ld : r * ld) + off + c;
+        const float4 v = *reinterpret_cast<const float4*>(x + xo);
+        const float4 m = *reinterpret_cast<const float4*>(mask + r * C + c);
+        *reinterpret_cast<float4*>(out + r * C + c) = make_float4(v.x * m.x * scale, v.y * m.y * scale, v.z * m.z * scale, v.w * m.w * scale);
+    }
+}
+extern "C" int vame_mask_scale_f32(const float* x, int64_t off, int64_t ld, int64_t seg, int64_t seg_stride, const float* mask, float scale,
+                                   float* out, int64_t R, int C, void* stream) {
+    VAME_CHECK_ARG(x && mask && out && R >= 1 && C >= 4, VAME_E_BADARG, "mask_scale: bad argument");
+    VAME_CHECK_ARG(C % 4 == 0 && ld % 4 == 0 && off % 4 == 0 && seg_stride % 4 == 0 && (uintptr_t)x % 16 == 0 && (uintptr_t)mask % 16 == 0 &&
+                   (uintptr_t)out % 16 == 0, VAME_E_SHAPE, "mask_scale: rows must be 16-byte aligned (C=%d)", C);
+    hipLaunchKernelGGL(mask_scale_kernel, dim3(ew_blocks(R * (C / 4))), dim3(256), 0, (hipStream_t)stream, x, off, ld, seg, seg_stride, mask,
+                       scale, out, R, C);
+    VAME_LAUNCH_CHECK("mask_scale");
     return VAME_OK;
 }
 

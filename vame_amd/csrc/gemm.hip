@@ -6,6 +6,9 @@
 // 16-byte and register-prefetched one k-tile ahead.
 #include "vame_common.h"
 
+#ifndef VAME_GEMM_EPI_DEFAULT
+#define VAME_GEMM_EPI_DEFAULT 1
+#endif
 struct GemmOperand {
     const float* p;
     int64_t ld, seg, seg_stride;   // row i -> (seg ? (i/seg)*seg_stride + (i%seg)*ld : i*ld)
@@ -19,6 +22,7 @@ struct GemmParams {
     float* ws;
     int M, N, K, kper, splitk, accumulate;
     int tiles_m, tiles_n, by_z;      // XCD-aware block->tile mapping (see map_tile)
+    int cvec, wsvec;                 // 16-byte stores to C / to the split-K workspace are legal
     int group;                       // > 1: that many problems of identical shape / layout in one launch (split-K >= 8 only):
     const float* gA[8];              //      per-problem operand bases; partial sums of problem g go to ws + g * splitk * M * N
     const float* gB[8];
@@ -181,8 +185,37 @@ extern "C" int vame_probe_set_gemm(long long* p) { return (int)hipMemcpyToSymbol
 #define PROBE_ADD(acc)
 #endif
 
+// One output value: split-K partial -> workspace slab z, else C (+ bias, + previous C when accumulating)
+__device__ __forceinline__ void emit4(const GemmParams& p, float* ws, int z, int row, int col, float4 v) {
+    if (p.splitk > 1) {
+        float* d = ws + ((int64_t)z * p.M + row) * p.N + col;
+        if (p.wsvec && col + 3 < p.N) { *reinterpret_cast<float4*>(d) = v; return; }
+        d[0] = v.x; if (col + 1 < p.N) d[1] = v.y; if (col + 2 < p.N) d[2] = v.z; if (col + 3 < p.N) d[3] = v.w;
+        return;
+    }
+    float* c = p.C + (int64_t)row * p.ldc + col;
+    if (p.cvec && col + 3 < p.N) {
+        if (p.bias) { const float* b = p.bias + col; v.x += b[0]; v.y += b[1]; v.z += b[2]; v.w += b[3]; }
+        if (p.accumulate) { const float4 o = *reinterpret_cast<const float4*>(c); v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
+        *reinterpret_cast<float4*>(c) = v;
+        return;
+    }
+    const float e[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        if (col + k < p.N) {
+            float x = e[k] + (p.bias ? p.bias[col + k] : 0.f);
+            if (p.accumulate) x += c[k];
+            c[k] = x;
+        }
+}
+
 // VAR (tuning variants, tools/microbench.py A/B): 1 unpredicated interior fetch, 4 s_setprio around the MFMAs
-template <int BM, int BN, int WM, int WN, bool AKM, bool BKM, int VAR>
+// EPI (epilogue): 0 = accumulator layout as computed (lane = output column): 16 dword stores per 32x32 tile, two full 128-byte
+//   lines each.  1 = the MFMA operands are SWAPPED (D^T = B^T A^T), which puts an output ROW in each lane and four consecutive
+//   columns in registers 4q..4q+3: 4 dwordx4 stores per tile.  2 = layout 0 transposed through a per-wave LDS scratch (the operand
+//   buffers, free after the k loop): 4 dwordx4 stores per tile, 8 full lines each.
+template <int BM, int BN, int WM, int WN, bool AKM, bool BKM, int VAR, int EPI>
 __global__ __launch_bounds__(WM * WN * 64, (BM / WM) * (BN / WN) > 64 * 64 ? 2 : 3) void gemm_kernel(GemmParams p) {
     constexpr int BK = 32, NT = WM * WN * 64, TM = BM / WM / 32, TN = BN / WN / 32;
     typedef TileIO<BK, BM, NT, AKM, BKM> TA;      // x-major image only for the A operand of the NN form
@@ -234,7 +267,8 @@ __global__ __launch_bounds__(WM * WN * 64, (BM / WM) * (BN / WN) > 64 * 64 ? 2 :
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
-                    for (int j = 0; j < TN; ++j) acc[i][j] = MFMA_32x32x2(a[i][e], b[j][e], acc[i][j]);
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = EPI == 1 ? MFMA_32x32x2(b[j][e], a[i][e], acc[i][j]) : MFMA_32x32x2(a[i][e], b[j][e], acc[i][j]);
         }
         if (VAR & 4) SETPRIO(0);
         PROBE_ADD(pm);
@@ -248,6 +282,47 @@ __global__ __launch_bounds__(WM * WN * 64, (BM / WM) * (BN / WN) > 64 * 64 ? 2 :
         o[4] = ps; o[5] = pb1; o[6] = pm; o[7] = pb2;
     }
 #endif
+    if (EPI == 1) {
+        // lane = output row, registers 4q..4q+3 = columns 8q + 4*hh + (0..3) of the 32x32 tile
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int row = m0 + wm * (BM / WM) + i * 32 + li;
+            if (row >= p.M) continue;
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int colb = n0 + wn * (BN / WN) + j * 32 + 4 * hh;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int col = colb + 8 * q;
+                    if (col < p.N) emit4(p, ws, z, row, col, make_float4(acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]));
+                }
+            }
+        }
+        return;
+    }
+    if (EPI == 2) {
+        constexpr int LDT = 36;
+        static_assert(EPI != 2 || (TA::LDS_FLOATS >= (WM * WN / 2) * 32 * LDT && TB::LDS_FLOATS >= (WM * WN / 2) * 32 * LDT), "scratch does not fit");
+        float* scr = (wv < WM * WN / 2 ? As + wv * 32 * LDT : Bs + (wv - WM * WN / 2) * 32 * LDT);      // (the loop's last barrier freed As / Bs)
+        const int rr = lane >> 3, c4 = 4 * (lane & 7);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) scr[frag_row(r, lane) * LDT + li] = acc[i][j][r];
+                WAVE_SYNC();
+                const int col = n0 + wn * (BN / WN) + j * 32 + c4;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int row = m0 + wm * (BM / WM) + i * 32 + rr + 8 * q;
+                    const float4 v = *reinterpret_cast<const float4*>(&scr[(rr + 8 * q) * LDT + c4]);
+                    if (row < p.M && col < p.N) emit4(p, ws, z, row, col, v);
+                }
+                WAVE_SYNC();
+            }
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -303,18 +378,35 @@ __global__ __launch_bounds__(256) void splitk_reduce_group_kernel(const float* _
 }
 
 #include <stdlib.h>
-template <int BM, int BN, int WM, int WN, int VAR>
-static int launch_gemm_var(const GemmParams& p, int akm, int bkm, dim3 grid, dim3 block, hipStream_t st) {
-    if (!akm && !bkm) hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, false, false, VAR>), grid, block, 0, st, p);
-    else if (!akm && bkm) hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, false, true, VAR>), grid, block, 0, st, p);
-    else if (akm && bkm) hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, true, true, VAR>), grid, block, 0, st, p);
+template <int BM, int BN, int WM, int WN, int VAR, int EPI>
+static int launch_gemm_epi(const GemmParams& p, int akm, int bkm, dim3 grid, dim3 block, hipStream_t st) {
+    if (!akm && !bkm) hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, false, false, VAR, EPI>), grid, block, 0, st, p);
+    else if (!akm && bkm) hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, false, true, VAR, EPI>), grid, block, 0, st, p);
+    else if (akm && bkm) hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, true, true, VAR, EPI>), grid, block, 0, st, p);
     else return VAME_E_UNSUPPORTED;
     return VAME_OK;
+}
+// epilogue form per tile shape (see gemm_kernel): the LDS-transposed one needs the 128x128 tile's operand buffers as scratch
+template <int BM, int BN, int WM, int WN, int VAR>
+static int launch_gemm_var(const GemmParams& p, int akm, int bkm, dim3 grid, dim3 block, hipStream_t st) {
+    int epi = VAME_GEMM_EPI_DEFAULT;
+#if defined(VAME_EMU) || defined(VAME_GEMM_AB)      // host-emulator tests and the A/B tuning build exercise every form
+    if (const char* e = getenv("VAME_GEMM_EPI")) epi = atoi(e);
+#endif
+    if (BM == 128 && BN == 128) {
+        if (epi == 2) return launch_gemm_epi<BM, BN, WM, WN, VAR, (BM == 128 && BN == 128) ? 2 : 1>(p, akm, bkm, grid, block, st);
+        if (epi == 0) return launch_gemm_epi<BM, BN, WM, WN, VAR, 0>(p, akm, bkm, grid, block, st);
+        return launch_gemm_epi<BM, BN, WM, WN, VAR, 1>(p, akm, bkm, grid, block, st);
+    }
+    if (epi == 0) return launch_gemm_epi<BM, BN, WM, WN, VAR, 0>(p, akm, bkm, grid, block, st);
+    return launch_gemm_epi<BM, BN, WM, WN, VAR, 1>(p, akm, bkm, grid, block, st);
 }
 template <int BM, int BN, int WM, int WN>
 static int launch_gemm(GemmParams p, int akm, int bkm, hipStream_t st) {
     p.tiles_m = (int)cdiv64(p.M, BM); p.tiles_n = (int)cdiv64(p.N, BN);
     p.by_z = p.splitk >= 8;
+    p.cvec = ((uintptr_t)p.C % 16 == 0) && (p.ldc % 4 == 0);
+    p.wsvec = p.ws && ((uintptr_t)p.ws % 16 == 0) && (p.N % 4 == 0);
     const int64_t per_unit = p.by_z ? (int64_t)p.tiles_m * p.tiles_n : p.tiles_n;
     const int64_t nunits = p.by_z ? (int64_t)p.splitk * p.group : (int64_t)p.splitk * p.tiles_m;
     dim3 grid((unsigned)(cdiv64(nunits, 8) * per_unit * 8)), block(WM * WN * 64);

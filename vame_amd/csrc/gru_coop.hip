@@ -17,6 +17,7 @@
 #include "gru_desc.h"
 
 #ifdef VAME_EMU
+#include <chrono>
 #include <thread>
 #define COOP_STORE16(ptr, v) (*reinterpret_cast<f32x4*>(ptr) = (v))
 #define COOP_LOAD16(dst, ptr) ((dst) = *reinterpret_cast<const f32x4*>(ptr))
@@ -24,7 +25,7 @@
 #define COOP_DRAIN()
 #define COOP_FLAG_STORE(p, v) __atomic_store_n((p), (v), __ATOMIC_RELEASE)
 #define COOP_FLAG_LOAD(p) __atomic_load_n((p), __ATOMIC_ACQUIRE)
-#define COOP_BACKOFF() std::this_thread::yield()
+#define COOP_BACKOFF() std::this_thread::sleep_for(std::chrono::microseconds(20))   /* one OS thread per workgroup: let the others run */
 #else
 // 16-byte write-through store / L1-bypassing load (sc1); asm because HIP has no 16-byte agent-scope access
 #define COOP_STORE16(ptr, v) asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(ptr), "v"(v) : "memory")
@@ -37,8 +38,21 @@
 #define COOP_BACKOFF() __builtin_amdgcn_s_sleep(2)
 #endif
 
-constexpr int COOP_MAX_POLLS = 1 << 18;       // ~0.3 s: a stuck group reports instead of hanging the queue; once *status != 0 every
-                                              // later wait of the launch gives up at once (results undefined, the launch ends)
+// Poll budget of one hand-off wait.  A stuck group reports through *status instead of hanging the queue; once *status != 0 every
+// later wait of the launch gives up at once (results undefined, the launch ends) and the optimizer kernel that follows refuses to
+// apply the step (vame_adam_amsgrad_f32's abort_flag).  Device default ~0.3 s; the host emulator (one OS thread per workgroup,
+// possibly oversubscribed) waits practically for ever.  vame_gru_coop_set_poll_limit overrides it (diagnostics / fail-fast tests).
+#ifdef VAME_EMU
+constexpr int COOP_DEFAULT_POLLS = 1 << 30;
+#else
+constexpr int COOP_DEFAULT_POLLS = 1 << 18;
+#endif
+static int g_coop_polls = COOP_DEFAULT_POLLS;
+extern "C" int vame_gru_coop_set_poll_limit(int polls) {
+    const int old = g_coop_polls;
+    g_coop_polls = polls != 0 ? polls : COOP_DEFAULT_POLLS;      // < 0: fault injection -- every launch reports one timeout
+    return old;
+}
 
 // block -> (group, member).  Workgroup b runs on XCD b % 8 (observed; speed only): all members of a group share b % 8.
 template <int NM>
@@ -52,7 +66,8 @@ template <int NM>
 static int coop_grid(int ngroups) { return (int)cdiv64(ngroups, 8) * 8 * NM; }
 
 template <int H>
-__global__ __launch_bounds__(256) void gru_coop_fwd_kernel(GruFwdParams P, int* __restrict__ flags, int base, int* __restrict__ status) {
+__global__ __launch_bounds__(256) void gru_coop_fwd_kernel(GruFwdParams P, int* __restrict__ flags, int base, int* __restrict__ status,
+                                                           int max_polls) {
     constexpr int NM = H / 32, LDH = H + 4, KC = H / 8, LDE = 33, LDX = 36;
     VAME_DYN_SMEM(smem_raw);
     f32x4* wl = reinterpret_cast<f32x4*>(smem_raw);                         // [KC][3][64] B fragments of this member's W_hh slice
@@ -61,6 +76,8 @@ __global__ __launch_bounds__(256) void gru_coop_fwd_kernel(GruFwdParams P, int* 
     float* hx = ex + 2 * 32 * LDE;                                         // [32][LDX] this member's h_t slice, row-major
     int g, m;
     if (!coop_map<NM>(P.nstreams * P.ntiles, g, m)) return;
+    const bool inject = max_polls < 0;
+    if (inject) max_polls = COOP_DEFAULT_POLLS;
     const int sidx = g % P.nstreams, tile = g / P.nstreams + P.tile_off;
     const GruFwdStream& S = P.s[sidx];
     const int B = P.B, T = (int)S.T;
@@ -164,10 +181,11 @@ __global__ __launch_bounds__(256) void gru_coop_fwd_kernel(GruFwdParams P, int* 
         if (tid == 0) COOP_FLAG_STORE(&gflags[m], (int)((unsigned)base + (unsigned)step + 1u));
         // ---- wait for all members' slices of h_t, then rebuild the full 32 x H tile in LDS
         if (tid < NM) {
-            int polls = COOP_FLAG_LOAD(status) != 0 ? COOP_MAX_POLLS : 0;
+            if (inject && step == 0 && tid == 0) atomicAdd(status, 1);          // fault injection (diagnostics): report, then wait normally
+            int polls = COOP_FLAG_LOAD(status) != 0 && !inject ? max_polls : 0;
             while ((int)((unsigned)COOP_FLAG_LOAD(&gflags[tid]) - ((unsigned)base + (unsigned)step + 1u)) < 0) {   // wrap-safe
                 COOP_BACKOFF();
-                if (++polls > COOP_MAX_POLLS) { atomicAdd(status, 1); break; }
+                if (++polls > max_polls) { atomicAdd(status, 1); break; }
             }
         }
         __syncthreads();
@@ -234,11 +252,38 @@ static int coop_cu_count() {
 #endif
 }
 
+template <int H> static size_t coop_bwd_lds();
+template <int H> __global__ void gru_coop_bwd_kernel(GruBwdParams, float*, int*, int, int*, int);
+// The runtime's own answer to "how many of these workgroups does one CU hold" (registers, LDS, waves): every cooperative kernel
+// must get >= 1, and the grid is then limited to ONE workgroup per CU (their LDS footprints exclude a second one anyway).
+static int coop_kernels_resident(int H) {
+#ifdef VAME_EMU
+    return 1;
+#else
+    static int ok[2] = {-1, -1};
+    int& r = ok[H == 256];
+    if (r < 0) {
+        int nf = 0, nb = 0;
+        hipError_t e1, e2;
+        if (H == 256) {
+            e1 = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nf, gru_coop_fwd_kernel<256>, 256, coop_fwd_lds<256>());
+            e2 = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, gru_coop_bwd_kernel<256>, 256, coop_bwd_lds<256>());
+        } else {
+            e1 = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nf, gru_coop_fwd_kernel<128>, 256, coop_fwd_lds<128>());
+            e2 = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, gru_coop_bwd_kernel<128>, 256, coop_bwd_lds<128>());
+        }
+        r = (e1 == hipSuccess && e2 == hipSuccess && nf >= 1 && nb >= 1) ? 1 : 0;
+        (void)hipGetLastError();
+    }
+    return r;
+#endif
+}
+
 extern "C" int vame_gru_coop_supported(int nstreams, int B, int H) {
     if (H != 128 && H != 256) return 0;
     const int64_t groups = (int64_t)nstreams * cdiv64(B, 32);
     const int64_t grid = cdiv64(groups, 8) * 8 * (H / 32);
-    return grid <= 256 && grid <= coop_cu_count();
+    return grid <= 256 && grid <= coop_cu_count() && coop_kernels_resident(H);
 }
 // rows [row0, row0 + nrows) of the batch (row0 a multiple of 32; nrows = 0: all of it)
 static int coop_row_range(int B, int row0, int nrows, int& tile_off, int& ntiles) {
@@ -272,10 +317,10 @@ extern "C" int vame_gru_coop_fwd_f32(const int64_t* desc, int nstreams, int B, i
 #endif
     if (H == 256) {
         COOP_ALLOW_LDS(gru_coop_fwd_kernel<256>, coop_fwd_lds<256>());
-        hipLaunchKernelGGL((gru_coop_fwd_kernel<256>), dim3(coop_grid<8>(ngroups)), dim3(256), coop_fwd_lds<256>(), st, P, flags, epoch_base, status);
+        hipLaunchKernelGGL((gru_coop_fwd_kernel<256>), dim3(coop_grid<8>(ngroups)), dim3(256), coop_fwd_lds<256>(), st, P, flags, epoch_base, status, g_coop_polls);
     } else {
         COOP_ALLOW_LDS(gru_coop_fwd_kernel<128>, coop_fwd_lds<128>());
-        hipLaunchKernelGGL((gru_coop_fwd_kernel<128>), dim3(coop_grid<4>(ngroups)), dim3(256), coop_fwd_lds<128>(), st, P, flags, epoch_base, status);
+        hipLaunchKernelGGL((gru_coop_fwd_kernel<128>), dim3(coop_grid<4>(ngroups)), dim3(256), coop_fwd_lds<128>(), st, P, flags, epoch_base, status, g_coop_polls);
     }
 #ifdef VAME_EMU
     emu::g_coop = false;
@@ -294,7 +339,7 @@ extern "C" int vame_gru_coop_fwd_f32(const int64_t* desc, int nstreams, int B, i
 // summation order of that K = 3H contraction (split by member here).
 template <int H>
 __global__ __launch_bounds__(256) void gru_coop_bwd_kernel(GruBwdParams P, float* __restrict__ xbuf, int* __restrict__ flags, int base,
-                                                           int* __restrict__ status) {
+                                                           int* __restrict__ status, int max_polls) {
     constexpr int NM = H / 32, LDG = 132, LDP = H + 4, LDC = 36, TPW = NM / 4;      // TPW: 32-column output tiles per wave
     static_assert(NM == 8 || NM == 4, "written for H = 128 / 256");
     VAME_DYN_SMEM(smem_raw);
@@ -304,6 +349,8 @@ __global__ __launch_bounds__(256) void gru_coop_bwd_kernel(GruBwdParams P, float
     float* cd = ps + 32 * LDP;                                          // [32][LDC]  dh_t slice in, u-gated carry / reduced dh_{t-1} out
     int g, m;
     if (!coop_map<NM>(P.nstreams * P.ntiles, g, m)) return;
+    const bool inject = max_polls < 0;
+    if (inject) max_polls = COOP_DEFAULT_POLLS;
     const int sidx = g % P.nstreams, tile = g / P.nstreams + P.tile_off;
     const GruBwdStream& S = P.s[sidx];
     const int B = P.B, T = (int)S.T;
@@ -416,10 +463,11 @@ __global__ __launch_bounds__(256) void gru_coop_bwd_kernel(GruBwdParams P, float
         __syncthreads();
         if (tid == 0) COOP_FLAG_STORE(&gflags[m], (int)((unsigned)base + (unsigned)step + 1u));
         if (tid < NM) {
-            int polls = COOP_FLAG_LOAD(status) != 0 ? COOP_MAX_POLLS : 0;
+            if (inject && step == 0 && tid == 0) atomicAdd(status, 1);          // fault injection (diagnostics): report, then wait normally
+            int polls = COOP_FLAG_LOAD(status) != 0 && !inject ? max_polls : 0;
             while ((int)((unsigned)COOP_FLAG_LOAD(&gflags[tid]) - ((unsigned)base + (unsigned)step + 1u)) < 0) {   // wrap-safe
                 COOP_BACKOFF();
-                if (++polls > COOP_MAX_POLLS) { atomicAdd(status, 1); break; }
+                if (++polls > max_polls) { atomicAdd(status, 1); break; }
             }
         }
         __syncthreads();
@@ -486,10 +534,10 @@ extern "C" int vame_gru_coop_bwd_f32(const int64_t* desc, int nstreams, int B, i
 #endif
     if (H == 256) {
         COOP_ALLOW_LDS(gru_coop_bwd_kernel<256>, coop_bwd_lds<256>());
-        hipLaunchKernelGGL((gru_coop_bwd_kernel<256>), dim3(coop_grid<8>(ngroups)), dim3(256), coop_bwd_lds<256>(), st, P, xbuf, flags, epoch_base, status);
+        hipLaunchKernelGGL((gru_coop_bwd_kernel<256>), dim3(coop_grid<8>(ngroups)), dim3(256), coop_bwd_lds<256>(), st, P, xbuf, flags, epoch_base, status, g_coop_polls);
     } else {
         COOP_ALLOW_LDS(gru_coop_bwd_kernel<128>, coop_bwd_lds<128>());
-        hipLaunchKernelGGL((gru_coop_bwd_kernel<128>), dim3(coop_grid<4>(ngroups)), dim3(256), coop_bwd_lds<128>(), st, P, xbuf, flags, epoch_base, status);
+        hipLaunchKernelGGL((gru_coop_bwd_kernel<128>), dim3(coop_grid<4>(ngroups)), dim3(256), coop_bwd_lds<128>(), st, P, xbuf, flags, epoch_base, status, g_coop_polls);
     }
 #ifdef VAME_EMU
     emu::g_coop = false;

@@ -563,9 +563,13 @@ extern "C" int vame_gru_seq_fwd_f32(const int64_t* desc, int nstreams, int B, in
     switch (H) {
         case 32: launch_fwd<32>(P, st); break;
         case 64: launch_fwd<64>(P, st); break;
+        case 96: launch_fwd<96>(P, st); break;
         case 128: launch_fwd<128>(P, st); break;
+        case 160: launch_fwd<160>(P, st); break;
+        case 192: launch_fwd<192>(P, st); break;
+        case 224: launch_fwd<224>(P, st); break;
         case 256: launch_fwd<256>(P, st); break;
-        default: VAME_CHECK_ARG(false, VAME_E_UNSUPPORTED, "gru_seq_fwd: H=%d unsupported (32,64,128,256)", H);
+        default: VAME_CHECK_ARG(false, VAME_E_UNSUPPORTED, "gru_seq_fwd: H=%d unsupported (multiples of 32 up to 256)", H);
     }
     VAME_LAUNCH_CHECK("gru_seq_fwd");
     return VAME_OK;
@@ -580,9 +584,13 @@ extern "C" int vame_gru_seq_bwd_f32(const int64_t* desc, int nstreams, int B, in
     switch (H) {
         case 32: launch_bwd<32>(P, st); break;
         case 64: launch_bwd<64>(P, st); break;
+        case 96: launch_bwd<96>(P, st); break;
         case 128: launch_bwd<128>(P, st); break;
+        case 160: launch_bwd<160>(P, st); break;
+        case 192: launch_bwd<192>(P, st); break;
+        case 224: launch_bwd<224>(P, st); break;
         case 256: launch_bwd<256>(P, st); break;
-        default: VAME_CHECK_ARG(false, VAME_E_UNSUPPORTED, "gru_seq_bwd: H=%d unsupported (32,64,128,256)", H);
+        default: VAME_CHECK_ARG(false, VAME_E_UNSUPPORTED, "gru_seq_bwd: H=%d unsupported (multiples of 32 up to 256)", H);
     }
     VAME_LAUNCH_CHECK("gru_seq_bwd");
     return VAME_OK;

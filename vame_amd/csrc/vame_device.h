@@ -10,6 +10,7 @@ typedef f32x4_emu f32x4;
 #define MFMA_16x16x4(a, b, c) emu_mfma_16x16x4((a), (b), (c))
 #define VAME_DYN_SMEM(name) char* name = emu::dyn_smem()
 #define SETPRIO(n)
+#define WAVE_SYNC() emu::wave_sync()      /* lanes are fibers on the host: a wave-private LDS exchange needs an explicit rendezvous */
 #define SCHED_FENCE()
 #define RING_FENCE()
 #define RING_LOAD(dst, ptr, idx) (dst) = *reinterpret_cast<const f32x4*>((ptr) + (idx))
@@ -26,6 +27,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define MFMA_16x16x4(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
 #define VAME_DYN_SMEM(name) extern __shared__ __attribute__((aligned(16))) char name[]
 #define SETPRIO(n) __builtin_amdgcn_s_setprio(n)
+#define WAVE_SYNC() __builtin_amdgcn_wave_barrier()   /* lanes of a wave run in lock step and its LDS accesses complete in order: ordering hint only */
 #define SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)   /* keep the scheduler from merging phases (register pressure) */
 #define RING_FENCE() __builtin_amdgcn_sched_barrier(0)    /* prefetch-ring refills stay behind the MFMAs that read the slot */
 // Register prefetch ring for the L2-resident weight fragments.  hipcc's own s_waitcnt insertion drains the whole vector-memory

@@ -37,6 +37,17 @@ class Spec:
     softplus: bool
     legacy: bool = False      # RNN_VAE_LEGACY topology (rnn_model.py:186-324): encoder = two stacked 1-layer bi-GRUs, softplus
                               # always, uni-directional reconstruction decoder, no latent->hidden initial states
+    H_rec: int = 0            # hidden_size_rec / hidden_size_pred (rnn_model.py:148-160) when they differ from the encoder's
+    H_pred: int = 0           # hidden size H (0 = same as H)
+    dropout: float = 0.0      # dropout_encoder: inter-layer dropout of the 2-layer encoder GRU in training (rnn_model.py:34-35)
+
+    @property
+    def Hd(self):
+        return self.H_rec or self.H
+
+    @property
+    def Hf(self):
+        return self.H_pred or self.H
 
 
 class ParamTable:
@@ -86,12 +97,15 @@ class VAEEngine:
     def __init__(self, spec: Spec, table: ParamTable, flat_p: torch.Tensor, flat_g: torch.Tensor):
         self.spec, self.table, self.p, self.g = spec, table, flat_p, flat_g
         self.dev = flat_p.device
-        H, F, Z = spec.H, spec.F, spec.Z
-        if H % 32 or H > 1024:
-            raise ValueError(f"hidden size {H}: the gfx950 GRU kernels support multiples of 32 up to 1024")
+        H, F, Z, Hd, Hf = spec.H, spec.F, spec.Z, spec.Hd, spec.Hf
+        for hh in (H, Hd, Hf):
+            if hh % 32 or hh > 1024:
+                raise ValueError(f"hidden size {hh}: the gfx950 GRU kernels support multiples of 32 up to 1024")
+        if spec.legacy and not (H == Hd == Hf):
+            raise ValueError("RNN_VAE_LEGACY on the gfx950 kernels needs one hidden size for all GRUs")
         # H <= 256: persistent sequence kernels (h and the gate tiles stay on chip for all T steps).  Larger H: the gate
         # GEMM per step is a real dense contraction (M = batch) -> per-step vame_gemm_f32 + gate-math kernels
-        self.stepwise = H > 256
+        self.force_stepwise = False
         if spec.legacy:       # same arithmetic as the 2-layer encoder, parameters live in two 1-layer modules
             e0, e1, s1 = "encoder.rnn_1", "encoder.rnn_2", "_l0"
         else:
@@ -99,12 +113,12 @@ class VAEEngine:
             s1 = "_l1"
         self.enc = [[GruDir(e0, "_l0", H, F, self.dev), GruDir(e0, "_l0_reverse", H, F, self.dev)],
                     [GruDir(e1, s1, H, 2 * H, self.dev), GruDir(e1, s1 + "_reverse", H, 2 * H, self.dev)]]
-        self.dec = [GruDir("decoder.rnn_rec", "_l0", H, Z, self.dev)]
+        self.dec = [GruDir("decoder.rnn_rec", "_l0", Hd, Z, self.dev)]
         if not spec.legacy:
-            self.dec.append(GruDir("decoder.rnn_rec", "_l0_reverse", H, Z, self.dev))
+            self.dec.append(GruDir("decoder.rnn_rec", "_l0_reverse", Hd, Z, self.dev))
         self.h0_from_z = not spec.legacy      # Linear(z).view(2,B,H) initial states (rnn_model.py:103-104,136-137); legacy: zeros
-        self.fut = ([GruDir("decoder_future.rnn_pred", "_l0", H, Z, self.dev),
-                     GruDir("decoder_future.rnn_pred", "_l0_reverse", H, Z, self.dev)] if spec.future else [])
+        self.fut = ([GruDir("decoder_future.rnn_pred", "_l0", Hf, Z, self.dev),
+                     GruDir("decoder_future.rnn_pred", "_l0_reverse", Hf, Z, self.dev)] if spec.future else [])
         self.ws = Workspace()
         self._wgrad_queue = None
         self.group_wgrads = os.environ.get("VAME_AMD_GROUP_WGRADS", "1") != "0"
@@ -119,11 +133,25 @@ class VAEEngine:
         self.coop = os.environ.get("VAME_AMD_COOP", "1") != "0"
         self._coop_state = None
         self._nuc_state = None
+        self._drop_mask = None
         self.packed_version = -1
         self.version = 0          # bumped by the owner whenever flat_p changes
+        self.serial = 0           # bumped by every call that overwrites the forward workspace (stale-backward guard)
         self._B = None
 
     # ------------------------------------------------------------------ helpers
+    @property
+    def stepwise(self):
+        """True when the ENCODER runs the per-step GEMM path (tests force it on small models by assignment)."""
+        return self._stepwise(self.spec.H)
+
+    @stepwise.setter
+    def stepwise(self, v):
+        self.force_stepwise = bool(v)
+
+    def _stepwise(self, H):
+        return self.force_stepwise or H > 256
+
     def _all_dirs(self):
         return self.enc[0] + self.enc[1] + self.dec + self.fut
 
@@ -270,16 +298,31 @@ class VAEEngine:
 
     # ------------------------------------------------------------------ GRU sequence dispatch
     def check_async_errors(self):
-        """Called where the host synchronises anyway (once per epoch): surfaces device-side failures that cannot raise."""
+        """Called where the host synchronises anyway (end of an epoch, before a checkpoint, after an inference call whose result
+        goes to the host): surfaces device-side failures that cannot raise.  Free when no cooperative launch happened since."""
         if self._coop_state is not None:
             self._coop_state.check()
 
-    def _coop_parts(self, rows, B, tkey=None):
+    def poll_async_errors(self):
+        """Start of a step: raise if an earlier step's status snapshot has arrived non-zero (never blocks)."""
+        if self._coop_state is not None:
+            self._coop_state.poll()
+
+    def snapshot_async_errors(self):
+        """End of a step: enqueue the 4-byte status copy that poll_async_errors() of the next steps looks at."""
+        if self._coop_state is not None:
+            self._coop_state.snapshot()
+
+    def abort_flag(self):
+        """Device word the optimizer kernel tests before it touches the weights (None: no cooperative launch so far)."""
+        return self._coop_state.status if self._coop_state is not None else None
+
+    def _coop_parts(self, rows, B, tkey=None, H=None):
         """[(streams, (row0, nrows))] cooperative launches that cover this GRU launch, each fitting one workgroup per CU; at
         most two per stream set (beyond that the persistent kernels win).  [] = use the persistent kernels."""
-        if self.stepwise or not self.coop:
+        H = H or self.spec.H
+        if self._stepwise(H) or not self.coop:
             return []
-        H = self.spec.H
         steps = lambda r: int(r[tkey]) if (r and tkey is not None) else 1                    # noqa: E731
         options = [([rows], ops.coop_row_chunks(len(rows), B, H))]
         if len(rows) > 2 and len(rows) % 2 == 0:                       # decoder + future decoder: one pair of directions each
@@ -294,31 +337,39 @@ class VAEEngine:
         return [(st, ch) for st in sets for ch in chunks]
 
     def _gru_fwd(self, rows, B):
-        if not self.stepwise:
-            if all(r[GF["Y"]] and not r.get(GF["WPX"]) for r in rows):
-                parts = self._coop_parts(rows, B, GF["T"])
+        """One launch for streams of one hidden size; streams of different sizes (hidden_size_rec != hidden_size_pred) go out
+        as one launch per size."""
+        for H in sorted({r["_s"].d.H for r in rows}, reverse=True):
+            part_rows = [r for r in rows if r["_s"].d.H == H]
+            if self._stepwise(H):
+                for r in part_rows:
+                    self._stepwise_fwd(r["_s"], B)
+                continue
+            if all(r[GF["Y"]] and not r.get(GF["WPX"]) for r in part_rows):
+                parts = self._coop_parts(part_rows, B, GF["T"], H)
                 for part, chunk in parts:
-                    ops.gru_coop_fwd(part, B, self.spec.H, self._coop_state, rows=chunk)
+                    ops.gru_coop_fwd(part, B, H, self._coop_state, rows=chunk)
                 if parts:
-                    return
-            return ops.gru_seq_fwd(rows, B, self.spec.H)
-        for r in rows:
-            self._stepwise_fwd(r["_s"], B)
+                    continue
+            ops.gru_seq_fwd(part_rows, B, H)
 
     def _gru_bwd(self, rows, B):
-        if not self.stepwise:
-            parts = self._coop_parts(rows, B, GB["T"])
+        for H in sorted({r["_s"].d.H for r in rows}, reverse=True):
+            part_rows = [r for r in rows if r["_s"].d.H == H]
+            if self._stepwise(H):
+                for r in part_rows:
+                    self._stepwise_bwd(r["_s"], B)
+                continue
+            parts = self._coop_parts(part_rows, B, GB["T"], H)
             for part, chunk in parts:
-                ops.gru_coop_bwd(part, B, self.spec.H, self._coop_state, rows=chunk)
-            if parts:
-                return
-            return ops.gru_seq_bwd(rows, B, self.spec.H)
-        for r in rows:
-            self._stepwise_bwd(r["_s"], B)
+                ops.gru_coop_bwd(part, B, H, self._coop_state, rows=chunk)
+            if not parts:
+                ops.gru_seq_bwd(part_rows, B, H)
 
     def _stepwise_fwd(self, s, B):
         """One (layer,direction) stream step by step: gh = h_{t-1} W_hh^T (GEMM) then the gate kernel."""
-        H, d, T = self.spec.H, s.d, s.T
+        d, T = s.d, s.T
+        H = d.H
         Yrow, col = (s.y_T + 2) * 2 * H, s.dirn * H
         Y = s.Y if (s.Y is not None and s.write_y) else self.buf("Y_step", B, s.y_T + 2, 2 * H)
         yv = Y[:B * Yrow].view(B, s.y_T + 2, 2 * H)
@@ -340,7 +391,8 @@ class VAEEngine:
             s.hn[:rows * s.hn_row].view(rows, s.hn_row)[:B, s.hn_off:s.hn_off + H].copy_(yv[:, last, col:col + H])
 
     def _stepwise_bwd(self, s, B):
-        H, d, T = self.spec.H, s.d, s.T
+        d, T = s.d, s.T
+        H = d.H
         dh, dgh = self.buf("dh_step", B, H), self.buf("dgh_step", B, 3 * H)
         dhv = dh[:B * H].view(B, H)
         if s.dhn is not None:
@@ -366,7 +418,7 @@ class VAEEngine:
     # ------------------------------------------------------------------ forward
     def _gru_fwd_stream(self, d: GruDir, gi, gi_row, gi_t, h0, h0_off, Y, y_cols, y_T, dirn, hn, hn_off, hn_row, stash, T,
                         write_y=True):
-        H = self.spec.H
+        H = d.H
         spec = SimpleNamespace(d=d, gi=gi, gi_row=gi_row, gi_t=gi_t, h0=h0, h0_off=h0_off, Y=Y, y_T=y_T, dirn=dirn, hn=hn,
                                hn_off=hn_off, hn_row=hn_row, stash=stash, T=T, write_y=write_y)
         return {"_s": spec,
@@ -377,10 +429,13 @@ class VAEEngine:
                 GF["HN"]: ops.addr(hn, hn_off) if hn is not None else 0, GF["HN_ROW"]: hn_row,
                 GF["STASH"]: ops.addr(stash) if stash is not None else 0, GF["T"]: T, GF["REVERSE"]: dirn, GF["PAD"]: 1}
 
-    def encode(self, win, win_row, B, training):
-        """win: (B, >=T, F) windows with row stride win_row (elements).  Returns hn (B,4H)."""
+    def encode(self, win, win_row, B, training, drop_mask=None):
+        """win: (B, >=T, F) windows with row stride win_row (elements).  Returns hn (B,4H).
+        drop_mask (B,T,2H) of {0,1}: inter-layer dropout of the encoder (training, spec.dropout > 0): layer 1 reads
+        Y0 * mask / (1 - p) (torch.nn.GRU semantics: the final states of layer 0 stay undropped)."""
         s, H, T, F = self.spec, self.spec.H, self.spec.T, self.spec.F
         self.repack()
+        self.serial += 1
         x_op = Operand(win, F, seg=T, seg_stride=win_row)
         Y0 = self.buf("Y0", B, T + 2, 2 * H)
         hn = self.buf("hn", B, 4 * H)
@@ -400,6 +455,14 @@ class VAEEngine:
             rows.append(row)
         self._gru_fwd(rows, B)
         y_op = Operand(Y0, 2 * H, off=2 * H, seg=T, seg_stride=(T + 2) * 2 * H)
+        self._drop_mask = None
+        if training and s.dropout > 0:
+            if drop_mask is None:
+                raise ValueError("encode(training=True) with dropout_encoder > 0 needs a dropout mask")
+            Y0d = self.buf("Y0d", B, T, 2 * H)
+            ops.mask_scale(Y0, 2 * H, 2 * H, T, (T + 2) * 2 * H, drop_mask, 1.0 / (1.0 - s.dropout), Y0d, B * T, 2 * H)
+            y_op = Operand(Y0d, 2 * H)
+            self._drop_mask = drop_mask
         Y1 = self.buf("Y1", B, T + 2, 2 * H) if (training or coop) else None
         rows, jobs = [], []
         for dirn, d in enumerate(self.enc[1]):
@@ -415,6 +478,7 @@ class VAEEngine:
 
     def latent(self, hn, B, eps, training, want_kl=True):
         s, H, Z = self.spec, self.spec.H, self.spec.Z
+        self.serial += 1
         mu, lvr = self.buf("mu", B, Z), self.buf("lv_raw", B, Z)
         logvar, z = self.buf("logvar", B, Z), self.buf("z", B, Z)
         hn_op = Operand(hn, 4 * H)
@@ -428,7 +492,7 @@ class VAEEngine:
         return z, mu, logvar
 
     def _decode_one(self, tag, name, dirs, steps, z, B, training, rows, jobs):
-        H, Z = self.spec.H, self.spec.Z
+        H, Z = dirs[0].H, self.spec.Z
         hid = None
         if self.h0_from_z:
             hid = self.buf(f"hid_{tag}", B, 2 * H)
@@ -443,23 +507,30 @@ class VAEEngine:
             rows.append(self._gru_fwd_stream(d, gi, 3 * H, 0, hid, dirn * B * H, Y, 2 * H, steps, dirn, None, 0, 0, st, steps))
         return Y
 
-    def decode(self, z, B, training):
+    def decode(self, z, B, training, which="both"):
+        """Decoder (+ Decoder_Future) from z.  which = "dec" / "fut" runs only that one (the sub-module call patterns
+        model.decoder(ins, z) / model.decoder_future(ins, z) of generative_functions.py:39)."""
         s, H, F, T, FS = self.spec, self.spec.H, self.spec.F, self.spec.T, self.spec.FS
         self.repack()
+        self.serial += 1
         rows, jobs = [], []
-        Yd = self._decode_one("dec", "decoder", self.dec, T, z, B, training, rows, jobs)
-        Yf = self._decode_one("fut", "decoder_future", self.fut, FS, z, B, training, rows, jobs) if s.future else None
+        want_d, want_f = which in ("both", "dec"), s.future and which in ("both", "fut")
+        Yd = self._decode_one("dec", "decoder", self.dec, T, z, B, training, rows, jobs) if want_d else None
+        Yf = self._decode_one("fut", "decoder_future", self.fut, FS, z, B, training, rows, jobs) if want_f else None
         self._parallel(jobs, self.small_streams)      # <= 6 independent (B x 3H|2H x Z) projections of z
         self._gru_fwd(rows, B)
-        pred = self.buf("pred", B, T, F)
-        Kd = len(self.dec) * H                 # H for the uni-directional legacy decoder: only the first half of each Y row
-        ops.gemm(B * T, F, Kd, Operand(Yd, 2 * H, off=2 * H, seg=T, seg_stride=(T + 2) * 2 * H), 0,
-                 self.P("decoder.hidden_to_output.weight", Kd), 0, pred, F, bias=self._pv("decoder.hidden_to_output.bias"))
+        H, Hf = s.Hd, s.Hf
+        pred = None
+        if want_d:
+            pred = self.buf("pred", B, T, F)
+            Kd = len(self.dec) * H             # H for the uni-directional legacy decoder: only the first half of each Y row
+            ops.gemm(B * T, F, Kd, Operand(Yd, 2 * H, off=2 * H, seg=T, seg_stride=(T + 2) * 2 * H), 0,
+                     self.P("decoder.hidden_to_output.weight", Kd), 0, pred, F, bias=self._pv("decoder.hidden_to_output.bias"))
         fut = None
-        if s.future:
+        if want_f:
             fut = self.buf("futp", B, FS, F)
-            ops.gemm(B * FS, F, 2 * H, Operand(Yf, 2 * H, off=2 * H, seg=FS, seg_stride=(FS + 2) * 2 * H), 0,
-                     self.P("decoder_future.hidden_to_output.weight", 2 * H), 0, fut, F,
+            ops.gemm(B * FS, F, 2 * Hf, Operand(Yf, 2 * Hf, off=2 * Hf, seg=FS, seg_stride=(FS + 2) * 2 * Hf), 0,
+                     self.P("decoder_future.hidden_to_output.weight", 2 * Hf), 0, fut, F,
                      bias=self._pv("decoder_future.hidden_to_output.bias"))
         return pred, fut
 
@@ -475,13 +546,13 @@ class VAEEngine:
         ops.nuclear(G, Z, kloss, B, klmbda, bsize, self.buf("losses", 8), LOSS_KMEANS, self.buf("Minv", Z, Z), gscale=kl_weight,
                     vstate=self._nuc_state)
 
-    def forward(self, win, win_row, B, eps, training, cluster=None, enc_in=None):
+    def forward(self, win, win_row, B, eps, training, cluster=None, enc_in=None, drop_mask=None):
         """Full RNN_VAE.forward (rnn_model.py:162-179).  Returns workspace views pred, fut, z, mu, logvar.
         cluster = (kl_weight, kloss, klmbda, bsize) also evaluates the nuclear-norm loss as soon as z exists.
         enc_in (B,T,F contiguous) replaces the first T steps of `win` as the encoder input (input-noise option)."""
         s = self.spec
         xin, xin_row = (win, win_row) if enc_in is None else (enc_in, s.T * s.F)
-        hn = self.encode(xin, xin_row, B, training)
+        hn = self.encode(xin, xin_row, B, training, drop_mask=drop_mask)
         z, mu, logvar = self.latent(hn, B, eps, training)
         if cluster is not None:
             self.cluster_terms(B, *cluster)
@@ -512,7 +583,7 @@ class VAEEngine:
 
     # ------------------------------------------------------------------ backward
     def _gru_bwd_stream(self, d, stash, Y, y_T, dirn, dY, dy_T, dhn, dhn_off, dhn_row, dG, dh0, dh0_off, dbias, T):
-        H = self.spec.H
+        H = d.H
         spec = SimpleNamespace(d=d, stash=stash, Y=Y, y_T=y_T, dirn=dirn, dY=dY, dy_T=dy_T, dhn=dhn, dhn_off=dhn_off, dhn_row=dhn_row,
                                dG=dG, dh0=dh0, dh0_off=dh0_off, dbias=dbias, T=T)
         return {"_s": spec,
@@ -525,7 +596,7 @@ class VAEEngine:
 
     def _gru_param_grads(self, d: GruDir, dG, dbias, ntiles, B, T, Yseq, dirn, x_op, x_K, const_in=None):
         """dW_ih, dW_hh, db_ih, db_hh of one (layer,direction) from its dG (B,T,4H) stash."""
-        H, g, t = self.spec.H, self.g, self.table
+        H, g, t = d.H, self.g, self.table
         K = B * T
         dG_i = Operand(dG, 4 * H)                               # [da_r | da_z | dgi_n] = cols 0..3H
         if const_in is None:
@@ -543,7 +614,7 @@ class VAEEngine:
                               (dbias, 3 * H, ntiles, H, 4 * H, g, ob_h + 2 * H)]
 
     def _decoder_backward(self, tag, name, dirs, steps, dpred, B, dz, first):
-        H, F, Z, t = self.spec.H, self.spec.F, self.spec.Z, self.table
+        H, F, Z, t = dirs[0].H, self.spec.F, self.spec.Z, self.table
         ntiles = (B + 31) // 32
         Y = self.buf(f"Y_{tag}", B, steps + 2, 2 * H)
         Yrows = Operand(Y, 2 * H, off=2 * H, seg=steps, seg_stride=(steps + 2) * 2 * H)
@@ -583,7 +654,9 @@ class VAEEngine:
             groups.append(("decoder_future", per_f, Yf, dhid_f, FS))
         self._gru_bwd(rows, B)
         first = True
+        He = H
         for name, per, Y, dhid, steps in groups:
+            H = per[0][0].H                                          # hidden size of this decoder
             for dirn, (d, dG, dbias, dgsum) in enumerate(per):
                 ops.timesum(dG, B, steps, 3 * H, 4 * H, dgsum)       # z is constant in time: sum_t dG first
                 self._gru_param_grads(d, dG, dbias, ntiles, B, steps, Y, dirn, None, Z, const_in=(dgsum, z))
@@ -594,6 +667,7 @@ class VAEEngine:
                 self._gemm_wgrad(2 * H, Z, B, Operand(dhid, 2 * H), Operand(z, Z), wl)
                 ops.colsum(dhid, 0, B, 2 * H, 2 * H, self.g, t.off(f"{name}.latent_to_hidden.bias"))
                 ops.gemm(B, Z, 2 * H, Operand(dhid, 2 * H), 0, self.P(wl, Z), 1, dz, Z, accumulate=True, splitk=0)
+        H = He
         if use_minv and kl_weight != 0:
             ops.gemm(B, Z, Z, Operand(z, Z), 0, Operand(self.buf("Minv", Z, Z), Z), 1, dz, Z, accumulate=True)
         if dz_ext is not None:
@@ -625,9 +699,13 @@ class VAEEngine:
         self._gru_bwd(rows, B)
         dY0 = self.buf("dY0", B, T, 2 * H)
         y0rows = Operand(Y0, 2 * H, off=2 * H, seg=T, seg_stride=(T + 2) * 2 * H)
+        if self._drop_mask is not None:             # layer 1 saw the dropped sequence: its dW_ih contracts with that one
+            y0rows = Operand(self.buf("Y0d", B, T, 2 * H), 2 * H)
         for dirn, (d, dG, dbias) in enumerate(per):
             ops.gemm(B * T, 2 * H, 3 * H, Operand(dG, 4 * H), 0, self.P(d.w_ih, 2 * H), 1, dY0, 2 * H, accumulate=dirn > 0)
             self._gru_param_grads(d, dG, dbias, ntiles, B, T, Y1, dirn, y0rows, 2 * H)
+        if self._drop_mask is not None:             # d(Y0 * m / (1-p)) / dY0
+            ops.mask_scale(dY0, 0, 2 * H, 0, 0, self._drop_mask, 1.0 / (1.0 - s.dropout), dY0, B * T, 2 * H)
         # ---- encoder layer 0
         rows, per = [], []
         for dirn, d in enumerate(self.enc[0]):

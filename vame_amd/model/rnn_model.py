@@ -44,7 +44,9 @@ class Encoder(nn.Module, _EngineOwner):
         _check(T == eng.spec.T and F == eng.spec.F, f"encoder input {tuple(x.shape)} != (B,{eng.spec.T},{eng.spec.F})")
         with torch.no_grad():
             hn = eng.encode(x, T * F, B, training=False)
-            return hn[:B * 4 * eng.spec.H].view(B, 4 * eng.spec.H).clone()
+            out = hn[:B * 4 * eng.spec.H].view(B, 4 * eng.spec.H).clone()
+        eng.check_async_errors()
+        return out
 
 
 class Lambda(nn.Module, _EngineOwner):
@@ -77,13 +79,22 @@ class _DecoderBase(nn.Module, _EngineOwner):
         eng = self._eng()
         zt = _as_f32(z, eng.dev)
         B = zt.shape[0]
-        # `inputs` is z tiled over time by construction (rnn_model.py:169-170); the kernels read z once.
+        # `inputs` is z tiled over time in every reference caller (rnn_model.py:169-170, generative_functions.py:36-39); the kernels
+        # read z once.  A caller that passes something else gets an error instead of silently different numbers.
+        if inputs is not None and torch.is_tensor(inputs):
+            steps = eng.spec.T if which == "dec" else eng.spec.FS
+            _check(inputs.dim() == 3 and inputs.shape[0] == B and inputs.shape[1] >= steps and inputs.shape[2] == eng.spec.Z,
+                   f"decoder inputs {tuple(inputs.shape)}: expected z tiled over time (B, >={steps}, {eng.spec.Z})")
+            it = inputs.detach().to(device=eng.dev, dtype=torch.float32)
+            _check(bool(torch.equal(it[:, 0, :], zt) and torch.equal(it[:, steps - 1, :], zt)),
+                   "vame_amd decoders take the latent tiled over time as `inputs` (as RNN_VAE.forward builds it); other inputs are "
+                   "not supported by the fused kernels")
         with torch.no_grad():
-            pred, fut = eng.decode(zt, B, training=False)
+            pred, fut = eng.decode(zt, B, training=False, which=which)
             s = eng.spec
-            if which == "dec":
-                return pred[:B * s.T * s.F].view(B, s.T, s.F).clone()
-            return fut[:B * s.FS * s.F].view(B, s.FS, s.F).clone()
+            out = pred[:B * s.T * s.F].view(B, s.T, s.F).clone() if which == "dec" else fut[:B * s.FS * s.F].view(B, s.FS, s.F).clone()
+        eng.check_async_errors()
+        return out
 
 
 class Decoder(_DecoderBase):
@@ -132,11 +143,11 @@ class _VAEFunction(torch.autograd.Function):
     """Autograd bridge for `model(x)` in training mode: HIP forward, HIP backward into the flat bucket."""
 
     @staticmethod
-    def forward(ctx, model, x, eps, *params):
+    def forward(ctx, model, x, eps, drop_mask, *params):
         eng = model._ensure_engine()
         B = x.shape[0]
-        outs = eng.forward(x, x.shape[1] * x.shape[2], B, eps, training=True)
-        ctx.model, ctx.B, ctx.x = model, B, x
+        outs = eng.forward(x, x.shape[1] * x.shape[2], B, eps, training=True, drop_mask=drop_mask)
+        ctx.model, ctx.B, ctx.x, ctx.serial = model, B, x, eng.serial
         return tuple(o.clone() if o is not None else None for o in outs)
 
     @staticmethod
@@ -144,6 +155,12 @@ class _VAEFunction(torch.autograd.Function):
         model, B = ctx.model, ctx.B
         eng = model._ensure_engine()
         s = eng.spec
+        if eng.serial != ctx.serial:
+            # the BPTT stashes / sequences of this forward live in the engine's shared workspace (one step's worth, ~11 GB at
+            # batch 4096): another forward of the same model has overwritten them, so these gradients would be another batch's
+            raise RuntimeError("vame_amd.RNN_VAE: backward() of a forward pass whose activations were overwritten by a later "
+                               "model(x) / loss_step / encoder / decoder call; call backward() before the next forward "
+                               "(one outstanding training forward per model)")
 
         def seed(name, g, n):
             buf = eng.buf(name, n)
@@ -161,7 +178,7 @@ class _VAEFunction(torch.autograd.Function):
         finally:
             eng.g = model._flat_g
         model._accumulate_tmp_grads()
-        return (None, None, None) + (None,) * len(model._param_list)
+        return (None, None, None, None) + (None,) * len(model._param_list)
 
 
 class RNN_VAE(nn.Module):
@@ -170,16 +187,21 @@ class RNN_VAE(nn.Module):
     def __init__(self, TEMPORAL_WINDOW, ZDIMS, NUM_FEATURES, FUTURE_DECODER, FUTURE_STEPS, hidden_size_layer_1,
                  hidden_size_layer_2, hidden_size_rec, hidden_size_pred, dropout_encoder, dropout_rec, dropout_pred, softplus):
         super().__init__()
-        _check(hidden_size_layer_1 == hidden_size_rec and (not FUTURE_DECODER or hidden_size_pred == hidden_size_layer_1)
-               and (not self._LEGACY or hidden_size_layer_2 == hidden_size_layer_1),
-               "vame_amd: the gfx950 kernels need one hidden size for encoder, decoder and future decoder")
-        _check(not (dropout_encoder or dropout_rec or dropout_pred), "vame_amd: dropout > 0 is not supported by the HIP GRU kernels")
+        _check(not self._LEGACY or (hidden_size_layer_2 == hidden_size_layer_1 == hidden_size_rec
+                                    and (not FUTURE_DECODER or hidden_size_pred == hidden_size_layer_1)),
+               "vame_amd: RNN_VAE_LEGACY on the gfx950 kernels needs one hidden size for all GRUs")
+        _check(0 <= float(dropout_encoder) < 1, f"dropout_encoder={dropout_encoder} must be in [0, 1)")
+        # dropout_rec / dropout_pred: torch.nn.GRU ignores dropout for num_layers=1 (it only warns), so they have no effect in
+        # the reference either (rnn_model.py:91-92,125-126); dropout_encoder acts between the two encoder layers in training
         self.FUTURE_DECODER = FUTURE_DECODER
         self.seq_len = int(TEMPORAL_WINDOW / 2)
         self._build_modules(ZDIMS, NUM_FEATURES, FUTURE_DECODER, FUTURE_STEPS, hidden_size_layer_1, hidden_size_layer_2,
                             hidden_size_rec, hidden_size_pred, dropout_encoder, dropout_rec, dropout_pred, softplus)
         self.spec = Spec(T=self.seq_len, F=NUM_FEATURES, Z=ZDIMS, H=hidden_size_layer_1, FS=FUTURE_STEPS if FUTURE_DECODER else 0,
-                         future=bool(FUTURE_DECODER), softplus=bool(softplus) or self._LEGACY, legacy=self._LEGACY)
+                         future=bool(FUTURE_DECODER), softplus=bool(softplus) or self._LEGACY, legacy=self._LEGACY,
+                         H_rec=0 if hidden_size_rec == hidden_size_layer_1 else hidden_size_rec,
+                         H_pred=0 if (not FUTURE_DECODER or hidden_size_pred == hidden_size_layer_1) else hidden_size_pred,
+                         dropout=0.0 if self._LEGACY else float(dropout_encoder))
         for m in (self.encoder, self.lmbda, self.decoder, getattr(self, "decoder_future", None)):
             if m is not None:
                 object.__setattr__(m, "_owner", (self,))       # tuple: not registered as a sub-module
@@ -198,8 +220,7 @@ class RNN_VAE(nn.Module):
     def _ensure_engine(self):
         plist = list(self.named_parameters())
         dev = plist[0][1].device
-        if dev.type != "cuda" and not _lib.emulated():
-            raise _lib.VameHipError("vame_amd.RNN_VAE runs only on an MI355X: move the model with .cuda() (no CPU fallback)")
+        _lib.require_device_tensor(plist[0][1])     # "move the model with .cuda()": there is no CPU fallback
         ok = self._flat_p is not None and self._flat_p.device == dev
         if ok:
             base, esz, tab = self._flat_p.data_ptr(), 4, self._table
@@ -237,10 +258,23 @@ class RNN_VAE(nn.Module):
         return self._flat_p, self._flat_g
 
     # ---------------------------------------------------------------- forward
-    def forward(self, seq, eps=None):
+    def _dropout_mask(self, B, drop_mask, dev):
+        """{0,1} keep-mask (B, T, 2H) of the encoder's inter-layer dropout (training, dropout_encoder > 0), drawn on the device
+        unless injected (parity tests)."""
+        s = self.spec
+        if not (self.training and s.dropout > 0):
+            return None
+        if drop_mask is None:
+            return torch.bernoulli(torch.full((B, s.T, 2 * s.H), 1.0 - s.dropout, device=dev))
+        drop_mask = drop_mask.to(device=dev, dtype=torch.float32).contiguous()
+        _check(tuple(drop_mask.shape) == (B, s.T, 2 * s.H), f"drop_mask {tuple(drop_mask.shape)} != {(B, s.T, 2 * s.H)}")
+        return drop_mask
+
+    def forward(self, seq, eps=None, drop_mask=None):
         """rnn_model.py:162-179.  Returns (prediction, future, z, mu, logvar) or, without the
         future decoder, (prediction, z, mu, logvar).  `eps` optionally injects the N(0,1) draw of
-        the reparameterisation (parity tests); by default it is drawn on the device."""
+        the reparameterisation, `drop_mask` the encoder's dropout keep-mask (parity tests); by default both are drawn on
+        the device."""
         eng = self._ensure_engine()
         s = self.spec
         x = seq.to(device=eng.dev, dtype=torch.float32).contiguous()
@@ -250,14 +284,16 @@ class RNN_VAE(nn.Module):
             if eps is None:
                 eps = torch.randn(B, s.Z, device=eng.dev)
             eps = eps.to(device=eng.dev, dtype=torch.float32).contiguous()
+        drop_mask = self._dropout_mask(B, drop_mask, eng.dev)
         if self.training and torch.is_grad_enabled():
-            pred, fut, z, mu, lv = _VAEFunction.apply(self, x, eps, *self._param_list)
+            pred, fut, z, mu, lv = _VAEFunction.apply(self, x, eps, drop_mask, *self._param_list)
         else:
             with torch.no_grad():
-                outs = eng.forward(x, s.T * s.F, B, eps, training=self.training)
+                outs = eng.forward(x, s.T * s.F, B, eps, training=self.training, drop_mask=drop_mask)
                 pred, fut, z, mu, lv = [o.clone() if o is not None else None for o in outs]
             if not self.training:
                 z = mu
+            eng.check_async_errors()
         self.lmbda.mean, self.lmbda.logvar = mu, lv
         if self.FUTURE_DECODER:
             return pred, fut, z, mu, lv
@@ -265,7 +301,7 @@ class RNN_VAE(nn.Module):
 
     # ---------------------------------------------------------------- fused training / evaluation step
     def loss_step(self, win, kl_weight, *, beta, kloss, klmbda, bsize, mse_red="sum", mse_pred="sum", eps=None, backward=True,
-                  enc_in=None):
+                  enc_in=None, drop_mask=None):
         """One fused forward + loss (+ backward) over a batch of windows, entirely on device.
 
         win: (B, L, F) fp32 device tensor, L >= T (+FS): steps [0,T) are the encoder input and
@@ -277,6 +313,7 @@ class RNN_VAE(nn.Module):
         s = self.spec
         B, L, F = win.shape
         training = self.training
+        eng.poll_async_errors()
         _check(F == s.F and L >= s.T + (s.FS if (training and s.future) else 0), f"window batch {tuple(win.shape)} too short")
         if training and eps is None:
             eps = torch.randn(B, s.Z, device=eng.dev)
@@ -284,7 +321,8 @@ class RNN_VAE(nn.Module):
             if enc_in is not None:
                 enc_in = enc_in.to(device=eng.dev, dtype=torch.float32).contiguous()
                 _check(tuple(enc_in.shape) == (B, s.T, F), f"enc_in {tuple(enc_in.shape)} != {(B, s.T, F)}")
-            eng.forward(win, L * F, B, eps, training, cluster=(kl_weight, kloss, klmbda, bsize), enc_in=enc_in)
+            eng.forward(win, L * F, B, eps, training, cluster=(kl_weight, kloss, klmbda, bsize), enc_in=enc_in,
+                        drop_mask=self._dropout_mask(B, drop_mask, eng.dev))
             # test(): no future term (rnn_vae.py:183-198)
             losses = eng.loss(B, win, L * F, s.T * F, kl_weight, kloss, klmbda, bsize, mse_red, mse_pred,
                               with_future=training and s.future)
@@ -296,6 +334,7 @@ class RNN_VAE(nn.Module):
                 out[0] = out[0] / (B * s.T * F)
             if s.future and mse_pred != "sum":
                 out[1] = out[1] / (B * s.FS * F)
+        eng.snapshot_async_errors()
         return out
 
     def load_state_dict(self, state_dict, *a, **k):

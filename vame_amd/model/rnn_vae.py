@@ -109,8 +109,10 @@ class FusedAdamAMSGrad(torch.optim.Optimizer):
             raise RuntimeError("the model was moved after the optimizer was built")
         self.t += 1
         g = self.param_groups[0]
+        eng = self.model._engine
         ops.adam_amsgrad(flat_p, flat_g, self.m, self.v, self.vmax, flat_p.numel(), g["lr"], self.t, gscale=gscale,
-                         beta1=g["betas"][0], beta2=g["betas"][1], eps=g["eps"])
+                         beta1=g["betas"][0], beta2=g["betas"][1], eps=g["eps"],
+                         abort_flag=eng.abort_flag() if eng is not None else None)
 
     def zero_grad(self, set_to_none=False):
         pass  # every backward overwrites the whole bucket
@@ -218,7 +220,15 @@ def _maybe_init_distributed():
             dist.init_process_group("nccl", device_id=torch.device("cuda", local))
         else:
             dist.init_process_group("gloo")
+        import atexit
+        atexit.register(shutdown_distributed)      # the group outlives train_model(): pose_segmentation() reuses it
     return _world()
+
+
+def shutdown_distributed():
+    """Tear down the process group this package created (also registered with atexit)."""
+    if dist.is_available() and dist.is_initialized():
+        dist.destroy_process_group()
 
 
 def train_model(config):
@@ -238,9 +248,7 @@ def train_model(config):
         os.makedirs(os.path.join(pp, 'model', 'best_model', 'snapshots', ""), exist_ok=True)
         os.makedirs(os.path.join(pp, 'model', 'model_losses', ""), exist_ok=True)
 
-    if not torch.cuda.is_available() and not _lib.emulated():
-        raise _lib.VameHipError("vame_amd.train_model needs an MI355X (torch.cuda.is_available() is False); there is no CPU path")
-    dev = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cpu")
+    dev = _lib.device()                  # raises without an MI355X: there is no CPU path
     if dev.type == "cuda":
         print("Using HIP device:", torch.cuda.get_device_name(dev), "| ranks:", world)
 
@@ -282,6 +290,12 @@ def train_model(config):
     model = RNN(TEMPORAL_WINDOW, ZDIMS, NUM_FEATURES, FUTURE_DECODER, FUTURE_STEPS, cfg['hidden_size_layer_1'],
                     cfg['hidden_size_layer_2'], cfg['hidden_size_rec'], cfg['hidden_size_pred'], cfg['dropout_encoder'],
                     cfg['dropout_rec'], cfg['dropout_pred'], cfg['softplus']).to(dev)
+    if world > 1:
+        # identical weights on every rank (same seed above), but independent draws afterwards: eps of the reparameterisation,
+        # input noise and dropout masks must not repeat across the ranks' batches
+        torch.manual_seed(SEED + 1000 * (rank + 1))
+        if dev.type == "cuda":
+            torch.cuda.manual_seed(SEED + 1000 * (rank + 1))
 
     if pretrained_weights:
         cand = os.path.join(pp, 'model', 'best_model', pretrained_model + '_' + cfg['Project'] + '.pkl')

@@ -11,16 +11,13 @@ GB = dict(STASH=0, Y=1, Y_ROW=2, Y_T=3, H0=4, H0_ROW=5, WPT=6, DY=7, DY_ROW=8, D
 
 
 def _stream():
-    if _lib.emulated():
-        return None
-    return torch.cuda.current_stream().cuda_stream
+    return _lib.stream_handle()
 
 
 def _ptr(t, off=0):
     if t is None:
         return None
-    if not _lib.emulated() and not t.is_cuda:
-        raise _lib.VameHipError("vame_amd ops need CUDA(HIP) tensors; there is no CPU path")
+    _lib.require_device_tensor(t)
     assert t.dtype in (torch.float32, torch.float64, torch.int64, torch.int32), t.dtype
     return t.data_ptr() + off * t.element_size()
 
@@ -120,12 +117,53 @@ def gru_seq_fwd(streams, B, H):
 
 
 class CoopState:
-    """Flag words + launch epoch + poll-timeout counter shared by the cooperative (column-split) GRU launches of one device."""
+    """Flag words + launch epoch + poll-timeout counter shared by the cooperative (column-split) GRU launches of one device.
+
+    Failure handling: a launch that gives up waiting for a group member increments `status` on the device.  The optimizer
+    kernel reads the same word and drops the step (vame_adam_amsgrad_f32 abort_flag), so undefined gradients never reach
+    the weights; the host learns about it from `poll()` -- an asynchronous 4-byte copy into pinned memory after every step,
+    looked at when the next step is enqueued (no stall) -- or from `check()` wherever it synchronises anyway."""
 
     def __init__(self, dev, ints=1 << 16):
         self.flags = torch.zeros(ints, dtype=torch.int32, device=dev)
         self.status = torch.zeros(1, dtype=torch.int32, device=dev)
         self.epoch = 1
+        self.dirty = False                                   # cooperative launches since the last check()
+        self._host = [torch.zeros(1, dtype=torch.int32, pin_memory=dev.type == "cuda") for _ in range(2)]
+        self._ev = [None, None]
+        self._k = 0
+
+    def snapshot(self):
+        """Enqueue a copy of the status word to the host (end of a step); never blocks."""
+        if not self.dirty:
+            return
+        k = self._k = self._k ^ 1
+        if self._ev[k] is not None:
+            self._ev[k].synchronize()                        # the copy that used this buffer two steps ago (long finished)
+            self._raise_if(int(self._host[k][0]))
+        self._host[k].copy_(self.status, non_blocking=True)
+        if self.status.is_cuda:
+            self._ev[k] = torch.cuda.Event()
+            self._ev[k].record()
+        else:
+            self._raise_if(int(self._host[k][0]))
+
+    def poll(self):
+        """Look at the snapshots that have already arrived (start of a step); never blocks."""
+        for k in (0, 1):
+            ev = self._ev[k]
+            if ev is not None and ev.query():
+                self._ev[k] = None
+                self._raise_if(int(self._host[k][0]))
+
+    def _raise_if(self, n):
+        if n:
+            self.status.zero_()
+            self._ev = [None, None]
+            self.dirty = False
+            raise _lib.VameHipError(f"cooperative GRU kernel: {n} hand-off wait(s) timed out (workgroups of a group were not co-resident); "
+                                    "the affected optimizer step was dropped on the device; set engine.coop = False "
+                                    "(VAME_AMD_COOP=0) to use the batch-tile-persistent kernels")
 
     def next_base(self, T):
         b = self.epoch                                       # compared modulo 2^32 on the device (signed difference)
@@ -134,11 +172,15 @@ class CoopState:
 
     def check(self):
         """Host sync: raise if a cooperative launch ever gave up waiting for a group member (its results were undefined)."""
-        n = int(self.status.item())
-        if n:
-            self.status.zero_()
-            raise _lib.VameHipError(f"cooperative GRU kernel: {n} hand-off wait(s) timed out (workgroups of a group were not co-resident); "
-                                    "set engine.coop = False to use the batch-tile-persistent kernels")
+        if not self.dirty:
+            return
+        self.dirty = False
+        self._raise_if(int(self.status.item()))
+
+
+def gru_coop_set_poll_limit(polls):
+    """Poll budget of the cooperative kernels' hand-off waits (0 = default); returns the previous value."""
+    return int(_lib.lib().vame_gru_coop_set_poll_limit(int(polls)))
 
 
 def gru_coop_supported(nstreams, B, H):
@@ -164,6 +206,7 @@ def gru_coop_fwd(streams, B, H, state: CoopState, rows=(0, 0)):
     need = _lib.lib().vame_gru_coop_flag_ints(len(streams), rows[1] or B, H)
     assert state.flags.numel() >= need, "cooperative flag buffer too small"
     T = max(int(s[GF["T"]]) for s in streams)
+    state.dirty = True
     rc = _lib.lib().vame_gru_coop_fwd_f32(d.data_ptr(), len(streams), B, H, rows[0], rows[1], _ptr(state.flags), state.next_base(T),
                                           _ptr(state.status), _stream())
     _lib.check(rc, "vame_gru_coop_fwd_f32")
@@ -175,6 +218,7 @@ def gru_coop_bwd(streams, B, H, state: CoopState, rows=(0, 0)):
     if getattr(state, "xbuf", None) is None or state.xbuf.numel() < need:
         state.xbuf = torch.empty(need, device=state.flags.device)
     T = max(int(s[GB["T"]]) for s in streams)
+    state.dirty = True
     rc = _lib.lib().vame_gru_coop_bwd_f32(d.data_ptr(), len(streams), B, H, rows[0], rows[1], _ptr(state.xbuf), _ptr(state.flags),
                                           state.next_base(T), _ptr(state.status), _stream())
     _lib.check(rc, "vame_gru_coop_bwd_f32")
@@ -257,10 +301,16 @@ def colsum_batch(jobs):
         _lib.check(rc, "vame_colsum_batch_f32")
 
 
-def adam_amsgrad(p, g, m, v, vmax, n, lr, step, gscale=1.0, beta1=0.9, beta2=0.999, eps=1e-8):
+def adam_amsgrad(p, g, m, v, vmax, n, lr, step, gscale=1.0, beta1=0.9, beta2=0.999, eps=1e-8, abort_flag=None):
     rc = _lib.lib().vame_adam_amsgrad_f32(_ptr(p), _ptr(g), _ptr(m), _ptr(v), _ptr(vmax), n, lr, beta1, beta2, eps, step,
-                                          gscale, _stream())
+                                          gscale, _ptr(abort_flag), _stream())
     _lib.check(rc, "vame_adam_amsgrad_f32")
+
+
+def mask_scale(x, off, ld, seg, seg_stride, mask, scale, out, R, C):
+    """out (R,C) = x[two-level rows, see vame_mask_scale_f32] * mask (R,C) * scale."""
+    rc = _lib.lib().vame_mask_scale_f32(_ptr(x), off, ld, seg, seg_stride, _ptr(mask), float(scale), _ptr(out), R, C, _stream())
+    _lib.check(rc, "vame_mask_scale_f32")
 
 
 def axpy(x, a, y, n, x_off=0, y_off=0):
