@@ -89,6 +89,38 @@ def check_gemm_cases(dev, small=True):
     np.testing.assert_allclose(N_(C), np.concatenate([dG[:, :8], dG[:, 12:]], 1).T @ np.repeat(z, Tq, 0), atol=1e-4)
 
 
+def check_gemm_pipelined_shapes(dev):
+    """Shapes that qualify for the software-pipelined loop of gemm_kernel (interior 128x128 tiles, >= 3 whole k-tiles, 16-byte
+    aligned operands): all three layouts, split-K, two-level row addressing with one segment border per k-tile, the column gap."""
+    rng = np.random.default_rng(5)
+    for (M, Nn, K, akm, bkm, sk) in [(256, 128, 160, 0, 0, 1), (128, 256, 96, 0, 1, 1), (256, 256, 128, 1, 1, 1), (128, 128, 1024, 1, 1, 8),
+                                     (384, 128, 100, 0, 0, 1)]:
+        A = rng.standard_normal((K, M) if akm else (M, K)).astype(np.float32)
+        Bm = rng.standard_normal((K, Nn) if bkm else (Nn, K)).astype(np.float32)
+        Ct = torch.zeros(M, Nn, device=dev)
+        ws = torch.zeros(sk * M * Nn, device=dev) if sk > 1 else None
+        ops.gemm(M, Nn, K, Operand(T_(A, dev), A.shape[1]), akm, Operand(T_(Bm, dev), Bm.shape[1]), bkm, Ct, Nn, splitk=sk, ws=ws)
+        ref = (A.T if akm else A).astype(np.float64) @ (Bm if bkm else Bm.T).astype(np.float64)
+        np.testing.assert_allclose(N_(Ct), ref, atol=2e-4 * np.sqrt(K), err_msg=str((M, Nn, K, akm, bkm, sk)))
+    # weight-gradient form on padded sequences: A = dG (B*T, 4H) with a column gap, B = rows (b,t) of a (B, T+2, W) sequence
+    Bq, Tq, Hh = 4, 40, 64                                 # K = B*T = 160 = 5 k-tiles, segment length 40 >= 32
+    dG = rng.standard_normal((Bq * Tq, 4 * Hh)).astype(np.float32)
+    Y = rng.standard_normal((Bq, Tq + 2, 128)).astype(np.float32)
+    C = torch.zeros(3 * Hh + 64, 128, device=dev)         # 256 x 128 output: rows from columns [0,128) and [192,320) of dG
+    ops.gemm(256, 128, Bq * Tq, Operand(T_(dG[:, :1].repeat(1, 1) if False else np.concatenate([dG, dG[:, :64]], 1), dev), 320), 1,
+             Operand(T_(Y, dev), 128, off=128, seg=Tq, seg_stride=(Tq + 2) * 128), 1, C, 128, a_gap_at=128, a_gap=64)
+    dGw = np.concatenate([dG, dG[:, :64]], 1)
+    Aeff = np.concatenate([dGw[:, :128], dGw[:, 192:320]], 1)
+    np.testing.assert_allclose(N_(C), Aeff.T.astype(np.float64) @ Y[:, 1:Tq + 1].reshape(-1, 128).astype(np.float64), atol=3e-3)
+    # NT form with a segmented row-major A (the gi projection reads rows (b,t) of a padded sequence)
+    Bq, Tq, W = 8, 16, 96                                  # M = 128 rows, K = 96
+    Y = rng.standard_normal((Bq, Tq + 2, W)).astype(np.float32)
+    Wt = rng.standard_normal((128, W)).astype(np.float32)
+    C = torch.zeros(Bq * Tq, 128, device=dev)
+    ops.gemm(Bq * Tq, 128, W, Operand(T_(Y, dev), W, off=W, seg=Tq, seg_stride=(Tq + 2) * W), 0, Operand(T_(Wt, dev), W), 0, C, 128)
+    np.testing.assert_allclose(N_(C), Y[:, 1:Tq + 1].reshape(-1, W).astype(np.float64) @ Wt.T.astype(np.float64), atol=1e-3)
+
+
 def _gru_weights(rng, I, H):
     k = 1 / np.sqrt(H)
     return (rng.uniform(-k, k, (3 * H, I)).astype(np.float32), rng.uniform(-k, k, (3 * H, H)).astype(np.float32),

@@ -5,7 +5,7 @@ the CPU; the same checks run on the real GPU in test_kernels_gpu.py.
 """
 import pytest
 
-from kernel_cases import (check_adam, check_adam_abort_and_mask_scale, check_colsum, check_colsum_batch, check_kmeans, check_gather, check_gemm_cases, check_gemm_group, check_gru_bwd, check_gru_coop_bwd, check_gru_coop_fwd, check_gru_fwd, check_gru_fwd_fused,
+from kernel_cases import (check_adam, check_adam_abort_and_mask_scale, check_colsum, check_colsum_batch, check_kmeans, check_gather, check_gemm_cases, check_gemm_group, check_gemm_pipelined_shapes, check_gru_bwd, check_gru_coop_bwd, check_gru_coop_fwd, check_gru_fwd, check_gru_fwd_fused,
                           check_latent, check_mse, check_nuclear, check_prep_fill_rules, check_prepare_series_golden,
                           check_prepare_series_vs_oracle)
 
@@ -18,6 +18,14 @@ def test_gemm(emu, epi, monkeypatch):
     monkeypatch.setenv("VAME_GEMM_EPI", epi)
     check_gemm_cases(DEV, small=True)
     check_gemm_group(DEV)
+
+
+def test_gemm_software_pipelined_loop(emu, monkeypatch):
+    for var in ("13", "9", "0"):            # pipelined (+ setprio), pipelined, plain loop on the same shapes
+        monkeypatch.setenv("VAME_GEMM_VAR", var)
+        for epi in ("1", "2"):
+            monkeypatch.setenv("VAME_GEMM_EPI", epi)
+            check_gemm_pipelined_shapes(DEV)
 
 
 @pytest.mark.parametrize("H,B,T", [(32, 5, 4), (64, 40, 3), (96, 5, 3)])

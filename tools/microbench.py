@@ -139,13 +139,38 @@ def gemm_ab(rounds=4):
         B = torch.randn((K, N) if bkm else (N, K), device=dev)
         C = torch.empty(M, N, device=dev)
         ws = torch.empty(sk * M * N, device=dev) if sk > 1 else None
-        res = {v: [] for v in (0, 1, 4, 5)}
+        res = {v: [] for v in (0, 1, 5, 9, 13)}
         for r in range(rounds):
             for v in res:
                 os.environ["VAME_GEMM_VAR"] = str(v)
                 ms = timeit(lambda: ops.gemm(M, N, K, Operand(A, A.shape[1]), akm, Operand(B, B.shape[1]), bkm, C, N, splitk=sk, ws=ws), reps=5)
                 res[v].append(2.0 * M * N * K / ms / 1e9)
         print(f"M={M} N={N} K={K} akm={akm} bkm={bkm} sk={sk}: " + "  ".join(f"v{v}: {statistics.median(t):6.1f} (max {max(t):6.1f})" for v, t in res.items()))
+
+
+def gemm_sk(rounds=3):
+    """split-K sweep of the weight-gradient (TN) shapes for the plain (VAR 5, 3 workgroups per CU) and the software-pipelined
+    (VAR 13, 2 per CU) loops, single and grouped launches (tuning build)."""
+    import statistics
+    BT = 4096 * 30
+    for (M, N, K, cnt, sks) in [(768, 512, BT, 1, (16, 21, 32, 42, 64)), (768, 256, BT, 1, (32, 42, 64, 85, 128)), (768, 256, BT, 6, (8, 14, 16, 21, 32)),
+                                (768, 512, BT, 2, (8, 16, 21, 32)), (768, 256, BT // 2, 2, (16, 21, 32, 42))]:
+        As = [torch.randn(K, M, device=dev) for _ in range(cnt)]
+        Bs = [torch.randn(K, N, device=dev) for _ in range(cnt)]
+        C = torch.empty(cnt * M, N, device=dev)
+        for sk in sks:
+            ws = torch.empty(cnt * sk * M * N, device=dev)
+            res = {}
+            for r in range(rounds):
+                for v in (5, 13):
+                    os.environ["VAME_GEMM_VAR"] = str(v)
+                    if cnt == 1:
+                        fn = lambda: ops.gemm(M, N, K, Operand(As[0], M), 1, Operand(Bs[0], N), 1, C, N, splitk=sk, ws=ws)
+                    else:
+                        fn = lambda: ops.gemm_group(M, N, K, [Operand(a, M) for a in As], 1, [Operand(b, N) for b in Bs], 1, C, [g * M * N for g in range(cnt)], N, sk, ws)
+                    ms = timeit(fn, reps=5)
+                    res.setdefault(v, []).append(2.0 * M * N * K * cnt / ms / 1e9)
+            print(f"M={M} N={N} K={K} x{cnt} sk={sk:3d}: " + "  ".join(f"v{v}: {statistics.median(t):6.1f}" for v, t in res.items()), flush=True)
 
 
 def gemm_epi(rounds=4):
@@ -170,6 +195,9 @@ def gemm_epi(rounds=4):
 
 
 if __name__ == "__main__":
+    if len(sys.argv) > 2 and sys.argv[2] == "gemm_sk":
+        gemm_sk()
+        sys.exit(0)
     if len(sys.argv) > 2 and sys.argv[2] == "gemm_epi":
         gemm_epi()
         sys.exit(0)

@@ -73,7 +73,7 @@ int main(int argc, char** argv) {
     for (size_t i = 0; i < h.size(); ++i) h[i] = (float)((i * 2654435761u >> 8) & 0xffff) / 65536.f - 0.5f;
     hipMemcpy(A, h.data(), na * 4, hipMemcpyHostToDevice); hipMemcpy(B, h.data(), nb * 4, hipMemcpyHostToDevice);
     const int maxwg = 1 << 16, waves = 4;
-    long long* probe; hipMalloc(&probe, (size_t)maxwg * waves * 8 * 8); hipMemset(probe, 0, (size_t)maxwg * waves * 8 * 8);
+    long long* probe; hipMalloc(&probe, (size_t)maxwg * waves * PROBE_SLOTS * 8); hipMemset(probe, 0, (size_t)maxwg * waves * PROBE_SLOTS * 8);
     vame_probe_set_gemm(probe);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     auto run = [&]() { return vame_gemm_f32(M, N, K, A, akm ? M : K, akm, 0, 0, B, bkm ? N : K, bkm, 0, 0, nullptr, C, N, 0, sk, ws, 0, 0, nullptr); };
@@ -83,18 +83,18 @@ int main(int argc, char** argv) {
     hipEventRecord(e0, 0); for (int i = 0; i < reps; ++i) run(); hipEventRecord(e1, 0); hipEventSynchronize(e1); hipEventElapsedTime(&ms, e0, e1);
     ms /= reps;
     printf("M=%d N=%d K=%d akm=%d bkm=%d sk=%d: %.1f us per call (incl. split-K reduce), %.1f TF\n", M, N, K, akm, bkm, sk, ms * 1e3, 2.0 * M * N * K / ms / 1e9);
-    std::vector<long long> p((size_t)maxwg * waves * 8);
+    std::vector<long long> p((size_t)maxwg * waves * PROBE_SLOTS);
     hipMemcpy(p.data(), probe, p.size() * 8, hipMemcpyDeviceToHost);
     long long tmin = -1, tmax = 0; double s[4] = {0, 0, 0, 0}, dur = 0, rdur = 0; size_t n = 0;
     std::vector<double> starts, ends, durs;
     for (size_t w = 0; w < (size_t)maxwg * waves; ++w) {
-        const long long* o = &p[w * 8];
+        const long long* o = &p[w * PROBE_SLOTS];
         if (!o[1]) continue;
         if (tmin < 0 || o[2] < tmin) tmin = o[2];
         tmax = std::max(tmax, o[3]);
     }
     for (size_t w = 0; w < (size_t)maxwg * waves; ++w) {
-        const long long* o = &p[w * 8];
+        const long long* o = &p[w * PROBE_SLOTS];
         if (!o[1]) continue;
         ++n; dur += (double)(o[1] - o[0]); rdur += (double)(o[3] - o[2]);
         for (int i = 0; i < 4; ++i) s[i] += (double)o[4 + i];
@@ -111,6 +111,22 @@ int main(int argc, char** argv) {
     const double tot = s[0] + s[1] + s[2] + s[3];
     printf("loop time split: stage(regs->LDS, incl. vmcnt wait) %.1f%%  barrier1 %.1f%%  mfma phase %.1f%%  barrier2 %.1f%%;  loop = %.1f%% of wave length\n",
            100 * s[0] / tot, 100 * s[1] / tot, 100 * s[2] / tot, 100 * s[3] / tot, 100 * tot / dur);
+    {   // whole wave lifetime (kernel entry -> stores acknowledged) vs the loop: what the slots are held for, and how full they are
+        double pro = 0, epi = 0, life = 0; long long emin = -1, emax = 0;
+        std::vector<double> lifes;
+        for (size_t w = 0; w < (size_t)maxwg * waves; ++w) {
+            const long long* o = &p[w * PROBE_SLOTS];
+            if (!o[1]) continue;
+            pro += (double)(o[2] - o[8]); epi += (double)(o[9] - o[3]); life += (double)(o[9] - o[8]); lifes.push_back((double)(o[9] - o[8]));
+            if (emin < 0 || o[8] < emin) emin = o[8];
+            emax = std::max(emax, o[9]);
+        }
+        std::sort(lifes.begin(), lifes.end());
+        printf("wave lifetime us: mean %.1f p50 %.1f  = prologue (entry -> loop) %.1f + loop %.1f + epilogue (loop end -> stores acknowledged) %.1f\n",
+               life / n / 100.0, q(lifes, .5), pro / n / 100.0, rdur / n / 100.0, epi / n / 100.0);
+        printf("kernel span entry->exit %.1f us; mean resident waves %.0f of %d slots (3 workgroups x 4 waves x 256 CUs)\n", (double)(emax - emin) / 100.0,
+               life / (double)(emax - emin), 3072);
+    }
     const double ktiles = (double)((K + sk - 1) / sk + 31) / 32;
     printf("memtime ticks per k-tile per wave: %.0f (mfma phase %.0f; 64 MFMAs x 64 cycles = 4096 if alone on the SIMD)\n", tot / n / ktiles, s[2] / n / ktiles);
     return 0;

@@ -7,7 +7,7 @@
 #include "vame_common.h"
 
 #ifndef VAME_GEMM_EPI_DEFAULT
-#define VAME_GEMM_EPI_DEFAULT 1
+#define VAME_GEMM_EPI_DEFAULT 2      /* 128x128 tiles: LDS-transposed full-line stores; other tiles fall back to form 1 */
 #endif
 struct GemmOperand {
     const float* p;
@@ -141,6 +141,56 @@ struct TileIO {
     static constexpr bool XMAJ = !KM && XM;
     static constexpr int LD = XMAJ ? BK + 4 : BX + 4;
     static constexpr int LDS_FLOATS = XMAJ ? BX * (BK + 4) : BK * (BX + 4);
+    // ---- item-wise, branch-free forms for the software-pipelined loop (interior tiles only: 16-byte loads legal, nothing
+    // predicated; k-major operands: seg == 0 or seg >= BK, so advancing a row index by BK crosses at most one segment border)
+    int64_t poff[PER];                     // element offset of the item's next load
+    int pt[KM ? PER : 1];                  // KM: index of the item's row inside its segment
+    int64_t pstep, pwrap;                  // KM: offset step per k-tile; correction when the row index wraps into the next segment
+    __device__ __forceinline__ void pipe_init(const GemmOperand& o, int x0, int kb, int tid) {
+        if (!KM) {
+#pragma unroll
+            for (int it = 0; it < PER; ++it) poff[it] = (int64_t)rowo[it] + kb + 4 * (tid % KQ);
+            pstep = BK; pwrap = 0;
+        } else {
+            const int gx = x0 + 4 * (tid % XQ);
+            const int gxs = gx + (gx >= o.gap_at ? o.gap : 0);
+            pstep = (int64_t)BK * o.ld;
+            pwrap = o.seg ? o.seg_stride - o.seg * o.ld : 0;
+#pragma unroll
+            for (int it = 0; it < PER; ++it) {
+                const unsigned g = (unsigned)(kb + tid / XQ + it * (NT / XQ));
+                const unsigned b = o.seg ? g / (unsigned)o.seg : 0u, t = o.seg ? g % (unsigned)o.seg : g;
+                pt[it] = (int)t;
+                poff[it] = (o.seg ? (int64_t)b * o.seg_stride : 0) + (int64_t)t * o.ld + gxs;
+            }
+        }
+    }
+    __device__ __forceinline__ void pipe_fetch_item(const GemmOperand& o, int it) {
+        v[it] = *reinterpret_cast<const float4*>(o.p + poff[it]);
+        poff[it] += pstep;
+        if (KM) {
+            pt[it] += BK;
+            const bool w = o.seg != 0 && pt[it] >= (int)o.seg;
+            pt[it] -= w ? (int)o.seg : 0;
+            poff[it] += w ? pwrap : 0;
+        }
+    }
+    __device__ __forceinline__ void store_item(float* lds, int tid, int it) const {
+        const int idx = tid + it * NT;
+        if (KM) {
+            const int k = idx / XQ, xq = idx % XQ;
+            *reinterpret_cast<float4*>(&lds[k * LD + 4 * xq]) = v[it];
+        } else if (XMAJ) {
+            const int x = idx / KQ, kq = idx % KQ;
+            *reinterpret_cast<float4*>(&lds[x * LD + 4 * kq]) = v[it];
+        } else {
+            const int x = idx / KQ, kq = idx % KQ;
+            lds[(4 * kq + 0) * LD + x] = v[it].x;
+            lds[(4 * kq + 1) * LD + x] = v[it].y;
+            lds[(4 * kq + 2) * LD + x] = v[it].z;
+            lds[(4 * kq + 3) * LD + x] = v[it].w;
+        }
+    }
     __device__ __forceinline__ void store(float* lds, int tid) const {
 #pragma unroll
         for (int it = 0; it < PER; ++it) {
@@ -178,12 +228,18 @@ struct TileIO {
 __device__ long long* g_gemm_probe;
 extern "C" int vame_probe_set_gemm(long long* p) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_gemm_probe), &p, sizeof(p)); }
 #define PROBE_T() ((long long)__builtin_amdgcn_s_memtime())
+#define PROBE_SLOTS 12
+#define PROBE_ENTRY const long long pr_entry = (long long)__builtin_amdgcn_s_memrealtime()
 #define PROBE_DECL long long pt0 = PROBE_T(), pr0 = (long long)__builtin_amdgcn_s_memrealtime(), pa = pt0, ps = 0, pb1 = 0, pm = 0, pb2 = 0
 #define PROBE_ADD(acc) do { const long long t_ = PROBE_T(); acc += t_ - pa; pa = t_; } while (0)
 #else
 #define PROBE_DECL
 #define PROBE_ADD(acc)
+#define PROBE_ENTRY
 #endif
+
+struct GemmTrue { static constexpr bool value = true; };
+struct GemmFalse { static constexpr bool value = false; };
 
 // One output value: split-K partial -> workspace slab z, else C (+ bias, + previous C when accumulating)
 __device__ __forceinline__ void emit4(const GemmParams& p, float* ws, int z, int row, int col, float4 v) {
@@ -210,18 +266,25 @@ __device__ __forceinline__ void emit4(const GemmParams& p, float* ws, int z, int
         }
 }
 
-// VAR (tuning variants, tools/microbench.py A/B): 1 unpredicated interior fetch, 4 s_setprio around the MFMAs
+// VAR (tuning variants, tools/microbench.py A/B): 1 unpredicated interior fetch, 4 s_setprio around the MFMAs,
+//   8 software pipeline: two LDS images of the operand tiles and ONE barrier per k-tile -- while the MFMAs of tile t run from image
+//   t&1, the same wave writes tile t+1 (fetched during tile t-1) into the other image and then re-issues the global loads for
+//   tile t+2, all between MFMAs (an f32 MFMA holds the matrix pipe for 64 cycles: ~16 issue slots per MFMA are free).  The plain
+//   form serialises [stage -> barrier -> MFMAs -> barrier] per workgroup and relies on three co-resident workgroups to fill each
+//   other's gaps, which they do only partly (they fall into step: 83 % MFMA-pipe use inside the loop, tools/probe_gemm).
 // EPI (epilogue): 0 = accumulator layout as computed (lane = output column): 16 dword stores per 32x32 tile, two full 128-byte
 //   lines each.  1 = the MFMA operands are SWAPPED (D^T = B^T A^T), which puts an output ROW in each lane and four consecutive
 //   columns in registers 4q..4q+3: 4 dwordx4 stores per tile.  2 = layout 0 transposed through a per-wave LDS scratch (the operand
 //   buffers, free after the k loop): 4 dwordx4 stores per tile, 8 full lines each.
 template <int BM, int BN, int WM, int WN, bool AKM, bool BKM, int VAR, int EPI>
-__global__ __launch_bounds__(WM * WN * 64, (BM / WM) * (BN / WN) > 64 * 64 ? 2 : 3) void gemm_kernel(GemmParams p) {
+__global__ __launch_bounds__(WM * WN * 64, ((BM / WM) * (BN / WN) > 64 * 64 || (VAR & 8)) ? 2 : 3) void gemm_kernel(GemmParams p) {
     constexpr int BK = 32, NT = WM * WN * 64, TM = BM / WM / 32, TN = BN / WN / 32;
+    constexpr bool PIPE = (VAR & 8) != 0;
     typedef TileIO<BK, BM, NT, AKM, BKM> TA;      // x-major image only for the A operand of the NN form
     typedef TileIO<BK, BN, NT, BKM, false> TB;
-    __shared__ __attribute__((aligned(16))) float As[TA::LDS_FLOATS];
-    __shared__ __attribute__((aligned(16))) float Bs[TB::LDS_FLOATS];
+    __shared__ __attribute__((aligned(16))) float As[(PIPE ? 2 : 1) * TA::LDS_FLOATS];
+    __shared__ __attribute__((aligned(16))) float Bs[(PIPE ? 2 : 1) * TB::LDS_FLOATS];
+    PROBE_ENTRY;
     int tm_, tn_, z, g;
     if (!map_tile(p, tm_, tn_, z, g)) return;
     GemmOperand opA = p.A, opB = p.B;
@@ -244,8 +307,75 @@ __global__ __launch_bounds__(WM * WN * 64, (BM / WM) * (BN / WN) > 64 * 64 ? 2 :
     TB tb;
     ta.init(opA, m0, p.M, kb, tid);
     tb.init(opB, n0, p.N, kb, tid);
-    if (kb < ke) { ta.template fetch<(VAR & 1) != 0>(opA, m0, p.M, kb, ke, tid); tb.template fetch<(VAR & 1) != 0>(opB, n0, p.N, kb, ke, tid); }
     PROBE_DECL;
+    bool piped = false;
+    constexpr bool PIPE_STATIC = PIPE && TA::ITEMS == 4 * NT && TB::ITEMS == 4 * NT && TM == 2 && TN == 2;
+    if constexpr (PIPE_STATIC) {
+    // eligibility of the pipelined loop (wave-uniform): interior tile, 16-byte loads, whole k-tiles and at least three of them,
+    // at most one segment border per BK rows of a k-major operand; everything else takes the plain loop below
+    const bool pipe_ok = opA.vec && opB.vec && m0 + BM <= p.M &&
+                         n0 + BN <= p.N && (ke - kb) % BK == 0 && ke - kb >= 3 * BK && (!AKM || opA.seg == 0 || opA.seg >= BK) &&
+                         (!BKM || opB.seg == 0 || opB.seg >= BK);
+    if (pipe_ok) {
+        ta.pipe_init(opA, m0, kb, tid);
+        tb.pipe_init(opB, n0, kb, tid);
+        // one k-tile: 16 steps of 4 MFMAs (step s = 4c + e contracts k = {8c + e, 8c + 4 + e}); the fragments of chunk c + 1 are read
+        // during chunk c, and ONE staging operation rides in every step: steps 0..7 write the registers of tile t+1 into the other
+        // LDS image, steps 8..15 re-load them with tile t+2.  sched_barrier pins that order (hipcc would batch them otherwise).
+        auto tile = [&](const float* Ac, const float* Bc, float* An, float* Bn, auto wtag, auto ltag) {
+            constexpr bool W = decltype(wtag)::value, L = decltype(ltag)::value;
+            float a[2][2][4], b[2][2][4];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) { TA::frag(Ac, wm * (BM / WM) + i * 32, li, hh, 0, a[0][i]); TB::frag(Bc, wn * (BN / WN) + i * 32, li, hh, 0, b[0][i]); }
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int q = c & 1;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int st = 4 * c + e;
+                    acc[0][0] = EPI == 1 ? MFMA_32x32x2(b[q][0][e], a[q][0][e], acc[0][0]) : MFMA_32x32x2(a[q][0][e], b[q][0][e], acc[0][0]);
+                    if (e == 0 && c < 3) {
+#pragma unroll
+                        for (int i = 0; i < 2; ++i) { TA::frag(Ac, wm * (BM / WM) + i * 32, li, hh, c + 1, a[q ^ 1][i]); TB::frag(Bc, wn * (BN / WN) + i * 32, li, hh, c + 1, b[q ^ 1][i]); }
+                    }
+                    SCHED_FENCE();
+                    acc[0][1] = EPI == 1 ? MFMA_32x32x2(b[q][1][e], a[q][0][e], acc[0][1]) : MFMA_32x32x2(a[q][0][e], b[q][1][e], acc[0][1]);
+                    if (W && st < 4) ta.store_item(An, tid, st);
+                    if (W && st >= 4 && st < 8) tb.store_item(Bn, tid, st - 4);
+                    if (L && st >= 8 && st < 12) ta.pipe_fetch_item(opA, st - 8);
+                    if (L && st >= 12) tb.pipe_fetch_item(opB, st - 12);
+                    SCHED_FENCE();
+                    acc[1][0] = EPI == 1 ? MFMA_32x32x2(b[q][0][e], a[q][1][e], acc[1][0]) : MFMA_32x32x2(a[q][1][e], b[q][0][e], acc[1][0]);
+                    acc[1][1] = EPI == 1 ? MFMA_32x32x2(b[q][1][e], a[q][1][e], acc[1][1]) : MFMA_32x32x2(a[q][1][e], b[q][1][e], acc[1][1]);
+                    SCHED_FENCE();
+                }
+            }
+        };
+#pragma unroll
+        for (int it = 0; it < 4; ++it) { ta.pipe_fetch_item(opA, it); tb.pipe_fetch_item(opB, it); }
+        ta.store(As, tid);
+        tb.store(Bs, tid);
+#pragma unroll
+        for (int it = 0; it < 4; ++it) { ta.pipe_fetch_item(opA, it); tb.pipe_fetch_item(opB, it); }
+        __syncthreads();
+        int cur = 0, k0 = kb;
+        for (; k0 + 2 * BK < ke; k0 += BK) {
+            tile(As + cur * TA::LDS_FLOATS, Bs + cur * TB::LDS_FLOATS, As + (cur ^ 1) * TA::LDS_FLOATS, Bs + (cur ^ 1) * TB::LDS_FLOATS, GemmTrue{}, GemmTrue{});
+            PROBE_ADD(pm);
+            __syncthreads();           // image cur fully read, image cur^1 fully written
+            PROBE_ADD(pb2);
+            cur ^= 1;
+        }
+        tile(As + cur * TA::LDS_FLOATS, Bs + cur * TB::LDS_FLOATS, As + (cur ^ 1) * TA::LDS_FLOATS, Bs + (cur ^ 1) * TB::LDS_FLOATS, GemmTrue{}, GemmFalse{});
+        __syncthreads();
+        cur ^= 1;
+        tile(As + cur * TA::LDS_FLOATS, Bs + cur * TB::LDS_FLOATS, As, Bs, GemmFalse{}, GemmFalse{});
+        __syncthreads();               // (the LDS-transposed epilogue reuses the images)
+        piped = true;
+    }
+    }
+    if (!piped && kb < ke) { ta.template fetch<(VAR & 1) != 0>(opA, m0, p.M, kb, ke, tid); tb.template fetch<(VAR & 1) != 0>(opB, n0, p.N, kb, ke, tid); }
+    if (!piped)
     for (int k0 = kb; k0 < ke; k0 += BK) {
         ta.store(As, tid);
         tb.store(Bs, tid);
@@ -277,7 +407,7 @@ __global__ __launch_bounds__(WM * WN * 64, (BM / WM) * (BN / WN) > 64 * 64 ? 2 :
     }
 #ifdef VAME_PROBE
     if (lane == 0 && g_gemm_probe) {
-        long long* o = g_gemm_probe + ((long long)blockIdx.x * (NT / 64) + wv) * 8;
+        long long* o = g_gemm_probe + ((long long)blockIdx.x * (NT / 64) + wv) * PROBE_SLOTS;
         o[0] = pt0; o[1] = PROBE_T(); o[2] = pr0; o[3] = (long long)__builtin_amdgcn_s_memrealtime();
         o[4] = ps; o[5] = pb1; o[6] = pm; o[7] = pb2;
     }
@@ -298,9 +428,7 @@ __global__ __launch_bounds__(WM * WN * 64, (BM / WM) * (BN / WN) > 64 * 64 ? 2 :
                 }
             }
         }
-        return;
-    }
-    if (EPI == 2) {
+    } else if (EPI == 2) {
         constexpr int LDT = 36;
         static_assert(EPI != 2 || (TA::LDS_FLOATS >= (WM * WN / 2) * 32 * LDT && TB::LDS_FLOATS >= (WM * WN / 2) * 32 * LDT), "scratch does not fit");
         float* scr = (wv < WM * WN / 2 ? As + wv * 32 * LDT : Bs + (wv - WM * WN / 2) * 32 * LDT);      // (the loop's last barrier freed As / Bs)
@@ -321,8 +449,7 @@ __global__ __launch_bounds__(WM * WN * 64, (BM / WM) * (BN / WN) > 64 * 64 ? 2 :
                 }
                 WAVE_SYNC();
             }
-        return;
-    }
+    } else {
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -345,6 +472,17 @@ __global__ __launch_bounds__(WM * WN * 64, (BM / WM) * (BN / WN) > 64 * 64 ? 2 :
                 }
             }
         }
+    }
+#ifdef VAME_PROBE
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the wave's slot is held until its stores are acknowledged
+    if (lane == 0 && g_gemm_probe) {
+        long long* o = g_gemm_probe + ((long long)blockIdx.x * (NT / 64) + wv) * PROBE_SLOTS;
+        o[8] = pr_entry; o[9] = (long long)__builtin_amdgcn_s_memrealtime();
+        unsigned hwid; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+        unsigned xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        o[10] = (long long)hwid | ((long long)xcc << 32);
+    }
+#endif
 }
 
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ ws, int splitk, int M, int N,
@@ -410,22 +548,30 @@ static int launch_gemm(GemmParams p, int akm, int bkm, hipStream_t st) {
     const int64_t per_unit = p.by_z ? (int64_t)p.tiles_m * p.tiles_n : p.tiles_n;
     const int64_t nunits = p.by_z ? (int64_t)p.splitk * p.group : (int64_t)p.splitk * p.tiles_m;
     dim3 grid((unsigned)(cdiv64(nunits, 8) * per_unit * 8)), block(WM * WN * 64);
-#if !defined(VAME_EMU) && defined(VAME_GEMM_AB)
-    if (BM == 128 && BN == 128) {            // A/B tuning build only (make ab): variant chosen per call from the environment
+#if defined(VAME_EMU) || defined(VAME_GEMM_AB)
+    if (BM == 128 && BN == 128) {            // A/B tuning build (make ab) and host-emulator tests: variant chosen per call from the environment
         const char* e = getenv("VAME_GEMM_VAR");
         switch (e ? atoi(e) : -1) {
             case 0: return launch_gemm_var<BM, BN, WM, WN, 0>(p, akm, bkm, grid, block, st);
             case 1: return launch_gemm_var<BM, BN, WM, WN, 1>(p, akm, bkm, grid, block, st);
             case 4: return launch_gemm_var<BM, BN, WM, WN, 4>(p, akm, bkm, grid, block, st);
             case 5: return launch_gemm_var<BM, BN, WM, WN, 5>(p, akm, bkm, grid, block, st);
+            case 8: return launch_gemm_var<BM, BN, WM, WN, 8>(p, akm, bkm, grid, block, st);
+            case 9: return launch_gemm_var<BM, BN, WM, WN, 9>(p, akm, bkm, grid, block, st);
+            case 13: return launch_gemm_var<BM, BN, WM, WN, 13>(p, akm, bkm, grid, block, st);
             default: break;
         }
     }
 #endif
-    // measured on MI355X (interleaved A/B, tools/microbench.py gemm_ab): the unpredicated interior fetch + s_setprio
-    // variant wins +6..10 % on split-K weight-gradient GEMMs and +2 % on the data-gradient (NN) form, and loses on the
-    // NT form and on un-split TN, which keep the baseline variant
-    if (akm && bkm && p.splitk >= 8) return launch_gemm_var<BM, BN, WM, WN, 5>(p, akm, bkm, grid, block, st);
+    // measured on MI355X (interleaved A/B, tools/microbench.py gemm_ab / gemm_sk, profiles/r02_gemm_variants.txt): the
+    // software-pipelined loop (VAR 13) wins wherever a tile has few k-tiles per output tile -- +14 % on the NT form (gi
+    // projections, 104 -> 119 TF), +9 % on the NN form (dx, 115 -> 125 TF), +11 % on an un-split TN square -- and ties the plain loop
+    // with 3 workgroups per CU on the split-K weight gradients (112-122 TF both: those run at a 1.99 GHz shader clock, i.e. at
+    // 86-92 % of what the clock allows), which keep the plain loop + s_setprio (VAR 5).  Other tile shapes: plain loop.
+    if (BM == 128 && BN == 128) {
+        if (akm && bkm && p.splitk >= 8) return launch_gemm_var<BM, BN, WM, WN, 5>(p, akm, bkm, grid, block, st);
+        return launch_gemm_var<BM, BN, WM, WN, 13>(p, akm, bkm, grid, block, st);
+    }
     if (!akm && bkm) return launch_gemm_var<BM, BN, WM, WN, 1>(p, akm, bkm, grid, block, st);
     return launch_gemm_var<BM, BN, WM, WN, 0>(p, akm, bkm, grid, block, st);
 }
