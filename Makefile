@@ -1,26 +1,52 @@
 # Builds the product library (gfx950) and the CPU emulation library used by the non-GPU tests.
+# Objects are compiled per source file (make -j parallelises; only changed files rebuild).
 HIPCC ?= /opt/rocm/bin/hipcc
 HOSTCXX ?= /opt/rocm/lib/llvm/bin/clang++
-SRC := vame_amd/csrc/gru_seq.hip vame_amd/csrc/gemm.hip vame_amd/csrc/elementwise.hip vame_amd/csrc/prep.hip vame_amd/csrc/gru_coop.hip
+NAMES := gru_seq gemm elementwise prep gru_coop
+SRC := $(foreach n,$(NAMES),vame_amd/csrc/$(n).hip)
 HDR := vame_amd/csrc/vame_device.h vame_amd/csrc/vame_common.h vame_amd/csrc/gru_desc.h include/vame_hip.h
+HIPFLAGS := --offload-arch=gfx950 -O3 -std=c++17 -fPIC
+EMUFLAGS := -DVAME_EMU -O2 -std=c++17 -fPIC -pthread -Itests/emu -Wno-unknown-attributes
 
 all: vame_amd/libvame_hip.so tests/emu/libvame_emu.so
 
-vame_amd/libvame_hip.so: $(SRC) $(HDR)
-	$(HIPCC) --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -o $@ $(SRC)
+build/hip/%.o: vame_amd/csrc/%.hip $(HDR)
+	@mkdir -p build/hip
+	$(HIPCC) $(HIPFLAGS) -c -o $@ $<
 
-tests/emu/libvame_emu.so: $(SRC) $(HDR) tests/emu/hip_emu.h tests/emu/hip_emu.cpp
-	$(HOSTCXX) -DVAME_EMU -O2 -std=c++17 -fPIC -shared -pthread -Itests/emu -Wno-unknown-attributes \
-	    -o $@ $(foreach f,$(SRC),-x c++ $(f)) -x c++ tests/emu/hip_emu.cpp
+vame_amd/libvame_hip.so: $(foreach n,$(NAMES),build/hip/$(n).o)
+	$(HIPCC) --offload-arch=gfx950 -shared -fPIC -o $@ $^
 
-# tuning build with all GEMM variants selectable through VAME_GEMM_VAR (tools/microbench.py ab)
-ab: $(SRC) $(HDR)
-	$(HIPCC) --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -DVAME_GEMM_AB -DVAME_TUNING_BUILD -o tools/libvame_hip_ab.so $(SRC)
+build/emu/%.o: vame_amd/csrc/%.hip $(HDR) tests/emu/hip_emu.h
+	@mkdir -p build/emu
+	$(HOSTCXX) $(EMUFLAGS) -c -o $@ -x c++ $<
+
+build/emu/hip_emu.o: tests/emu/hip_emu.cpp tests/emu/hip_emu.h
+	@mkdir -p build/emu
+	$(HOSTCXX) $(EMUFLAGS) -c -o $@ $<
+
+tests/emu/libvame_emu.so: $(foreach n,$(NAMES),build/emu/$(n).o) build/emu/hip_emu.o
+	$(HOSTCXX) -shared -fPIC -pthread -o $@ $^
+
+# tuning build with all GEMM variants selectable through VAME_GEMM_VAR / VAME_GEMM_EPI and the GRU ablation masks
+# (tools/microbench.py gemm_ab / gemm_epi / gemm_sk / ablate)
+build/ab/%.o: vame_amd/csrc/%.hip $(HDR)
+	@mkdir -p build/ab
+	$(HIPCC) $(HIPFLAGS) -DVAME_GEMM_AB -DVAME_TUNING_BUILD -c -o $@ $<
+
+tools/libvame_hip_ab.so: $(foreach n,$(NAMES),build/ab/$(n).o)
+	$(HIPCC) --offload-arch=gfx950 -shared -fPIC -o $@ $^
+
+ab: tools/libvame_hip_ab.so
 	@echo "use: VAME_LIB=tools/libvame_hip_ab.so python tools/microbench.py 10 gemm_ab"
 
-probe: $(SRC) $(HDR) tools/probe_gemm.hip
-	$(HIPCC) --offload-arch=gfx950 -O3 -std=c++17 -DVAME_PROBE -Wno-unused-value -Wno-unused-result -o tools/probe_gemm tools/probe_gemm.hip vame_amd/csrc/elementwise.hip
-	$(HIPCC) --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -DVAME_PROBE -o tools/libvame_hip_probe.so $(SRC)
+build/probe/%.o: vame_amd/csrc/%.hip $(HDR)
+	@mkdir -p build/probe
+	$(HIPCC) $(HIPFLAGS) -DVAME_PROBE -c -o $@ $<
+
+probe: $(foreach n,$(NAMES),build/probe/$(n).o) tools/probe_gemm.hip
+	$(HIPCC) --offload-arch=gfx950 -O3 -std=c++17 -DVAME_PROBE -Wno-unused-value -Wno-unused-result -o tools/probe_gemm tools/probe_gemm.hip build/probe/elementwise.o
+	$(HIPCC) --offload-arch=gfx950 -shared -fPIC -o tools/libvame_hip_probe.so $(foreach n,$(NAMES),build/probe/$(n).o)
 
 clean:
-	rm -f vame_amd/libvame_hip.so tests/emu/libvame_emu.so tools/libvame_hip_ab.so tools/libvame_hip_probe.so tools/probe_gemm
+	rm -rf build vame_amd/libvame_hip.so tests/emu/libvame_emu.so tools/libvame_hip_ab.so tools/libvame_hip_probe.so tools/probe_gemm

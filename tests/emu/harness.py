@@ -43,7 +43,7 @@ def uninstall():
 
 def build():
     import subprocess
-    subprocess.run(["make", "-s", "tests/emu/libvame_emu.so"], cwd=ROOT, check=True)
+    subprocess.run(["make", "-s", "-j8", "tests/emu/libvame_emu.so"], cwd=ROOT, check=True)
 
 
 if __name__ == "__main__":

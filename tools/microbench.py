@@ -79,7 +79,7 @@ def bench_gru(H, B, T, nstreams, quiet=False, hook=None):
 
 def ablate():
     """GRU kernel ablations; needs the tuning build: make ab && VAME_LIB=tools/libvame_hip_ab.so python tools/microbench.py 10 ablate"""
-    for var, masks in (("VAME_ABL_FWD", (0, 1, 2, 4, 8, 16, 32, 7, 63)), ("VAME_ABL_BWD", (0, 1, 2, 3, 16, 32, 51))):
+    for var, masks in (("VAME_ABL_FWD", (0, 256, 0, 256)), ("VAME_ABL_BWD", (0, 128, 256, 384, 0, 128, 256, 384))):
         for m in masks:
             os.environ[var] = str(m)
             print(f"--- {var}={m}")

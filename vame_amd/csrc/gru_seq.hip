@@ -335,11 +335,12 @@ __global__ __launch_bounds__(H / 32 * 64) void gru_seq_fwd_kernel(GruFwdParams P
                 hnext[CR(r) * LDH] = hv;
             }
             if (!(ABL & 1) && stash) {
-                sp[(0 * 4 + q) * 64] = make_float4(ani[4 * q], ani[4 * q + 1], ani[4 * q + 2], ani[4 * q + 3]);
-                sp[(1 * 4 + q) * 64] = make_float4(au[4 * q], au[4 * q + 1], au[4 * q + 2], au[4 * q + 3]);
-                sp[(2 * 4 + q) * 64] = make_float4(ust[4 * q], ust[4 * q + 1], ust[4 * q + 2], ust[4 * q + 3]);
-                sp[(3 * 4 + q) * 64] = make_float4(ar[4 * q], ar[4 * q + 1], ar[4 * q + 2], ar[4 * q + 3]);
-                sp[(4 * 4 + q) * 64] = make_float4(anh[4 * q], anh[4 * q + 1], anh[4 * q + 2], anh[4 * q + 3]);
+                const float4 v0 = make_float4(ani[4 * q], ani[4 * q + 1], ani[4 * q + 2], ani[4 * q + 3]);
+                const float4 v1 = make_float4(au[4 * q], au[4 * q + 1], au[4 * q + 2], au[4 * q + 3]);
+                const float4 v2 = make_float4(ust[4 * q], ust[4 * q + 1], ust[4 * q + 2], ust[4 * q + 3]);
+                const float4 v3 = make_float4(ar[4 * q], ar[4 * q + 1], ar[4 * q + 2], ar[4 * q + 3]);
+                const float4 v4 = make_float4(anh[4 * q], anh[4 * q + 1], anh[4 * q + 2], anh[4 * q + 3]);
+                sp[(0 * 4 + q) * 64] = v0; sp[(1 * 4 + q) * 64] = v1; sp[(2 * 4 + q) * 64] = v2; sp[(3 * 4 + q) * 64] = v3; sp[(4 * 4 + q) * 64] = v4;
             }
             SCHED_FENCE();
         }
@@ -473,7 +474,7 @@ __global__ __launch_bounds__(H / 32 * 64) void gru_seq_bwd_kernel(GruBwdParams P
             }
         }
         GRU_PHASE(3);                 // dG copy-out
-        if (!(ABL & 2) && step + 1 < T) load_step(step + 1);
+        if (!(ABL & 2) && (ABL & 128) && step + 1 < T) load_step(step + 1);      // (ablation: the old place, before the MFMA loop)
         GRU_PHASE(4);                 // next step's stash / dy loads (issue)
         f32x16 acc1;
 #pragma unroll
@@ -483,6 +484,7 @@ __global__ __launch_bounds__(H / 32 * 64) void gru_seq_bwd_kernel(GruBwdParams P
         for (int c0 = 0; c0 < KC / 2; c0 += PD)
 #pragma unroll
         for (int j = 0; j < PD; ++j) {
+            if ((ABL & 64) && j == 0 && c0 == (KC / 2 / PD * 3 / 4) * PD && step + 1 < T) load_step(step + 1);
             const int c = 2 * (c0 + j);
             const float4 a0 = *reinterpret_cast<const float4*>(grow_a + 8 * c);
             const float4 a1 = *reinterpret_cast<const float4*>(grow_a + 8 * c + 8);
@@ -499,6 +501,9 @@ __global__ __launch_bounds__(H / 32 * 64) void gru_seq_bwd_kernel(GruBwdParams P
             }
             if (j == PD - 1) GRU_PHASE_DYN(8 + c0 / PD);
         }
+        // next step's stash / dy loads: issued AFTER the MFMA loop -- before it they sit in front of every weight-fragment load of the
+        // loop in the in-order vmcnt queue (measured: 2-3 % slower); their latency overlaps barrier 2 and the other wave's loop tail
+        if (!(ABL & 2) && !(ABL & 192) && step + 1 < T) load_step(step + 1);
 #pragma unroll
         for (int r = 0; r < 16; ++r) dh[r] = acc0[r] + acc1[r];
         GRU_PHASE(5);                 // MFMA loop
@@ -548,6 +553,7 @@ static void launch_bwd(const GruBwdParams& P, hipStream_t st) {
     if (H == 256) switch (abl_env("VAME_ABL_BWD")) {
         ABL_CASE(gru_seq_bwd_kernel, 256, 1, P, st) ABL_CASE(gru_seq_bwd_kernel, 256, 2, P, st) ABL_CASE(gru_seq_bwd_kernel, 256, 3, P, st)
         ABL_CASE(gru_seq_bwd_kernel, 256, 16, P, st) ABL_CASE(gru_seq_bwd_kernel, 256, 32, P, st) ABL_CASE(gru_seq_bwd_kernel, 256, 51, P, st)
+        ABL_CASE(gru_seq_bwd_kernel, 256, 64, P, st) ABL_CASE(gru_seq_bwd_kernel, 256, 128, P, st)
         default: break;
     }
 #endif
