@@ -188,6 +188,31 @@ int64_t vame_gru_coop_xbuf_floats(int nstreams, int B, int H);
 int vame_gru_coop_bwd_f32(const int64_t* desc, int nstreams, int B, int H, int row0, int nrows, float* xbuf, int* flags, int epoch_base,
                           int* status, void* stream);
 
+/* ---- Gaussian HMM over the latents (reference pose_segmentation.py:145-158 = hmmlearn GaussianHMM(covariance_type=
+ * "full").fit / .predict; vame_amd/csrc/hmm.hip).  float64; X (N, D) float32 latents; K <= 32 states, D <= 64; L = frames per chunk of the
+ * chunk-parallel recursions.  One EM iteration = emission -> forward -> backward -> stats; the M-step (K small matrices) is the host's.
+ *   emission: logB[t,k] = logconst[k] - 0.5 |Linv_k (x_t - mean_k)|^2 (Linv_k = inverse lower Cholesky factor of Sigma_k, row-major),
+ *             bexp = exp(logB - rowmax), rowmax[t] = max_k logB[t,k]
+ *   forward : alpha-hat (N,K) and the per-frame normalisers cnorm (log-likelihood = sum_t log cnorm[t] + rowmax[t])
+ *   backward: gamma (N,K) smoothed posteriors and R (N,K) with xi_t[i][j] = alpha_t[i] A[i][j] R_t[j]
+ *   stats   : [post K | start K | sum_t alpha_t^T R_t (K*K, multiply by A for the expected transitions) | obs K*D | loglik 1 |
+ *             sum_t gamma[t,k] x_t x_t^T (K*D*D)]; deterministic (fixed-order partial sums)
+ *   viterbi : most likely state path (int32) and its log probability from logB and log start / transition probabilities */
+int vame_hmm_emission_f64(const float* X, int64_t N, int D, const double* mean, const double* linv, const double* logconst, int K,
+                          double* logB, double* bexp, double* rowmax, void* stream);
+int64_t vame_hmm_ws_doubles(int64_t N, int K, int L);
+int vame_hmm_forward_f64(const double* bexp, int64_t N, int K, const double* startprob, const double* transmat, int L, double* alpha,
+                         double* cnorm, double* ws, void* stream);
+int vame_hmm_backward_f64(const double* bexp, int64_t N, int K, const double* transmat, const double* alpha, int L, double* gamma, double* R,
+                          double* ws, void* stream);
+int64_t vame_hmm_stats_doubles(int K, int D);
+int64_t vame_hmm_stats_ws_doubles(int K, int D);
+int vame_hmm_stats_f64(const float* X, int64_t N, int D, int K, const double* alpha, const double* gamma, const double* R, const double* cnorm,
+                       const double* rowmax, double* stats, double* ws, void* stream);
+int64_t vame_hmm_viterbi_ws_bytes(int64_t N, int K, int L);
+int vame_hmm_viterbi_f64(const double* logB, int64_t N, int K, const double* log_startprob, const double* log_transmat, int L, int* path,
+                         double* logprob, double* ws, unsigned char* bws, void* stream);
+
 /* ---- training-set preparation: the O(N*F) float64 passes of vame/model/create_training.py.
  * Arrays are (F, N) feature-major with a leading dimension (elements), like <file>-PE-seq.npy; results are bit-identical to
  * the reference's numpy / scipy arithmetic.  mean, sd, cutoff come from the host (np.mean / np.std / iqr_factor * scipy iqr). */

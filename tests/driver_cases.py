@@ -222,3 +222,37 @@ def check_parameterization_with_gpu_kmeans_option():
         ref, _, _ = fn(dict(cfg, amd_gpu_kmeans=False), *args[1:])
         from sklearn.metrics import adjusted_rand_score
         assert all(adjusted_rand_score(a, b) == 1.0 for a, b in zip(labels, ref))
+
+
+def check_pose_segmentation_hmm(project):
+    """cfg['parameterization'] = 'hmm' (pose_segmentation.py:145-158): Gaussian HMM over the latents (GaussianHMMHIP when hmmlearn is absent or
+    cfg['amd_gpu_hmm']), labels / motif usage files, results/hmm_trained.pkl, and the hmm_trained = True reload path."""
+    import pickle
+    import vame_amd as vame
+    root, cfg, g = project
+    hcfg = dict(cfg, parameterization="hmm", n_cluster=3, amd_gpu_hmm=True, hmm_trained=False)
+    with open(root / "config_hmm.yaml", "w") as f:
+        yaml.safe_dump(hcfg, f)
+    vame.pose_segmentation(str(root / "config_hmm.yaml"))
+    out = root / "results" / "vid1" / "VAME" / "hmm-3"
+    lat = np.load(out / "latent_vector_vid1.npy")
+    lab = np.load(out / "3_km_label_vid1.npy")
+    assert lab.shape == (lat.shape[0],) and set(np.unique(lab)) <= {0, 1, 2}
+    assert np.load(out / "motif_usage_vid1.npy").sum() == lat.shape[0]
+    assert not os.path.exists(out / "cluster_center_vid1.npy")                      # only the k-means branch writes centres (:306)
+    with open(root / "results" / "hmm_trained.pkl", "rb") as f:
+        model = pickle.load(f)
+    np.testing.assert_array_equal(model.predict(lat), lab)
+    # the fitted model is a local optimum of its own likelihood: the oracle's E-step on it reproduces the final log-likelihood trend
+    from oracle.hmm_oracle import GaussianHMMOracle
+    ref = GaussianHMMOracle(3)
+    ref.startprob_, ref.transmat_, ref.means_, ref.covars_ = model.startprob_, model.transmat_, model.means_, model.covars_
+    assert ref.score(lat.astype(np.float64)) >= model.history_[-1] - 1e-6 * abs(model.history_[-1])
+    np.testing.assert_array_equal(ref.predict(lat), lab)
+    # pretrained path: delete the result folder, reload the pickle
+    import shutil
+    shutil.rmtree(out)
+    with open(root / "config_hmm.yaml", "w") as f:
+        yaml.safe_dump(dict(hcfg, hmm_trained=True), f)
+    vame.pose_segmentation(str(root / "config_hmm.yaml"))
+    np.testing.assert_array_equal(np.load(out / "3_km_label_vid1.npy"), lab)

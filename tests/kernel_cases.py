@@ -559,3 +559,64 @@ def check_adam_abort_and_mask_scale(dev):
     d = T_(Y[:, 1:T + 1].copy(), dev)
     ops.mask_scale(d, 0, C, 0, 0, T_(mask, dev), 2.0, d, B * T, C)
     np.testing.assert_allclose(N_(d), Y[:, 1:T + 1] * mask * 2.0, rtol=1e-6)
+
+
+def _hmm_data(rng, N, K, D):
+    """A sticky K-state Gaussian chain: states are recoverable but overlapping enough for soft posteriors."""
+    A = np.full((K, K), 0.08 / (K - 1))
+    np.fill_diagonal(A, 0.92)
+    means = rng.standard_normal((K, D)) * 2.0
+    scales = rng.uniform(0.5, 1.5, (K, D))
+    z = np.empty(N, dtype=int)
+    z[0] = rng.integers(K)
+    for t in range(1, N):
+        z[t] = rng.choice(K, p=A[z[t - 1]])
+    X = means[z] + rng.standard_normal((N, D)) * scales[z]
+    return X.astype(np.float32), z
+
+
+def check_hmm(dev, N=700, K=4, D=6, chunk=64):
+    """GaussianHMMHIP (vame_amd/analysis/hmm_hip.py, float64 kernels) against the numpy restatement of hmmlearn's algorithm
+    (oracle/hmm_oracle.py): one E-step (log-likelihood, every sufficient statistic), the whole EM trajectory and the Viterbi path."""
+    from oracle.hmm_oracle import GaussianHMMOracle, log_mvn_density_full
+    from vame_amd.analysis.hmm_hip import GaussianHMMHIP
+    rng = np.random.default_rng(11)
+    X, z = _hmm_data(rng, N, K, D)
+    means0 = X[rng.choice(N, K, replace=False)].astype(np.float64)
+    ref = GaussianHMMOracle(K, n_iter=6)
+    ref.init_params(X.astype(np.float64), means0)
+    # perturbed parameters (non-uniform start / transition probabilities) for the single E-step comparison
+    ref.startprob_ = rng.dirichlet(np.ones(K))
+    ref.transmat_ = rng.dirichlet(np.ones(K) * 2, size=K)
+    hip = GaussianHMMHIP(K, n_iter=6, chunk=chunk)
+    hip._init_params(X, means0)
+    hip.startprob_, hip.transmat_ = ref.startprob_.copy(), ref.transmat_.copy()
+    Xd = hip._upload(X)
+    b = hip._buffers(N, D, Xd.device)
+    ll, st = hip._e_step(Xd, b)
+    ll_ref, st_ref, post_ref = ref.e_step(X.astype(np.float64))
+    np.testing.assert_allclose(b["logB"].cpu().numpy().reshape(N, K), log_mvn_density_full(X.astype(np.float64), ref.means_, ref.covars_), rtol=1e-9, atol=1e-9)
+    assert abs(ll - ll_ref) <= 1e-8 * abs(ll_ref), (ll, ll_ref)
+    np.testing.assert_allclose(b["gamma"].cpu().numpy().reshape(N, K), post_ref, atol=1e-10)
+    for k in ("post", "start", "trans", "obs", "obsobs"):
+        np.testing.assert_allclose(st[k], st_ref[k], rtol=1e-8, atol=1e-9, err_msg=k)
+    assert abs(st["trans"].sum() - (N - 1)) < 1e-6 and abs(st["post"].sum() - N) < 1e-6
+    # EM trajectory from the same initial means
+    ref2 = GaussianHMMOracle(K, n_iter=6).fit(X.astype(np.float64), means0)
+    hip2 = GaussianHMMHIP(K, n_iter=6, chunk=chunk).fit(X, means=means0)
+    np.testing.assert_allclose(hip2.history_, ref2.history, rtol=1e-8)
+    assert all(b2 >= a2 - 1e-6 for a2, b2 in zip(hip2.history_, hip2.history_[1:]))           # EM never decreases the likelihood
+    np.testing.assert_allclose(hip2.means_, ref2.means_, atol=1e-7)
+    np.testing.assert_allclose(hip2.covars_, ref2.covars_, atol=1e-7)
+    np.testing.assert_allclose(hip2.transmat_, ref2.transmat_, atol=1e-8)
+    # Viterbi: same path and score; the path's score is the maximum (>= the true states' joint log-probability)
+    lp, path = hip2.decode(X)
+    from oracle.hmm_oracle import log_mask_zero, viterbi_log
+    logB = log_mvn_density_full(X.astype(np.float64), ref2.means_, ref2.covars_)
+    lp_ref, path_ref = viterbi_log(log_mask_zero(ref2.startprob_), log_mask_zero(ref2.transmat_), logB)
+    np.testing.assert_array_equal(path, path_ref)
+    assert abs(lp - lp_ref) <= 1e-8 * abs(lp_ref)
+    np.testing.assert_array_equal(hip2.predict(X), path_ref)
+    import pickle
+    clone = pickle.loads(pickle.dumps(hip2))                                                   # results/hmm_trained.pkl round trip
+    np.testing.assert_array_equal(clone.predict(X), path_ref)

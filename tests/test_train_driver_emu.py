@@ -18,6 +18,10 @@ def test_pose_segmentation_outputs(project):
     dc.check_pose_segmentation_outputs(project)
 
 
+def test_pose_segmentation_hmm(project):
+    dc.check_pose_segmentation_hmm(project)
+
+
 def test_evaluate_model_outputs(project):
     dc.check_evaluate_model_outputs(project)
 

@@ -54,6 +54,15 @@ _SIGS = {
     "vame_gru_coop_fwd_f32": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p]),
     "vame_gru_coop_xbuf_floats": (c_int64, [c_int, c_int, c_int]),
     "vame_gru_coop_bwd_f32": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
+    "vame_hmm_emission_f64": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "vame_hmm_ws_doubles": (c_int64, [c_int64, c_int, c_int]),
+    "vame_hmm_forward_f64": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "vame_hmm_backward_f64": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "vame_hmm_stats_doubles": (c_int64, [c_int, c_int]),
+    "vame_hmm_stats_ws_doubles": (c_int64, [c_int, c_int]),
+    "vame_hmm_stats_f64": (c_int, [c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "vame_hmm_viterbi_ws_bytes": (c_int64, [c_int64, c_int, c_int]),
+    "vame_hmm_viterbi_f64": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "vame_prep_zscore_mask_f64": (c_int, [c_void_p, c_int, c_int64, c_int64, c_double, c_double, c_double, c_int, c_void_p, c_int64, c_void_p]),
     "vame_prep_ws_bytes": (c_int64, [c_int]),
     "vame_prep_fill_last_valid_f64": (c_int, [c_void_p, c_int, c_int64, c_int64, c_void_p, c_void_p, c_void_p]),

@@ -112,6 +112,19 @@ def _kmeans_cls(cfg):
     return KMeans
 
 
+def _hmm_cls(cfg):
+    """hmmlearn's GaussianHMM (the reference's exact behaviour) when it is installed and cfg['amd_gpu_hmm'] is not set; otherwise the
+    same Baum-Welch / Viterbi on the MI355X (vame_amd/analysis/hmm_hip.py)."""
+    if not cfg.get('amd_gpu_hmm', False):
+        try:
+            from hmmlearn import hmm
+            return hmm.GaussianHMM
+        except ImportError:
+            print("hmmlearn is not installed: using the MI355X Gaussian HMM (vame_amd.analysis.hmm_hip)")
+    from .hmm_hip import GaussianHMMHIP
+    return GaussianHMMHIP
+
+
 def same_parameterization(cfg, files, latent_vector_files, states, parameterization):
     KMeans = _kmeans_cls(cfg)
     labels, cluster_centers, motif_usages = [], [], []
@@ -122,11 +135,11 @@ def same_parameterization(cfg, files, latent_vector_files, states, parameterizat
         clust_center = kmeans.cluster_centers_
         label = kmeans.predict(latent_vector_cat)
     elif parameterization == "hmm":
-        from hmmlearn import hmm
+        GaussianHMM = _hmm_cls(cfg)
         save_data = os.path.join(cfg['project_path'], "results", "")
         if cfg['hmm_trained'] == False:  # noqa: E712
             print("Using a HMM as parameterization!")
-            hmm_model = hmm.GaussianHMM(n_components=states, covariance_type="full", n_iter=100)
+            hmm_model = GaussianHMM(n_components=states, covariance_type="full", n_iter=100)
             hmm_model.fit(latent_vector_cat)
             label = hmm_model.predict(latent_vector_cat)
             with open(save_data + "hmm_trained.pkl", "wb") as file:

@@ -18,7 +18,7 @@ def _ptr(t, off=0):
     if t is None:
         return None
     _lib.require_device_tensor(t)
-    assert t.dtype in (torch.float32, torch.float64, torch.int64, torch.int32), t.dtype
+    assert t.dtype in (torch.float32, torch.float64, torch.int64, torch.int32, torch.uint8), t.dtype
     return t.data_ptr() + off * t.element_size()
 
 
