@@ -188,6 +188,14 @@ int64_t vame_gru_coop_xbuf_floats(int nstreams, int B, int H);
 int vame_gru_coop_bwd_f32(const int64_t* desc, int nstreams, int B, int H, int row0, int nrows, float* xbuf, int* flags, int epoch_base,
                           int* status, void* stream);
 
+/* ---- wide hidden sizes, 256 < H <= 512 (H % 64 == 0; vame_amd/csrc/gru_wide.hip): batch-tile-persistent forward with two 32-column
+ * blocks per wave; descriptor table, sequence layout and fragment-order stash (NB = H/32 blocks) as vame_gru_seq_fwd_f32, no fused input
+ * projection.  vame_gru_cell_bwd_frag_f32: one BPTT step's gate math (vame_gru_cell_bwd_f32) reading that fragment-order stash. */
+int vame_gru_wide_supported(int H);
+int vame_gru_wide_fwd_f32(const int64_t* desc, int nstreams, int B, int H, void* stream);
+int vame_gru_cell_bwd_frag_f32(const float* stash, int T, int t, float* dh, const float* dy, int64_t dy_row, float* dG, int64_t dg_row,
+                               float* dgh, int B, int H, void* stream);
+
 /* ---- Gaussian HMM over the latents (reference pose_segmentation.py:145-158 = hmmlearn GaussianHMM(covariance_type=
  * "full").fit / .predict; vame_amd/csrc/hmm.hip).  float64; X (N, D) float32 latents; K <= 32 states, D <= 64; L = frames per chunk of the
  * chunk-parallel recursions.  One EM iteration = emission -> forward -> backward -> stats; the M-step (K small matrices) is the host's.

@@ -71,3 +71,8 @@ def test_device_window_loader_matches_reference_batcher(emu, tmp_path):
 
 def test_cooperative_launch_failure_is_contained(emu):
     check_coop_failure_is_contained("cpu")
+
+
+def test_wide_hidden_size_model_step_vs_oracle(emu):
+    """256 < H <= 512: persistent two-blocks-per-wave forward (gru_wide.hip) + step-wise BPTT on its fragment stash, whole train step."""
+    check_odd_dims_vs_oracle("cpu", F=12, Z=7, H=320, T=3, FS=2, B=5)

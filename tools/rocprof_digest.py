@@ -23,7 +23,7 @@ csv.field_size_limit(1 << 30)
 
 
 def short(name):
-    name = name.strip()
+    name = name.strip().replace("(anonymous namespace)::", "")
     m = re.match(r"^(?:void\s+)?([A-Za-z_][\w:]*)(<.*)?$", name.split("(")[0].strip())
     base = m.group(1) if m else name[:60]
     if base.startswith(("gemm_kernel", "gru_", "splitk", "nuclear", "window", "latent", "mse", "colsum", "timesum", "adam", "axpy", "mask_scale",

@@ -403,6 +403,50 @@ extern "C" int vame_gru_cell_bwd_f32(const float* stash, int64_t st_row, float* 
     return VAME_OK;
 }
 
+// The same step with the stash in the ACCUMULATOR-FRAGMENT order the persistent forward kernels write (gru_seq.hip / gru_wide.hip):
+// float4 index ((((tile*T + t)*NB + wb)*5 + k)*4 + rq)*64 + lane holds rows 8*rq + 4*(lane>>5) + (0..3) of column 32*wb + (lane&31).
+// One thread per float4 slot: five coalesced 16-byte loads, then four rows of dh / dy / dG / dgh (128-byte segments per half wave).
+__global__ __launch_bounds__(256) void gru_cell_bwd_frag_kernel(const float4* __restrict__ stash, int T, int t, float* __restrict__ dh,
+                                                                const float* __restrict__ dy, int64_t dy_row, float* __restrict__ dG,
+                                                                int64_t dg_row, float* __restrict__ dgh, int B, int H) {
+    const int NB = H / 32;
+    const int64_t n = (int64_t)((B + 31) / 32) * NB * 4 * 64;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int lane = (int)(i & 63), rq = (int)((i >> 6) & 3);
+        const int64_t tw = i >> 8;
+        const int wb = (int)(tw % NB);
+        const int64_t tile = tw / NB;
+        const int j = 32 * wb + (lane & 31);
+        const float4* sp = stash + ((((tile * T + t) * NB + wb) * 5) * 4 + rq) * 64 + lane;
+        const float4 cA = sp[0], cB = sp[4 * 64], u = sp[8 * 64], r4 = sp[12 * 64], g4 = sp[16 * 64];
+        const float a_[4] = {cA.x, cA.y, cA.z, cA.w}, b_[4] = {cB.x, cB.y, cB.z, cB.w}, u_[4] = {u.x, u.y, u.z, u.w},
+                    r_[4] = {r4.x, r4.y, r4.z, r4.w}, g_[4] = {g4.x, g4.y, g4.z, g4.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int64_t b = tile * 32 + 8 * rq + 4 * (lane >> 5) + e;
+            if (b >= B) continue;
+            const float d = dh[b * H + j] + (dy ? dy[b * dy_row + j] : 0.f);
+            const float dan = d * a_[e], dau = d * b_[e], dghn = dan * r_[e], dar = dghn * g_[e] * (1.0f - r_[e]);
+            dh[b * H + j] = d * u_[e];
+            float* o = dG + b * dg_row + j;
+            o[0] = dar; o[H] = dau; o[2 * H] = dan; o[3 * H] = dghn;
+            float* q = dgh + b * 3 * H + j;
+            q[0] = dar; q[H] = dau; q[2 * H] = dghn;
+        }
+    }
+}
+
+extern "C" int vame_gru_cell_bwd_frag_f32(const float* stash, int T, int t, float* dh, const float* dy, int64_t dy_row, float* dG, int64_t dg_row,
+                                          float* dgh, int B, int H, void* stream) {
+    VAME_CHECK_ARG(stash && dh && dG && dgh && B >= 1 && H >= 32 && H % 32 == 0 && t >= 0 && t < T, VAME_E_BADARG, "gru_cell_bwd_frag: bad argument");
+    VAME_CHECK_ARG((uintptr_t)stash % 16 == 0, VAME_E_SHAPE, "gru_cell_bwd_frag: stash must be 16-byte aligned");
+    const int64_t n = (int64_t)((B + 31) / 32) * (H / 32) * 4 * 64;
+    hipLaunchKernelGGL(gru_cell_bwd_frag_kernel, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const float4*>(stash), T, t, dh,
+                       dy, dy_row, dG, dg_row, dgh, B, H);
+    VAME_LAUNCH_CHECK("gru_cell_bwd_frag");
+    return VAME_OK;
+}
+
 // --------------------------------------------------------------------------------- k-means E-step
 // Nearest-centre assignment over the (N, D) latent vectors (vame/analysis/pose_segmentation.py:141,179: sklearn KMeans on the
 // embedding).  HBM-bound scan: 4*D bytes in per row; rows are staged through LDS with coalesced loads, the K centres live in

@@ -131,6 +131,7 @@ class VAEEngine:
         self.wgrad_streams = int(os.environ.get("VAME_AMD_WGRAD_STREAMS", "0"))
         # column-split GRU kernels for batches that leave most CUs idle (see _coop_parts); VAME_AMD_COOP=0 keeps the persistent ones
         self.coop = os.environ.get("VAME_AMD_COOP", "1") != "0"
+        self.wide = os.environ.get("VAME_AMD_WIDE", "1") != "0"
         self._coop_state = None
         self._nuc_state = None
         self._drop_mask = None
@@ -151,6 +152,11 @@ class VAEEngine:
 
     def _stepwise(self, H):
         return self.force_stepwise or H > 256
+
+    def _wide(self, H):
+        """256 < H <= 512: the forward recurrence runs in the two-blocks-per-wave persistent kernel (gru_wide.hip, fragment-order
+        stash); BPTT stays step by step (per-step GEMM + gate kernel reading that stash)."""
+        return self.wide and not self.force_stepwise and H > 256 and ops.gru_wide_supported(H)
 
     def _all_dirs(self):
         return self.enc[0] + self.enc[1] + self.dec + self.fut
@@ -341,6 +347,10 @@ class VAEEngine:
         as one launch per size."""
         for H in sorted({r["_s"].d.H for r in rows}, reverse=True):
             part_rows = [r for r in rows if r["_s"].d.H == H]
+            if self._wide(H):
+                for i in range(0, len(part_rows), 2):                # two streams per launch: one XCD parity class each
+                    ops.gru_wide_fwd(part_rows[i:i + 2], B, H)
+                continue
             if self._stepwise(H):
                 for r in part_rows:
                     self._stepwise_fwd(r["_s"], B)
@@ -406,8 +416,12 @@ class VAEEngine:
         for step in range(T):
             fstep = T - 1 - step
             t = T - 1 - fstep if s.dirn else fstep
-            ops.gru_cell_bwd(s.stash, t * 5 * H, T * 5 * H, dh, s.dY, (t * 2 * H + s.dirn * H) if s.dY is not None else 0,
-                             s.dy_T * 2 * H, s.dG, t * 4 * H, T * 4 * H, dgh, B, H)
+            if self._wide(H):
+                ops.gru_cell_bwd_frag(s.stash, T, t, dh, s.dY, (t * 2 * H + s.dirn * H) if s.dY is not None else 0, s.dy_T * 2 * H, s.dG, t * 4 * H,
+                                      T * 4 * H, dgh, B, H)
+            else:
+                ops.gru_cell_bwd(s.stash, t * 5 * H, T * 5 * H, dh, s.dY, (t * 2 * H + s.dirn * H) if s.dY is not None else 0,
+                                 s.dy_T * 2 * H, s.dG, t * 4 * H, T * 4 * H, dgh, B, H)
             ops.gemm(B, H, 3 * H, Operand(dgh, 3 * H), 0, self.P(d.w_hh, H), 1, dh, H, accumulate=True, splitk=sk_b, ws=ws_b)
         if s.dh0 is not None:
             s.dh0[s.dh0_off:s.dh0_off + B * H].view(B, H).copy_(dhv)

@@ -230,6 +230,22 @@ def gru_seq_bwd(streams, B, H):
     _lib.check(rc, "vame_gru_seq_bwd_f32")
 
 
+def gru_wide_supported(H):
+    return bool(_lib.lib().vame_gru_wide_supported(H))
+
+
+def gru_wide_fwd(streams, B, H):
+    """Persistent forward for 256 < H <= 512 (gru_wide.hip); same `streams` table as gru_seq_fwd."""
+    d = _desc_tensor(streams, GF["N"])
+    rc = _lib.lib().vame_gru_wide_fwd_f32(d.data_ptr(), len(streams), B, H, _stream())
+    _lib.check(rc, "vame_gru_wide_fwd_f32")
+
+
+def gru_cell_bwd_frag(stash, T, t, dh, dy, dy_off, dy_row, dG, dg_off, dg_row, dgh, B, H):
+    rc = _lib.lib().vame_gru_cell_bwd_frag_f32(_ptr(stash), T, t, _ptr(dh), _ptr(dy, dy_off), dy_row, _ptr(dG, dg_off), dg_row, _ptr(dgh), B, H, _stream())
+    _lib.check(rc, "vame_gru_cell_bwd_frag_f32")
+
+
 def gru_cell_fwd(gi, gi_off, gi_row, gh, bhn, hprev, hp_off, hp_row, hout, ho_off, ho_row, stash, st_off, st_row, B, H):
     rc = _lib.lib().vame_gru_cell_fwd_f32(_ptr(gi, gi_off), gi_row, _ptr(gh), _ptr(bhn), _ptr(hprev, hp_off), hp_row,
                                           _ptr(hout, ho_off), ho_row, _ptr(stash, st_off), st_row, B, H, _stream())
