@@ -193,6 +193,7 @@ int vame_gru_coop_bwd_f32(const int64_t* desc, int nstreams, int B, int H, int r
  * projection.  vame_gru_cell_bwd_frag_f32: one BPTT step's gate math (vame_gru_cell_bwd_f32) reading that fragment-order stash. */
 int vame_gru_wide_supported(int H);
 int vame_gru_wide_fwd_f32(const int64_t* desc, int nstreams, int B, int H, void* stream);
+int vame_gru_wide_bwd_f32(const int64_t* desc, int nstreams, int B, int H, void* stream);   /* contract of vame_gru_seq_bwd_f32 */
 int vame_gru_cell_bwd_frag_f32(const float* stash, int T, int t, float* dh, const float* dy, int64_t dy_row, float* dG, int64_t dg_row,
                                float* dgh, int B, int H, void* stream);
 

@@ -56,6 +56,7 @@ _SIGS = {
     "vame_gru_coop_bwd_f32": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
     "vame_gru_wide_supported": (c_int, [c_int]),
     "vame_gru_wide_fwd_f32": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p]),
+    "vame_gru_wide_bwd_f32": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p]),
     "vame_gru_cell_bwd_frag_f32": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int, c_int, c_void_p]),
     "vame_hmm_emission_f64": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "vame_hmm_ws_doubles": (c_int64, [c_int64, c_int, c_int]),

@@ -132,6 +132,7 @@ class VAEEngine:
         # column-split GRU kernels for batches that leave most CUs idle (see _coop_parts); VAME_AMD_COOP=0 keeps the persistent ones
         self.coop = os.environ.get("VAME_AMD_COOP", "1") != "0"
         self.wide = os.environ.get("VAME_AMD_WIDE", "1") != "0"
+        self.wide_bwd = os.environ.get("VAME_AMD_WIDE_BWD", "1") != "0"      # 0: BPTT step by step (per-step GEMM + gate kernel)
         self._coop_state = None
         self._nuc_state = None
         self._drop_mask = None
@@ -366,6 +367,10 @@ class VAEEngine:
     def _gru_bwd(self, rows, B):
         for H in sorted({r["_s"].d.H for r in rows}, reverse=True):
             part_rows = [r for r in rows if r["_s"].d.H == H]
+            if self._wide(H) and self.wide_bwd:
+                for i in range(0, len(part_rows), 2):
+                    ops.gru_wide_bwd(part_rows[i:i + 2], B, H)
+                continue
             if self._stepwise(H):
                 for r in part_rows:
                     self._stepwise_bwd(r["_s"], B)

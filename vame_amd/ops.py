@@ -241,6 +241,12 @@ def gru_wide_fwd(streams, B, H):
     _lib.check(rc, "vame_gru_wide_fwd_f32")
 
 
+def gru_wide_bwd(streams, B, H):
+    d = _desc_tensor(streams, GB["N"])
+    rc = _lib.lib().vame_gru_wide_bwd_f32(d.data_ptr(), len(streams), B, H, _stream())
+    _lib.check(rc, "vame_gru_wide_bwd_f32")
+
+
 def gru_cell_bwd_frag(stash, T, t, dh, dy, dy_off, dy_row, dG, dg_off, dg_row, dgh, B, H):
     rc = _lib.lib().vame_gru_cell_bwd_frag_f32(_ptr(stash), T, t, _ptr(dh), _ptr(dy, dy_off), dy_row, _ptr(dG, dg_off), dg_row, _ptr(dgh), B, H, _stream())
     _lib.check(rc, "vame_gru_cell_bwd_frag_f32")
