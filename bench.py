@@ -80,7 +80,8 @@ def profile_kernels(model, loader, steps=3):
         def f(streams, B, Hh):
             key_t = ops.GF["T"] if tag == "fwd" else ops.GB["T"]
             fl = sum(2.0 * 3 * Hh * Hh * B * int(s[key_t]) for s in streams)
-            return (f"gru_seq_{tag}_kernel<{Hh}> x{len(streams)} streams", fl)
+            name = "gru_seq" if Hh <= 256 else "gru_wide"
+            return (f"{name}_{tag}_kernel<{Hh}> x{len(streams)} streams", fl)
         return f
 
     def gemm_flops(M, N, K, A, akm, Bm, bkm, *a, **k):
@@ -90,6 +91,7 @@ def profile_kernels(model, loader, steps=3):
         kind = "NT" if (not akm and not bkm) else ("NN" if not akm else "TN")
         return (f"gemm_kernel {kind} M={M} N={N} K={K} x{len(As)} grouped", 2.0 * M * N * K * len(As))
     saved = {n: kt.wrap(ops, n, fn) for n, fn in (("gru_seq_fwd", gru_flops("fwd")), ("gru_seq_bwd", gru_flops("bwd")),
+                                                  ("gru_wide_fwd", gru_flops("fwd")), ("gru_wide_bwd", gru_flops("bwd")),
                                                   ("gemm", gemm_flops), ("gemm_group", group_flops))}
     try:
         for _ in range(steps):
@@ -345,7 +347,7 @@ def main():
         out = dict(metric=f"temporal windows/sec (train) T={T},F={F},h={H}", value=round(value, 1), unit="windows/s", n_gpus=world,
                    steps=args.steps, warmup=args.warmup, ms_per_step=round(dt / args.steps * 1e3, 3), higher_is_better=True,
                    scaling="weak", vs_baseline=None, dtype="f32", data="synthetic",
-                   config=dict(workload=((("BASELINE.json configs[1]" if (H, T, B_LOCAL) == (256, 30, 4096) else "non-headline shape (BASELINE.json configs[3] is H=512,T=60,batch 8192)")
+                   config=dict(workload=((("BASELINE.json configs[1]" if (H, T, B_LOCAL) == (256, 30, 4096) else ("BASELINE.json configs[3]" if (H, T, B_LOCAL) == (512, 60, 8192) else "non-headline shape (BASELINE.json configs[3] is H=512,T=60,batch 8192)"))
                                           if world == 1 else f"BASELINE.json configs[2] shape on {world} GPUs (data-parallel)")
                                          + f": T={T},F={F},zdims={Z},hidden={H},FS={FS}, batch={B_LOCAL}/GPU fp32 train step "
                                          "(gather+fwd+loss+bwd+allreduce+Adam-amsgrad)"), global_batch=B_LOCAL * world,

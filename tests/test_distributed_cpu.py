@@ -105,3 +105,74 @@ def test_bench_script_under_torchrun_two_ranks(emu):
     assert out["n_gpus"] == 2 and out["steps"] == 2 and out["warmup"] == 1 and out["value"] > 0
     assert all(np.isfinite(out["config"]["last_loss_terms"]))
     assert out["roofline"] is None and "cpu_baseline" not in out           # nothing measured off the GPU
+
+
+def _driver_worker(rank, world, port, root):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    sys.path.insert(0, os.path.join(ROOT, "tests", "emu"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world),
+                      VAME_EMU_THREADS="2")
+    torch.set_num_threads(1)
+    import harness
+    harness.install()
+    import vame_amd as vame
+    from vame_amd.model import rnn_vae
+    seen = {}
+    orig_loss_step = rnn_vae.RNN_VAE.loss_step
+
+    def spy(self, win, *a, **k):                       # record what this rank trained on and with which draws
+        seen.setdefault("first_win", win[:2].clone())
+        seen.setdefault("eps0", torch.randn(3))       # consumes the rank's stream once, at the first step
+        seen["model"] = self
+        return orig_loss_step(self, win, *a, **k)
+    rnn_vae.RNN_VAE.loss_step = spy
+    np.random.seed(0)                                  # same numpy stream on both ranks: disjoint slices of one draw
+    vame.train_model(os.path.join(root, "config.yaml"))
+    flat = seen["model"].flat_parameters()[0].numpy().copy()
+    np.save(os.path.join(root, f"rank{rank}_params.npy"), flat)
+    np.save(os.path.join(root, f"rank{rank}_win.npy"), seen["first_win"].numpy())
+    np.save(os.path.join(root, f"rank{rank}_eps.npy"), seen["eps0"].numpy())
+    vame.pose_segmentation(os.path.join(root, "config.yaml"))
+    rnn_vae.shutdown_distributed()
+
+
+def test_train_and_segment_drivers_two_ranks(emu, tmp_path):
+    """vame.train_model() + vame.pose_segmentation() as two gloo ranks (the multi-GPU launch contract: one process per GPU, RANK /
+    WORLD_SIZE / MASTER_* from the environment): replicas end with identical weights, they trained on different windows with
+    different reparameterisation draws, only rank 0 wrote files, and the sharded embedding equals the single-process one."""
+    import json
+    import yaml
+    g = load_golden("train_model_run")
+    cfg = json.loads(str(g["cfg_json"]))
+    root = tmp_path
+    os.makedirs(root / "data" / "train")
+    os.makedirs(root / "model")
+    np.save(root / "data" / "train" / "train_seq.npy", g["train_seq"])
+    np.save(root / "data" / "train" / "test_seq.npy", g["test_seq"])
+    os.makedirs(root / "data" / "vid1")
+    np.save(root / "data" / "vid1" / "vid1-PE-seq-clean.npy", g["train_seq"][:, :101])
+    cfg.update(project_path=str(root), n_cluster=3, parameterization="kmeans", individual_parameterization=False, video_sets=["vid1"],
+               all_data="yes", hmm_trained=False, random_state_kmeans=42, n_init_kmeans=2, max_epochs=7, batch_size=32, model_snapshot=50)
+    with open(root / "config.yaml", "w") as f:
+        yaml.safe_dump(cfg, f)
+    world = 2
+    mp.spawn(_driver_worker, args=(world, _free_port(), str(root)), nprocs=world, join=True)
+    p0, p1 = np.load(root / "rank0_params.npy"), np.load(root / "rank1_params.npy")
+    np.testing.assert_array_equal(p0, p1)                                                   # lock-step replicas
+    assert np.abs(np.load(root / "rank0_win.npy") - np.load(root / "rank1_win.npy")).max() > 1e-3      # different windows ...
+    assert np.abs(np.load(root / "rank0_eps.npy") - np.load(root / "rank1_eps.npy")).max() > 1e-3      # ... and different draws
+    sd = torch.load(root / "model" / "best_model" / "VAME_demo.pkl", map_location="cpu")
+    flat_saved = np.concatenate([v.numpy().ravel() for v in sd.values()])
+    assert flat_saved.size == sum(v.numel() for v in sd.values())
+    losses = np.load(root / "model" / "model_losses" / "train_losses_VAME.npy")
+    assert losses.shape == (6,) and np.isfinite(losses).all()
+    # n_batches per rank = N // (B * world): both ranks looped the same number of steps (a mismatch would dead-lock the all-reduce)
+    out = root / "results" / "vid1" / "VAME" / "kmeans-3"
+    lat = np.load(out / "latent_vector_vid1.npy")
+    assert lat.shape == (101 - cfg["time_window"], cfg["zdims"])
+    from oracle import vame_oracle as vo
+    p = {k: v.numpy() for k, v in sd.items()}
+    ref = vo.embed_series(p, np.load(root / "data" / "vid1" / "vid1-PE-seq-clean.npy"),
+                          vo.Spec(T=30, F=24, Z=30, H=cfg["hidden_size_layer_1"], FS=15), batch=64)
+    np.testing.assert_allclose(lat, ref, atol=2e-5)                                         # shards of two ranks, gathered, in order

@@ -231,3 +231,38 @@ def test_device_window_loader_matches_reference_batcher(hip, tmp_path):
 
 def test_cooperative_launch_failure_is_contained(hip):
     check_coop_failure_is_contained("cuda")
+
+
+def test_cfg4_full_batch_properties(hip):
+    """BASELINE config 4 at its real size (H=512, T=60, batch 8192) on the wide persistent kernels (gru_wide.hip): encoder rows are
+    independent of how the batch is tiled over workgroups, a slice of the big batch equals the numpy oracle, and a train step gives
+    finite loss terms and gradients whose reconstruction term equals the error of the returned prediction."""
+    T, F, Z, H, FS, B = 60, 24, 30, 512, 15, 8192
+    torch.manual_seed(19)
+    model = RNN_VAE(2 * T, Z, F, 1, FS, H, H, H, H, 0, 0, 0, False).cuda().eval()
+    eng = model._ensure_engine()
+    assert eng._wide(H) and eng.wide_bwd
+    gen = torch.Generator().manual_seed(1)
+    win = torch.randn(B, T + FS, F, generator=gen).cuda()
+    x = win[:, :T].contiguous()
+    mu_all = model(x)[3]
+    mu_part = model(x[5000:5100].contiguous())[3]
+    assert (mu_all[5000:5100] - mu_part).abs().max().item() < 1e-5
+    p = {k: v.cpu().numpy() for k, v in model.state_dict().items()}
+    spec = vo.Spec(T=T, F=F, Z=Z, H=H, FS=FS)
+    ref = vo.model_forward(p, x[:8].cpu().numpy(), None, spec, training=False)[3]
+    assert np.abs(mu_all[:8].cpu().numpy() - ref).max() < 1e-4
+    model.train()
+    eps = torch.randn(B, Z, generator=gen).cuda()
+    out = model.loss_step(win, 1.0, beta=1.0, kloss=Z, klmbda=0.1, bsize=B, eps=eps).cpu().numpy()
+    assert np.isfinite(out).all()
+    pred = eng.buf("pred", B, T, F)[:B * T * F].view(B, T, F)
+    assert abs(float(((pred - x) ** 2).sum()) - out[0]) <= 2e-4 * out[0]
+    gn = torch.stack([prm.grad.norm() for prm in model.parameters()])
+    assert torch.isfinite(gn).all() and float(gn.min()) > 0
+    # the same step with the step-wise BPTT (per-step GEMM + gate kernel on the same fragment stash) gives the same gradients
+    g_wide = model.flat_parameters()[1].clone()
+    eng.wide_bwd = False
+    model.loss_step(win, 1.0, beta=1.0, kloss=Z, klmbda=0.1, bsize=B, eps=eps)
+    g_step = model.flat_parameters()[1]
+    assert float((g_wide - g_step).abs().max()) <= 2e-4 * float(g_step.abs().max())

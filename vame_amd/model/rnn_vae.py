@@ -373,6 +373,8 @@ def train_model(config):
                 np.save(os.path.join(loss_dir, nm + model_name), arr)
         print("\n")
 
+    if world > 1:
+        dist.barrier()                      # rank 0's checkpoint / loss files are complete before any rank goes on (pose_segmentation)
     if convergence < cfg['model_convergence']:
         print('Finished training...')
         print('Model seems to have not reached convergence. You may want to check your model \n'
