@@ -5,7 +5,7 @@
                                     start (us since the first dispatch), duration (us) -- so that e.g. the one 6-problem grouped
                                     GEMM launch of a step can be told apart from the other launches of the same kernel name
   stats  <dir> <out.csv>            per (kernel, grid) summary of the same run: calls, total / avg / min / max duration
-  pmc    <fetch_dir> <write_dir> <lib.so> <out.json> [--key "<bench key>=<kernel substring>@<grid>"]...
+  pmc    <fetch_dir> <write_dir> <lib.so> <out.json> [--key "<bench key>=><kernel substring>@<grid>"]...
                                     HBM traffic per call from two separate --pmc passes (FETCH_SIZE, WRITE_SIZE; KB units),
                                     corrected as MI355X_MICROARCH.md prescribes (gfx950 FETCH_SIZE reports 1/2 of wide coalesced
                                     reads -> x2); stores the sha256 of the library the counters were taken with, and the
@@ -90,7 +90,7 @@ def pmc(fetch_dir, write_dir, lib, out, keys):
         sha = hashlib.sha256(fh.read()).hexdigest()
     by_key = {}
     for spec in keys:
-        bench_key, sel = spec.split("=", 1) if "@" in spec.split("=", 1)[1] else (spec, "")
+        bench_key, sel = spec.split("=>", 1)                    # "<bench key>=><kernel substring>@<grid>"
         sub, grid = sel.rsplit("@", 1)
         hits = [v for k, v in kernels.items() if sub in k and k.endswith(f"grid={grid}")]
         if len(hits) != 1:
@@ -103,12 +103,34 @@ def pmc(fetch_dir, write_dir, lib, out, keys):
     print("wrote", out, "kernels:", len(kernels), "bench keys:", list(by_key))
 
 
+def sq(d, out, note=""):
+    """per (kernel, grid) means of every counter of a --pmc pass (SQ / GRBM), plus mfma_busy_frac = SQ_VALU_MFMA_BUSY_CYCLES /
+    (GRBM_GUI_ACTIVE x 128): the share of kernel cycles the matrix pipes were busy (same normalisation as profiles/r01_pmc_gru_kernels.json)."""
+    agg = {}
+    for r in rows_of(d, "counter_collection.csv"):
+        k = f"{short(r['Kernel_Name'])} grid={r['Grid_Size']}"
+        a = agg.setdefault(k, {}).setdefault(r["Counter_Name"], [0, 0.0])
+        a[0] += 1; a[1] += float(r["Counter_Value"])
+    res = {}
+    for k, cs in agg.items():
+        e = {c: v[1] / v[0] for c, v in cs.items()}
+        e["calls"] = max(v[0] for v in cs.values())
+        if "SQ_VALU_MFMA_BUSY_CYCLES" in e and e.get("GRBM_GUI_ACTIVE"):
+            e["mfma_busy_frac"] = round(e["SQ_VALU_MFMA_BUSY_CYCLES"] / (e["GRBM_GUI_ACTIVE"] * 128.0), 4)
+        res[k] = e
+    keep = dict(sorted(res.items(), key=lambda kv: -kv[1].get("GRBM_GUI_ACTIVE", 0) * kv[1]["calls"])[:24])
+    json.dump(dict(note=note, kernels=keep), open(out, "w"), indent=1)
+    print("wrote", out, {k: v.get("mfma_busy_frac") for k, v in list(keep.items())[:8]})
+
+
 if __name__ == "__main__":
     cmd = sys.argv[1]
     if cmd == "trace":
         trace(sys.argv[2], sys.argv[3])
     elif cmd == "stats":
         trace(sys.argv[2], sys.argv[3], stats_only=True)
+    elif cmd == "sq":
+        sq(sys.argv[2], sys.argv[3], sys.argv[4] if len(sys.argv) > 4 else "")
     elif cmd == "pmc":
         keys = [sys.argv[i + 1] for i, a in enumerate(sys.argv) if a == "--key"]
         pmc(sys.argv[2], sys.argv[3], sys.argv[4], sys.argv[5], keys)
