@@ -131,7 +131,10 @@ int vame_mse_fwd_bwd_f32(const float* pred, const float* target, int64_t tgt_row
  * so that gscale * d loss/dz = z Minv (gscale = the KL-annealing weight).  k is clipped to
  * min(kloss, Z, nrows) like sv_2[:kloss] of the reference's (B,B) SVD.  One workgroup, parallel
  * cyclic Jacobi in fp64.  vstate (optional, ((Z+1)&~1)^2 doubles, zeroed before first use) carries the
- * eigenvectors from call to call as a warm start (1-2 sweeps instead of 6-8 during training). */
+ * eigenvectors from call to call as a warm start (1-2 sweeps instead of 6-8 during training).
+ * 64 < Z <= 512: the matrices leave the LDS for the state buffer, which is then REQUIRED and 3 Z'^2 doubles
+ * (vame_nuclear_state_doubles; same zero-on-first-use rule); one 1024-thread workgroup, milliseconds instead of ~0.1 ms. */
+int64_t vame_nuclear_state_doubles(int Z);
 int vame_nuclear_f32(const float* G, int Z, int kloss, int nrows, float lmbda, float bsize, float gscale,
                      float* loss_out, float* Minv, double* vstate, void* stream);
 

@@ -431,7 +431,7 @@ def check_nuclear(dev, B, Z, k):
     assert abs(N_(loss)[0] - vo.cluster_loss_svd(z, k, 0.1, B)) <= 1e-4 * max(1, abs(ref_loss))
     np.testing.assert_allclose(z @ N_(Minv), ref_dz, atol=2e-5 * max(1, np.abs(ref_dz).max()))
     # warm start: a second, slightly perturbed Gram solved from the stored eigenvectors gives the same answer as a cold solve
-    vst = torch.zeros(((Z + 1) // 2 * 2) ** 2, device=dev, dtype=torch.float64)
+    vst = torch.zeros(ops.nuclear_state_doubles(Z), device=dev, dtype=torch.float64)
     ops.nuclear(T_(G, dev), Z, k, B, 0.1, B, loss, 0, Minv, vstate=vst)
     z2 = (z + 0.01 * rng.standard_normal(z.shape)).astype(np.float32)
     G2 = (z2.astype(np.float64).T @ z2.astype(np.float64)).astype(np.float32)

@@ -48,7 +48,7 @@ def test_elementwise(emu):
     check_adam_abort_and_mask_scale(DEV)
 
 
-@pytest.mark.parametrize("B,Z,k", [(64, 30, 30), (8, 30, 30), (50, 7, 4), (128, 34, 34), (96, 48, 20), (200, 64, 64), (70, 63, 63)])
+@pytest.mark.parametrize("B,Z,k", [(64, 30, 30), (8, 30, 30), (50, 7, 4), (128, 34, 34), (96, 48, 20), (200, 64, 64), (70, 63, 63), (150, 66, 66), (300, 96, 40)])
 def test_nuclear(emu, B, Z, k):
     check_nuclear(DEV, B, Z, k)
 
@@ -88,7 +88,7 @@ def test_gemm_group(emu):
     check_gemm_group("cpu")
 
 
-@pytest.mark.parametrize("N,K,D,chunk", [(700, 4, 6, 64), (300, 3, 5, 7), (130, 17, 4, 16)])
+@pytest.mark.parametrize("N,K,D,chunk", [(700, 4, 6, 64), (300, 3, 5, 7), (130, 17, 4, 16), (3000, 5, 8, None)])
 def test_gaussian_hmm_next_row_n1(emu, N, K, D, chunk):
     check_hmm(DEV, N, K, D, chunk)
 

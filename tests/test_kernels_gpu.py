@@ -33,7 +33,7 @@ def test_elementwise(hip):
     check_adam_abort_and_mask_scale(DEV)
 
 
-@pytest.mark.parametrize("B,Z,k", [(64, 30, 30), (8, 30, 30), (50, 7, 4), (4096, 30, 30), (128, 34, 34), (96, 48, 20), (4096, 64, 64), (70, 63, 63)])
+@pytest.mark.parametrize("B,Z,k", [(64, 30, 30), (8, 30, 30), (50, 7, 4), (4096, 30, 30), (128, 34, 34), (96, 48, 20), (4096, 64, 64), (70, 63, 63), (150, 66, 66), (4096, 128, 128), (600, 200, 90)])
 def test_nuclear(hip, B, Z, k):
     check_nuclear(DEV, B, Z, k)
 
@@ -74,7 +74,7 @@ def test_gemm_group(hip):
     check_gemm_group(DEV, small=False)
 
 
-@pytest.mark.parametrize("N,K,D,chunk", [(700, 4, 6, 64), (300, 3, 5, 7), (130, 17, 4, 16), (20000, 15, 30, 128)])
+@pytest.mark.parametrize("N,K,D,chunk", [(700, 4, 6, 64), (300, 3, 5, 7), (130, 17, 4, 16), (20000, 15, 30, 128), (20000, 15, 30, 512), (3000, 5, 8, None)])
 def test_gaussian_hmm_next_row_n1(hip, N, K, D, chunk):
     check_hmm(DEV, N, K, D, chunk)
 

@@ -51,6 +51,11 @@ def test_unaligned_feature_and_latent_dims(emu):
     check_odd_dims_vs_oracle("cpu", F=12, Z=30, H=64, T=6, FS=3, B=33)
 
 
+def test_latent_width_above_64(emu):
+    """zdims > 64 leaves the LDS-resident nuclear-norm kernel for the state-buffer one; everything else is width-agnostic."""
+    check_odd_dims_vs_oracle("cpu", F=12, Z=72, H=32, T=5, FS=2, B=90)
+
+
 def test_small_batch_cooperative_path_vs_oracle(emu):
     """H = 128 with a tiny batch goes through the column-split GRU kernels (engine._coop_ok): full step vs the numpy oracle."""
     check_odd_dims_vs_oracle("cpu", F=10, Z=7, H=128, T=4, FS=2, B=5)

@@ -209,6 +209,11 @@ def test_unaligned_feature_and_latent_dims(hip):
     check_odd_dims_vs_oracle("cuda", F=12, Z=30, H=64, T=6, FS=3, B=33)
 
 
+def test_latent_width_above_64(hip):
+    """zdims > 64 leaves the LDS-resident nuclear-norm kernel for the state-buffer one; everything else is width-agnostic."""
+    check_odd_dims_vs_oracle("cuda", F=12, Z=72, H=32, T=5, FS=2, B=90)
+
+
 @pytest.mark.parametrize("H,B,T,FS", [(128, 5, 4, 2), (256, 37, 6, 3)])
 def test_small_batch_cooperative_path_vs_oracle(hip, H, B, T, FS):
     """Small batches run the column-split GRU kernels (engine._coop_ok): full train step vs the numpy oracle, and the same step

@@ -38,6 +38,7 @@ _SIGS = {
     "vame_latent_bwd_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_void_p,
                                     c_void_p, c_void_p]),
     "vame_mse_fwd_bwd_f32": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p]),
+    "vame_nuclear_state_doubles": (c_int64, [c_int]),
     "vame_nuclear_f32": (c_int, [c_void_p, c_int, c_int, c_int, c_float, c_float, c_float, c_void_p, c_void_p, c_void_p, c_void_p]),
     "vame_kmeans_assign_f32": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "vame_timesum_f32": (c_int, [c_void_p, c_int, c_int, c_int, c_int64, c_void_p, c_void_p]),

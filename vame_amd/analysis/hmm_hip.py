@@ -21,7 +21,7 @@ def _ptr(t):
 
 class GaussianHMMHIP:
     def __init__(self, n_components, covariance_type="full", n_iter=100, tol=1e-2, min_covar=1e-3, startprob_prior=1.0, transmat_prior=1.0,
-                 means_prior=0.0, means_weight=0.0, covars_prior=1e-2, covars_weight=1.0, random_state=None, chunk=128):
+                 means_prior=0.0, means_weight=0.0, covars_prior=1e-2, covars_weight=1.0, random_state=None, chunk=None):
         if covariance_type != "full":
             raise ValueError("GaussianHMMHIP implements covariance_type='full' (what the reference uses)")
         if not 1 <= n_components <= 32:
@@ -29,10 +29,19 @@ class GaussianHMMHIP:
         self.n_components, self.covariance_type, self.n_iter, self.tol, self.min_covar = n_components, covariance_type, n_iter, tol, min_covar
         self.startprob_prior, self.transmat_prior = startprob_prior, transmat_prior
         self.means_prior, self.means_weight, self.covars_prior, self.covars_weight = means_prior, means_weight, covars_prior, covars_weight
-        self.random_state, self.chunk = random_state, int(chunk)
+        self.random_state, self.chunk = random_state, chunk      # frames per chunk of the parallel scans (None: by sequence length)
         self.history_ = []
 
     # ------------------------------------------------------------------ device plumbing
+    def _chunk(self, N):
+        # the chunk chain is sequential (one workgroup): keep it to a few thousand links, and every chunk at least 64 frames
+        if self.chunk:
+            return int(self.chunk)
+        L = 64
+        while L < 1024 and N > 2048 * L:
+            L *= 2
+        return L
+
     def _upload(self, X):
         Xh = np.ascontiguousarray(X, dtype=np.float32)
         if Xh.ndim != 2 or Xh.shape[1] > 64:
@@ -40,7 +49,7 @@ class GaussianHMMHIP:
         return torch.from_numpy(Xh).to(_lib.device())
 
     def _buffers(self, N, D, dev):
-        K, L = self.n_components, self.chunk
+        K, L = self.n_components, self._chunk(N)
         f64 = dict(dtype=torch.float64, device=dev)
         L_ = _lib.lib()
         return dict(logB=torch.empty(N * K, **f64), bexp=torch.empty(N * K, **f64), rowmax=torch.empty(N, **f64), alpha=torch.empty(N * K, **f64),
@@ -70,7 +79,7 @@ class GaussianHMMHIP:
     def _e_step(self, Xd, b):
         """Forward / backward / statistics on the device; returns (log-likelihood, stats dict on the host)."""
         N, D = Xd.shape
-        K, L = self.n_components, self.chunk
+        K, L = self.n_components, self._chunk(N)
         dev = Xd.device
         to = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64)).to(dev)      # noqa: E731
         sp_d, tm_d = to(self.startprob_), to(self.transmat_)
@@ -146,7 +155,7 @@ class GaussianHMMHIP:
     def decode(self, X):
         Xd = self._upload(X)
         N, D = Xd.shape
-        K, L = self.n_components, self.chunk
+        K, L = self.n_components, self._chunk(N)
         dev = Xd.device
         f64 = dict(dtype=torch.float64, device=dev)
         lib = _lib.lib()

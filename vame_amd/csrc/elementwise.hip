@@ -676,13 +676,160 @@ __global__ __launch_bounds__(256) void nuclear_kernel(const float* __restrict__ 
     }
 }
 
+// Same decomposition for 64 < Z <= 512 (configurations far from VAME's zdims = 30 default): the matrices no longer fit the
+// LDS, so A, V and a scratch image live in a caller-provided state buffer st = [V | A | T] (3 Z'^2 doubles, L2-resident; V
+// doubles as the warm-start state exactly as above and must be zero on first use).  One 1024-thread workgroup; global
+// traffic between threads of the workgroup is ordered by the barriers.  Latency is milliseconds, not 0.1 ms.
+#define NUCB_MAXZ 512
+#define NUCB_THREADS 1024
+__global__ __launch_bounds__(NUCB_THREADS) void nuclear_big_kernel(const float* __restrict__ G, int Z, int kloss, int nrows, float lmbda,
+                                                                   float bsize, float gscale, float* __restrict__ loss_out,
+                                                                   float* __restrict__ Minv, double* st) {
+    __shared__ double cs[NUCB_MAXZ];       // c at [k], s at [k + NUCB_MAXZ / 2]
+    __shared__ int pq[NUCB_MAXZ];
+    __shared__ double wsel[NUCB_MAXZ];
+    __shared__ double ro[NUCB_THREADS], rd[NUCB_THREADS];
+    __shared__ int warm;
+    constexpr int HB = NUCB_MAXZ / 2, NT = NUCB_THREADS;
+    const int tid = threadIdx.x, n = Z + (Z & 1), np = n / 2, nn = n * n;
+    double* V = st;
+    double* A = st + nn;
+    double* Tm = st + 2 * nn;
+    if (tid == 0) warm = st[0] != 0.0;
+    __syncthreads();
+    for (int i = tid; i < nn; i += NT) {
+        const int r = i / n, c = i % n;
+        A[i] = (r < Z && c < Z) ? 0.5 * ((double)G[r * Z + c] + (double)G[c * Z + r]) / (double)bsize : 0.0;
+        if (!warm) V[i] = (r == c) ? 1.0 : 0.0;
+    }
+    __syncthreads();
+    if (warm) {
+        for (int i = tid; i < nn; i += NT) {              // T = A V
+            const int r = i / n, c = i % n;
+            double s = 0.0;
+            for (int k = 0; k < n; ++k) s += A[r * n + k] * V[k * n + c];
+            Tm[i] = s;
+        }
+        __syncthreads();
+        for (int i = tid; i < nn; i += NT) {              // A = V^T T
+            const int r = i / n, c = i % n;
+            double s = 0.0;
+            for (int k = 0; k < n; ++k) s += V[k * n + r] * Tm[k * n + c];
+            A[i] = s;
+        }
+        __syncthreads();
+        for (int i = tid; i < nn; i += NT) {              // symmetrise through T
+            const int r = i / n, c = i % n;
+            Tm[i] = 0.5 * (A[r * n + c] + A[c * n + r]);
+        }
+        __syncthreads();
+        for (int i = tid; i < nn; i += NT) A[i] = Tm[i];
+        __syncthreads();
+    }
+    for (int sweep = 0; sweep < 40; ++sweep) {
+        double off = 0.0, dg = 0.0;
+        for (int i = tid; i < nn; i += NT) {
+            const int r = i / n, c = i % n;
+            const double a = A[i];
+            if (r == c) dg += a * a; else off += a * a;
+        }
+        ro[tid] = off; rd[tid] = dg;
+        __syncthreads();
+        for (int s = NT / 2; s >= 1; s >>= 1) {
+            if (tid < s) { ro[tid] += ro[tid + s]; rd[tid] += rd[tid + s]; }
+            __syncthreads();
+        }
+        const bool done = ro[0] <= NUC_TOL * rd[0] || rd[0] == 0.0;
+        __syncthreads();
+        if (done) break;
+        for (int round = 0; round < n - 1; ++round) {
+            if (tid < np) {
+                int p, q;
+                if (tid == 0) { p = n - 1; q = round; }
+                else { p = (round + tid) % (n - 1); q = (round - tid + (n - 1)) % (n - 1); }
+                if (p > q) { const int t = p; p = q; q = t; }
+                const double app = A[p * n + p], aqq = A[q * n + q], apq = A[p * n + q];
+                double c = 1.0, s = 0.0;
+                if (fabs(apq) > 1e-300) {
+                    const double tau = (aqq - app) / (2.0 * apq);
+                    const double t = (tau >= 0 ? 1.0 : -1.0) / (fabs(tau) + sqrt(1.0 + tau * tau));
+                    c = 1.0 / sqrt(1.0 + t * t);
+                    s = t * c;
+                }
+                cs[tid] = c; cs[tid + HB] = s; pq[tid] = p; pq[tid + HB] = q;
+            }
+            __syncthreads();
+            for (int b = tid; b < np * np; b += NT) {          // A <- J^T A J, one 2x2 block (pair P, pair Q) at a time, out of place
+                const int P = b / np, Q = b % np;
+                const int bp0 = pq[P], bp1 = pq[P + HB], bq0 = pq[Q], bq1 = pq[Q + HB];
+                const double cp = cs[P], sp = cs[P + HB], cq = cs[Q], sq = cs[Q + HB];
+                const int i00 = bp0 * n + bq0, i01 = bp0 * n + bq1, i10 = bp1 * n + bq0, i11 = bp1 * n + bq1;
+                const double a00 = A[i00], a01 = A[i01], a10 = A[i10], a11 = A[i11];
+                const double r00 = cp * a00 - sp * a10, r01 = cp * a01 - sp * a11;
+                const double r10 = sp * a00 + cp * a10, r11 = sp * a01 + cp * a11;
+                Tm[i00] = cq * r00 - sq * r01; Tm[i01] = sq * r00 + cq * r01;
+                Tm[i10] = cq * r10 - sq * r11; Tm[i11] = sq * r10 + cq * r11;
+            }
+            for (int i = tid; i < np * n; i += NT) {           // V <- V J (columns; disjoint pairs, in place)
+                const int k = i / n, r = i % n;
+                const double c = cs[k], s = cs[k + HB];
+                const int p = pq[k], q = pq[k + HB];
+                const double vp = V[r * n + p], vq = V[r * n + q];
+                V[r * n + p] = c * vp - s * vq; V[r * n + q] = s * vp + c * vq;
+            }
+            __syncthreads();
+            { double* t = A; A = Tm; Tm = t; }                 // every entry belongs to exactly one block: the scratch image is complete
+        }
+    }
+    int keff = kloss < Z ? kloss : Z;
+    if (nrows < keff) keff = nrows;
+    for (int i = tid; i < Z; i += NT) {
+        const double w = A[i * n + i];
+        int rank = 0;
+        for (int j = 0; j < Z; ++j) {
+            const double wj = A[j * n + j];
+            rank += (wj > w) || (wj == w && j < i);
+        }
+        wsel[i] = (rank < keff && w > 0.0) ? sqrt(w) : 0.0;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        double s = 0.0;
+        for (int j = 0; j < Z; ++j) s += wsel[j];
+        loss_out[0] = (float)(lmbda * s);
+    }
+    if (Minv) {
+        for (int i = tid; i < Z * Z; i += NT) {
+            const int a = i / Z, b = i % Z;
+            double s = 0.0;
+            for (int j = 0; j < Z; ++j) {
+                const double sv = wsel[j];
+                if (sv > 0.0) s += V[a * n + j] * V[b * n + j] / sv;
+            }
+            Minv[i] = (float)((double)gscale * (double)lmbda / (double)bsize * s);
+        }
+    }
+}
+
+// doubles of state `vame_nuclear_f32` needs for a latent width: Z'^2 (optional warm start) up to Z = 64, 3 Z'^2 (required) above
+extern "C" int64_t vame_nuclear_state_doubles(int Z) {
+    const int64_t n = Z + (Z & 1);
+    return Z <= NUC_MAXZ ? n * n : 3 * n * n;
+}
+
 extern "C" int vame_nuclear_f32(const float* G, int Z, int kloss, int nrows, float lmbda, float bsize, float gscale,
                                 float* loss_out, float* Minv, double* vstate, void* stream) {
     VAME_CHECK_ARG(G && loss_out, VAME_E_BADARG, "nuclear: null pointer");
-    VAME_CHECK_ARG(Z >= 1 && Z <= NUC_MAXZ && kloss >= 1 && nrows >= 1 && bsize > 0, VAME_E_SHAPE, "nuclear: Z=%d must be in 1..%d",
-                   Z, NUC_MAXZ);
-    hipLaunchKernelGGL(nuclear_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, G, Z, kloss, nrows, lmbda, bsize, gscale,
-                       loss_out, Minv, vstate);
+    VAME_CHECK_ARG(Z >= 1 && Z <= NUCB_MAXZ && kloss >= 1 && nrows >= 1 && bsize > 0, VAME_E_SHAPE, "nuclear: Z=%d must be in 1..%d",
+                   Z, NUCB_MAXZ);
+    if (Z <= NUC_MAXZ) {
+        hipLaunchKernelGGL(nuclear_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, G, Z, kloss, nrows, lmbda, bsize, gscale,
+                           loss_out, Minv, vstate);
+    } else {
+        VAME_CHECK_ARG(vstate, VAME_E_BADARG, "nuclear: Z=%d > %d needs the state buffer (vame_nuclear_state_doubles)", Z, NUC_MAXZ);
+        hipLaunchKernelGGL(nuclear_big_kernel, dim3(1), dim3(NUCB_THREADS), 0, (hipStream_t)stream, G, Z, kloss, nrows, lmbda, bsize,
+                           gscale, loss_out, Minv, vstate);
+    }
     VAME_LAUNCH_CHECK("nuclear");
     return VAME_OK;
 }

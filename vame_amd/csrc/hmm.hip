@@ -176,29 +176,40 @@ __global__ __launch_bounds__(64) void hmm_scan_kernel(HmmChunking c, const doubl
     const int j = threadIdx.x;
     if (j < KP) cur[j] = j < c.K ? init[j] : (MAXPLUS ? -INFINITY : 0.0);
     __syncthreads();
+    // the chain is latency-bound (one dependent K x K product per chunk): the next chunk's operator column and scales are
+    // fetched into registers while the current one is applied
+    double pcol[KP], srow[KP];
+    auto fetch = [&](int64_t n) {
+        const int64_t ch = BACKWARD ? c.nchunks - 1 - n : n;
+        const double* p = P + ch * KP * KP;
+        const double* s = S + ch * KP;
+#pragma unroll
+        for (int i = 0; i < KP; ++i) { pcol[i] = (j < KP && i < c.K) ? p[i * KP + j] : 0.0; srow[i] = i < c.K ? s[i] : -INFINITY; }
+    };
+    fetch(0);
     for (int64_t n = 0; n < c.nchunks; ++n) {
         const int64_t ch = BACKWARD ? c.nchunks - 1 - n : n;
         if (j < KP) enter[ch * KP + j] = cur[j];
-        const double* p = P + ch * KP * KP;
-        const double* s = S + ch * KP;
+        double pc[KP], sr[KP];
+#pragma unroll
+        for (int i = 0; i < KP; ++i) { pc[i] = pcol[i]; sr[i] = srow[i]; }
+        if (n + 1 < c.nchunks) fetch(n + 1);
         double acc = MAXPLUS ? -INFINITY : 0.0;
         if (j < c.K) {
             if (MAXPLUS) {
-                for (int i = 0; i < c.K; ++i) acc = fmax(acc, cur[i] + p[i * KP + j]);
-            } else if (!BACKWARD) {
-                double smax = -INFINITY;
-                for (int i = 0; i < c.K; ++i)
-                    if (cur[i] > 0.0) smax = fmax(smax, s[i]);
-                for (int i = 0; i < c.K; ++i)
-                    if (cur[i] > 0.0 && s[i] > -INFINITY) acc += cur[i] * exp(s[i] - smax) * p[i * KP + j];
+#pragma unroll
+                for (int i = 0; i < KP; ++i)
+                    if (i < c.K) acc = fmax(acc, cur[i] + pc[i]);
             } else {
-                // backward operator acts on columns: u_enter_prev[i] = sum_j O[i][j] u[j]; pass 1 propagated unit vector j backwards,
-                // i.e. stored column j of O as its "row": O[i][j] = exp(S[j]) * P[j][i]
+                // forward: row vector times operator; backward: pass 1 propagated unit vector q backwards, i.e. stored column q of the
+                // chunk's operator O as its "row" (O[i][q] = exp(S[q]) P[q][i]), so the same sum applies with i <-> q
                 double smax = -INFINITY;
-                for (int q = 0; q < c.K; ++q)
-                    if (cur[q] > 0.0) smax = fmax(smax, s[q]);
-                for (int q = 0; q < c.K; ++q)
-                    if (cur[q] > 0.0 && s[q] > -INFINITY) acc += cur[q] * exp(s[q] - smax) * p[q * KP + j];
+#pragma unroll
+                for (int i = 0; i < KP; ++i)
+                    if (i < c.K && cur[i] > 0.0) smax = fmax(smax, sr[i]);
+#pragma unroll
+                for (int i = 0; i < KP; ++i)
+                    if (i < c.K && cur[i] > 0.0 && sr[i] > -INFINITY) acc += cur[i] * exp(sr[i] - smax) * pc[i];
             }
         }
         if (j < KP) nxt[j] = acc;

@@ -561,7 +561,7 @@ class VAEEngine:
         ws = self.ws.get("splitk_gram", sk * Z * Z, self.dev) if sk > 1 else None
         ops.gemm(Z, Z, B, Operand(z, Z), 1, Operand(z, Z), 1, G, Z, splitk=sk, ws=ws)
         if self._nuc_state is None:
-            self._nuc_state = torch.zeros(((Z + 1) // 2 * 2) ** 2, device=self.dev, dtype=torch.float64)
+            self._nuc_state = torch.zeros(ops.nuclear_state_doubles(Z), device=self.dev, dtype=torch.float64)
         ops.nuclear(G, Z, kloss, B, klmbda, bsize, self.buf("losses", 8), LOSS_KMEANS, self.buf("Minv", Z, Z), gscale=kl_weight,
                     vstate=self._nuc_state)
 

@@ -282,9 +282,16 @@ def mse_fwd_bwd(pred, target, tgt_off, tgt_row, B, TF, gscale, dpred, loss_out, 
     _lib.check(rc, "vame_mse_fwd_bwd_f32")
 
 
+def nuclear_state_doubles(Z):
+    return int(_lib.lib().vame_nuclear_state_doubles(int(Z)))
+
+
 def nuclear(G, Z, kloss, nrows, lmbda, bsize, loss_out, loss_off, Minv, gscale=1.0, vstate=None):
+    need = nuclear_state_doubles(Z)
+    if vstate is None and Z > 64:
+        vstate = torch.zeros(need, device=G.device, dtype=torch.float64)         # cold start: no state carried between calls
     if vstate is not None:
-        assert vstate.dtype == torch.float64 and vstate.numel() >= ((Z + 1) // 2 * 2) ** 2
+        assert vstate.dtype == torch.float64 and vstate.numel() >= need
     rc = _lib.lib().vame_nuclear_f32(_ptr(G), Z, kloss, nrows, float(lmbda), float(bsize), float(gscale),
                                      _ptr(loss_out, loss_off), _ptr(Minv), vstate.data_ptr() if vstate is not None else None,
                                      _stream())
