@@ -46,6 +46,45 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 #define VAME_WAVE 64
 
+// ---- buffer-resource addressing: uniform 48-bit base + byte range in four scalar registers, a 32-bit per-lane byte offset,
+// a scalar byte offset and a <= 4095 B immediate.  Used where a kernel walks rows of a tile with compile-time strides: the flat
+// (64-bit per-lane pointer) form makes hipcc materialise one address pair per row and spill them.  Out-of-range lanes load 0 and
+// their stores are dropped, which is how ragged tiles and absent (null, 0-byte) operands are handled without branches.
+// `soff` must be wave-uniform.  A range covers at most 4 GiB - 1: rebase per tile.
+#ifdef VAME_EMU
+struct BufRange { const char* base; uint32_t bytes; };
+static inline BufRange buf_range(const void* base, uint64_t bytes) {
+    return BufRange{reinterpret_cast<const char*>(base), base ? (uint32_t)(bytes > 0xffffffffull ? 0xffffffffull : bytes) : 0u};
+}
+static inline float buf_load_f32(BufRange r, uint32_t voff, uint32_t soff) {
+    const uint64_t o = (uint64_t)voff + soff;
+    return o + 4 <= r.bytes ? *reinterpret_cast<const float*>(r.base + o) : 0.0f;
+}
+static inline float4 buf_load_f32x4(BufRange r, uint32_t voff, uint32_t soff) {
+    const uint64_t o = (uint64_t)voff + soff;
+    return o + 16 <= r.bytes ? *reinterpret_cast<const float4*>(r.base + o) : float4{0.f, 0.f, 0.f, 0.f};
+}
+static inline void buf_store_f32(BufRange r, uint32_t voff, uint32_t soff, float v) {
+    const uint64_t o = (uint64_t)voff + soff;
+    if (o + 4 <= r.bytes) *reinterpret_cast<float*>(const_cast<char*>(r.base) + o) = v;
+}
+#else
+typedef __amdgpu_buffer_rsrc_t BufRange;
+__device__ __forceinline__ BufRange buf_range(const void* base, uint64_t bytes) {
+    const uint32_t n = base ? (uint32_t)(bytes > 0xffffffffull ? 0xffffffffull : bytes) : 0u;
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)n, 0x00020000);      // gfx9 raw buffer, 32-bit data format
+}
+__device__ __forceinline__ float buf_load_f32(BufRange r, uint32_t voff, uint32_t soff) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, (int)soff, 0));
+}
+__device__ __forceinline__ float4 buf_load_f32x4(BufRange r, uint32_t voff, uint32_t soff) {
+    return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 0));
+}
+__device__ __forceinline__ void buf_store_f32(BufRange r, uint32_t voff, uint32_t soff, float v) {
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, (int)voff, (int)soff, 0);
+}
+#endif
+
 // ---- 32x32 MFMA accumulator fragment (C/D) layout on gfx950:
 //   lane l holds column (l & 31); register r holds row  (r&3) + 8*(r>>2) + 4*(l>>5)
 __device__ __forceinline__ int frag_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
