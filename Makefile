@@ -45,8 +45,9 @@ build/probe/%.o: vame_amd/csrc/%.hip $(HDR)
 	$(HIPCC) $(HIPFLAGS) -DVAME_PROBE -c -o $@ $<
 
 probe: $(foreach n,$(NAMES),build/probe/$(n).o) tools/probe_gemm.hip
-	$(HIPCC) --offload-arch=gfx950 -O3 -std=c++17 -DVAME_PROBE -Wno-unused-value -Wno-unused-result -o tools/probe_gemm tools/probe_gemm.hip build/probe/elementwise.o
 	$(HIPCC) --offload-arch=gfx950 -shared -fPIC -o tools/libvame_hip_probe.so $(foreach n,$(NAMES),build/probe/$(n).o)
+	$(HIPCC) --offload-arch=gfx950 -O3 -std=c++17 -DVAME_PROBE -Wno-unused-value -Wno-unused-result -c -o build/probe/probe_gemm_main.o tools/probe_gemm.hip
+	$(HIPCC) --offload-arch=gfx950 -o tools/probe_gemm build/probe/probe_gemm_main.o build/probe/elementwise.o
 
 clean:
 	rm -rf build vame_amd/libvame_hip.so tests/emu/libvame_emu.so tools/libvame_hip_ab.so tools/libvame_hip_probe.so tools/probe_gemm

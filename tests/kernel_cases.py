@@ -136,6 +136,9 @@ def _pack(dev, W_hh, b_ih, b_hh, H):
     return wpf, wpb, bgi, bhn
 
 
+FORCE_WIDE = False           # set by check_gru_wide_small: the two-blocks-per-wave kernels at H <= 256
+
+
 def run_gru_fwd(dev, H, B, T, seed=0, coop=None, coop_chunks=None):
     """Two streams (forward + reverse dir, with h0) in one launch; returns everything needed for bwd.
     coop: an ops.CoopState -> the column-split small-batch kernel instead of the batch-tile-persistent one."""
@@ -162,7 +165,7 @@ def run_gru_fwd(dev, H, B, T, seed=0, coop=None, coop_chunks=None):
     if coop is not None:
         for chunk in (coop_chunks or [(0, 0)]):
             ops.gru_coop_fwd(rows, B, H, coop, rows=chunk)
-    elif H > 256:
+    elif H > 256 or FORCE_WIDE:
         ops.gru_wide_fwd(rows, B, H)
     else:
         ops.gru_seq_fwd(rows, B, H)
@@ -232,6 +235,17 @@ def check_gru_wide(dev, H, B, T):
             np.testing.assert_allclose(N_(dh), dd * u, atol=3e-5)
 
 
+def check_gru_wide_small(dev, H, B, T):
+    """The wide kernels are also instantiated for H = 128, 192, 256 (same contract as the gru_seq kernels there)."""
+    global FORCE_WIDE
+    FORCE_WIDE = True
+    try:
+        check_gru_fwd(dev, H, B, T)
+        check_gru_bwd(dev, H, B, T)
+    finally:
+        FORCE_WIDE = False
+
+
 def check_gru_fwd_fused(dev, H, B, T, I=24):
     """Fused input projection (encoder layer 0 mode): x (B,L,F) windows are read directly, no gi tensor."""
     rng = np.random.default_rng(11)
@@ -278,7 +292,7 @@ def _run_gru_bwd(dev, H, B, T, st, Y, dYt, dhNt, coop=None, coop_chunks=None):
     if coop is not None:
         for chunk in (coop_chunks or [(0, 0)]):
             ops.gru_coop_bwd(rows, B, H, coop, rows=chunk)
-    elif H > 256:
+    elif H > 256 or FORCE_WIDE:
         ops.gru_wide_bwd(rows, B, H)
     else:
         ops.gru_seq_bwd(rows, B, H)

@@ -14,6 +14,20 @@ ACC = [["%[ar0]", "%[au0]", "%[nh0]"], ["%[ar1]", "%[au1]", "%[nh1]"]]      # [b
 CHUNK = 3 * 64 * 16                 # bytes of one chunk of one block: 3 gates x 64 lanes x float4
 
 
+def preamble(q0, q1, lds, t0, t1):
+    """Everything per-lane is derived inside the statement from the lane id, so that the C++ side keeps no vector register alive for the
+    loop between steps (hipcc spilled exactly those and reloaded them behind a vmcnt(0)): fragment pointers v[q:q+1] = uniform 64-bit block
+    base (two scalar operands each) + lane * 16; A-operand row address = scalar LDS base + (lane & 31) * row bytes + (lane >> 5) * 16.
+    t0, t1: scratch registers that the loop overwrites later."""
+    out = ["s_nop 4", f"v_mbcnt_lo_u32_b32 v{t0}, -1, 0", f"v_mbcnt_hi_u32_b32 v{t0}, -1, v{t0}", f"v_lshlrev_b32_e32 v{t1}, 4, v{t0}"]
+    for q, name in ((q0, "b0"), (q1, "b1")):
+        out += [f"v_mov_b32_e32 v{q + 1}, %[{name}hi]", f"v_add_co_u32_e32 v{q}, vcc, %[{name}lo], v{t1}",
+                f"v_addc_co_u32_e32 v{q + 1}, vcc, 0, v{q + 1}, vcc"]
+    out += [f"v_and_b32_e32 v{t1}, 31, v{t0}", f"v_lshrrev_b32_e32 v{t0}, 5, v{t0}", f"v_mul_u32_u24_e32 v{t1}, %[rowb], v{t1}",
+            f"v_lshl_add_u32 v{t0}, v{t0}, 4, v{t1}", f"v_add_u32_e32 v{lds}, %[ldsb], v{t0}", "s_nop 1"]
+    return out
+
+
 def loads(slot):
     out = []
     for cb, p in enumerate((P0, P1)):
@@ -87,8 +101,7 @@ def bwd_macro():
             out += advance()
         return out
 
-    ls = ["s_nop 4", f"v_mov_b32_e32 v{Q0}, %[p0lo]", f"v_mov_b32_e32 v{Q0 + 1}, %[p0hi]", f"v_mov_b32_e32 v{Q1}, %[p1lo]", f"v_mov_b32_e32 v{Q1 + 1}, %[p1hi]",
-          f"v_mov_b32_e32 v{L}, %[lds]", "s_nop 1"]
+    ls = preamble(Q0, Q1, L, Aq[0], Aq[0] + 1)
     for s_ in range(NS):
         ls += refill(s_)
     ls += advance()
@@ -96,9 +109,7 @@ def bwd_macro():
     return ls, list(range(192, 245))
 
 
-lines = ["s_nop 4",
-         f"v_mov_b32_e32 v{P0}, %[p0lo]", f"v_mov_b32_e32 v{P0 + 1}, %[p0hi]", f"v_mov_b32_e32 v{P1}, %[p1lo]", f"v_mov_b32_e32 v{P1 + 1}, %[p1hi]",
-         f"v_mov_b32_e32 v{LDS}, %[lds]", "s_nop 1"]
+lines = preamble(P0, P1, LDS, A[0], A[0] + 1)
 lines += loads(0) + loads(1)
 lines += ["1:"] + body(True) + ["s_sub_u32 %[n], %[n], 1", "s_cmp_lg_u32 %[n], 0", "s_cbranch_scc1 1b"]
 lines += body(False)

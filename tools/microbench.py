@@ -74,12 +74,17 @@ def bench_gru(H, B, T, nstreams, quiet=False, hook=None):
         hook("bwd")
     if not quiet:
         print(f"gru_bwd H={H} B={B} T={T} streams={nstreams}: {ms2*1e3:8.1f} us  {fl/ms2/1e9:7.1f} TF")
+    if H % 64 == 0 and H >= 128 and not quiet:        # the two-blocks-per-wave kernels on the same launch
+        ms3 = timeit(lambda: ops.gru_wide_fwd(rows_f, B, H))
+        ms4 = timeit(lambda: ops.gru_wide_bwd(rows_b, B, H))
+        print(f"wide_fwd H={H} B={B} T={T} streams={nstreams}: {ms3*1e3:8.1f} us  {fl/ms3/1e9:7.1f} TF")
+        print(f"wide_bwd H={H} B={B} T={T} streams={nstreams}: {ms4*1e3:8.1f} us  {fl/ms4/1e9:7.1f} TF")
     return ms * 1e3, ms2 * 1e3
 
 
 def ablate():
     """GRU kernel ablations; needs the tuning build: make ab && VAME_LIB=tools/libvame_hip_ab.so python tools/microbench.py 10 ablate"""
-    for var, masks in (("VAME_ABL_FWD", (0, 256, 0, 256)), ("VAME_ABL_BWD", (0, 128, 256, 384, 0, 128, 256, 384))):
+    for var, masks in (("VAME_ABL_FWD", (0, 256, 0, 256)), ("VAME_ABL_BWD", (0, 256, 1, 0, 256, 1))):
         for m in masks:
             os.environ[var] = str(m)
             print(f"--- {var}={m}")
@@ -209,6 +214,10 @@ if __name__ == "__main__":
         sys.exit(0)
     if len(sys.argv) > 2 and sys.argv[2] == "gemm_ab":
         gemm_ab()
+        sys.exit(0)
+    if len(sys.argv) > 2 and sys.argv[2] == "gru":
+        for (h, b, t, n) in ((256, 4096, 30, 2), (256, 4096, 30, 4), (256, 4096, 15, 2), (128, 4096, 30, 2), (512, 8192, 60, 2)):
+            bench_gru(h, b, t, n)
         sys.exit(0)
     if len(sys.argv) > 2 and sys.argv[2] == "ablate":
         ablate()

@@ -14,12 +14,12 @@ from vame_amd import _lib  # noqa: E402
 
 L = _lib._lib
 L.vame_probe_set_gru.argtypes = [ctypes.c_void_p]
-probe = torch.zeros((1 << 16) + (1 << 14) * 24, dtype=torch.int64, device="cuda")
+probe = torch.zeros((1 << 16) + (1 << 14) * 24 + (1 << 14) * 64, dtype=torch.int64, device="cuda")
 L.vame_probe_set_gru(probe.data_ptr())
 
 
-FWD_PHASES = ["loop-top", "mfma", "gates+h->lds", "stash-st", "barrier", "y-store", "", ""]
-BWD_PHASES = ["loop-top", "coef+lds", "barrier1", "dG-copy", "ld-issue", "mfma", "barrier2", ""]
+FWD_PHASES = ["loop-top", "mfma", "gates+h->lds", "stash-st", "barrier", "y-store", "", "loop-groups"]
+BWD_PHASES = ["loop-top", "coef+lds", "barrier1", "dG-copy", "ld-issue", "mfma", "barrier2", "loop-groups"]
 T_CUR = [30]
 
 
@@ -34,8 +34,14 @@ def report(tag, nwg):
     tot = ph[:, :8].sum()
     print("      MFMA-loop groups (cycles/step): " + " ".join(f"{ph[:, 8 + g].mean() / T_CUR[0]:.0f}" for g in range(16) if ph[:, 8 + g].sum() > 0), flush=True)
     names = FWD_PHASES if "fwd" in tag else BWD_PHASES
-    print("      wave-0 cycles per step: " + "  ".join(f"{n} {ph[:, i].mean() / T_CUR[0]:.0f}" for i, n in enumerate(names) if n)
+    print("      wave-0 cycles per step: " + "  ".join(f"{n} {ph[:, i].mean() / T_CUR[0]:.0f}" for i, n in enumerate(names[:7]) if n)
           + f"   (sum {tot / len(ph) / T_CUR[0]:.0f}; MFMA floor 2 waves x 384 x 64 = 49152)", flush=True)
+    pw = probe[(1 << 16) + (1 << 14) * 24:(1 << 16) + (1 << 14) * 24 + 64 * nwg].view(-1, 8, 8).cpu().numpy().astype("float64")
+    pw = pw[pw[:, 0, :].sum(1) > 0]
+    if len(pw):
+        for i, n in enumerate(names):
+            if n:
+                print(f"      per wave, {n:>12s}: " + " ".join(f"{pw[:, w_, i].mean() / T_CUR[0]:7.0f}" for w_ in range(8)), flush=True)
     probe.zero_()
 
 

@@ -33,6 +33,12 @@ extern "C" int vame_probe_set_gru(long long* p) { return (int)hipMemcpyToSymbol(
     if (threadIdx.x == 0 && g_gru_probe) {                                                                    \
         long long* o_ = g_gru_probe + (1 << 16) + (long long)blockIdx.x * 24;                                 \
         for (int i_ = 0; i_ < 24; ++i_) o_[i_] = pp_[i_];                                                     \
+    }                                                                                                         \
+    if ((threadIdx.x & 63) == 0 && g_gru_probe) {      /* every wave: its first 8 phase sums, after wave 0's region */ \
+        long long* o_ = g_gru_probe + (1 << 16) + (1 << 14) * 24 + ((long long)blockIdx.x * 8 + (threadIdx.x >> 6)) * 8; \
+        for (int i_ = 0; i_ < 7; ++i_) o_[i_] = pp_[i_];                                                      \
+        long long g_ = 0; for (int i_ = 8; i_ < 24; ++i_) g_ += pp_[i_];                                      \
+        o_[7] = g_;                                     /* the MFMA loop's chunk groups together */           \
     }
 #else
 #define GRU_PROBE_BEGIN()
@@ -284,8 +290,7 @@ __global__ __launch_bounds__(H / 32 * 64) void gru_seq_fwd_kernel(GruFwdParams P
         // first PD chunks of a step were requested before the previous step's epilogue (they do not depend on h)
 #pragma unroll 1
         for (int c0 = 0; c0 < KC; c0 += PD) {
-        // gi of the next step: requested half way through the MFMA loop (measured: 1 % better than at its start)
-        if (!XIN && c0 == KC / 2 / PD * PD && step + 1 < T && S.gi_t != 0) load_gi(S.reverse ? t - 1 : t + 1);
+        if ((ABL & 256) && !XIN && c0 == KC / 2 / PD * PD && step + 1 < T && S.gi_t != 0) load_gi(S.reverse ? t - 1 : t + 1);   // (ablation: the round-1 place)
 #pragma unroll
         for (int j = 0; j < PD; ++j) {
             const int c = c0 + j;
@@ -310,6 +315,10 @@ __global__ __launch_bounds__(H / 32 * 64) void gru_seq_fwd_kernel(GruFwdParams P
         }
         GRU_PHASE_DYN(8 + c0 / PD);
         }
+        // gi of the next step: requested AFTER the loop's last weight-fragment wait.  The ring waits are vmcnt(9) -- "at most nine
+        // younger operations outstanding" -- so 48 gi loads issued inside the loop turn the next such wait into a wait for the gi
+        // loads themselves (probe: 6500 of a step's 80000 cycles); from here their latency runs under the epilogue and the barrier.
+        if (!(ABL & 256) && !XIN && !skip_first && step + 1 < T && S.gi_t != 0) load_gi(S.reverse ? t - 1 : t + 1);
         GRU_PHASE(1);                 // input projection + recurrent MFMA loop
         float* hnext = &hs[cur ^ 1][lrow * LDH + col0 + li];
         f32x16 ust;
@@ -365,7 +374,7 @@ __global__ __launch_bounds__(H / 32 * 64) void gru_seq_fwd_kernel(GruFwdParams P
 }
 
 // ------------------------------------------------------------------------------------------- backward
-// ABL: 1 no dG stores, 2 no stash/dy loads (first step's reused), 16 W fragments not re-streamed, 32 no barriers
+// ABL: 1 no dG stores, 2 no stash/dy loads (first step's reused), 16 W fragments not re-streamed, 32 no barriers, 256 dG copy-out after the loop
 template <int H, int ABL = 0>
 __global__ __launch_bounds__(H / 32 * 64) void gru_seq_bwd_kernel(GruBwdParams P) {
     constexpr int NW = H / 32, K3 = 3 * H, LDG = 4 * H + 4, KC = K3 / 8;
@@ -429,6 +438,22 @@ __global__ __launch_bounds__(H / 32 * 64) void gru_seq_bwd_kernel(GruBwdParams P
     f32x4 wq[PD][2];
 #pragma unroll
     for (int c = 0; c < PD; ++c) { RING_LOAD(wq[c][0], wpt, (2 * c) * 64); RING_LOAD(wq[c][1], wpt, (2 * c + 1) * 64); }
+    // dG[b][t][da_r | da_z | dgi_n | dgh_n] leaves through LDS: 16 coalesced 16-byte stores per thread
+    auto dg_copy_out = [&](int t) {
+        float* dgt = dg_copy + (int64_t)t * 4 * H;
+        if (full) {
+#pragma unroll 4
+            for (int i = 0; i < 16; ++i)
+                *reinterpret_cast<float4*>(dgt + (int64_t)(2 * i) * T * 4 * H) =
+                    *reinterpret_cast<const float4*>((i < 8 ? gs_copy : gs_copy + 16 * LDG) + 2 * (i & 7) * LDG);
+        } else {
+#pragma unroll 4
+            for (int i = 0; i < 16; ++i)
+                if (crow + 2 * i < nvalid)
+                    *reinterpret_cast<float4*>(dgt + (int64_t)(2 * i) * T * 4 * H) =
+                        *reinterpret_cast<const float4*>((i < 8 ? gs_copy : gs_copy + 16 * LDG) + 2 * (i & 7) * LDG);
+        }
+    };
     GRU_PHASE_DECL();
     for (int step = 0; step < T; ++step) {
         const int fstep = T - 1 - step;
@@ -457,22 +482,9 @@ __global__ __launch_bounds__(H / 32 * 64) void gru_seq_bwd_kernel(GruBwdParams P
         GRU_PHASE(1);                 // coefficient math + LDS tile writes (incl. the wait for the stash loads)
         if (!(ABL & 32)) __syncthreads();
         GRU_PHASE(2);                 // barrier 1
-        if (!(ABL & 1)) {
-            // dG[b][t][da_r | da_z | dgi_n | dgh_n] leaves through LDS: 16 coalesced 16-byte stores per thread
-            float* dgt = dg_copy + (int64_t)t * 4 * H;
-            if (full) {
-#pragma unroll 4
-                for (int i = 0; i < 16; ++i)
-                    *reinterpret_cast<float4*>(dgt + (int64_t)(2 * i) * T * 4 * H) =
-                        *reinterpret_cast<const float4*>((i < 8 ? gs_copy : gs_copy + 16 * LDG) + 2 * (i & 7) * LDG);
-            } else {
-#pragma unroll 4
-                for (int i = 0; i < 16; ++i)
-                    if (crow + 2 * i < nvalid)
-                        *reinterpret_cast<float4*>(dgt + (int64_t)(2 * i) * T * 4 * H) =
-                            *reinterpret_cast<const float4*>((i < 8 ? gs_copy : gs_copy + 16 * LDG) + 2 * (i & 7) * LDG);
-            }
-        }
+        // dG copy-out: BEFORE the MFMA loop, which covers its stores (ablation 256 = after the loop, where the stores delay barrier 2:
+        // measured 2-3 % slower although they then no longer sit in front of the loop's weight-fragment loads in the in-order queue)
+        if (!(ABL & 1) && (!(ABL & 256) || (step + 1 == T && S.dh0 == nullptr))) dg_copy_out(t);
         GRU_PHASE(3);                 // dG copy-out
         if (!(ABL & 2) && (ABL & 128) && step + 1 < T) load_step(step + 1);      // (ablation: the old place, before the MFMA loop)
         GRU_PHASE(4);                 // next step's stash / dy loads (issue)
@@ -504,6 +516,7 @@ __global__ __launch_bounds__(H / 32 * 64) void gru_seq_bwd_kernel(GruBwdParams P
         // next step's stash / dy loads: issued AFTER the MFMA loop -- before it they sit in front of every weight-fragment load of the
         // loop in the in-order vmcnt queue (measured: 2-3 % slower); their latency overlaps barrier 2 and the other wave's loop tail
         if (!(ABL & 2) && !(ABL & 192) && step + 1 < T) load_step(step + 1);
+        if (!(ABL & 1) && (ABL & 256)) dg_copy_out(t);            // (gs is intact until barrier 2)
 #pragma unroll
         for (int r = 0; r < 16; ++r) dh[r] = acc0[r] + acc1[r];
         GRU_PHASE(5);                 // MFMA loop
@@ -540,7 +553,7 @@ static void launch_fwd(const GruFwdParams& P, hipStream_t st) {
     if (H == 256) switch (abl_env("VAME_ABL_FWD")) {      // profiling-only ablations, tuning build (make ab) only
         ABL_CASE(gru_seq_fwd_kernel, 256, 1, P, st) ABL_CASE(gru_seq_fwd_kernel, 256, 2, P, st) ABL_CASE(gru_seq_fwd_kernel, 256, 4, P, st)
         ABL_CASE(gru_seq_fwd_kernel, 256, 8, P, st) ABL_CASE(gru_seq_fwd_kernel, 256, 16, P, st) ABL_CASE(gru_seq_fwd_kernel, 256, 32, P, st)
-        ABL_CASE(gru_seq_fwd_kernel, 256, 7, P, st) ABL_CASE(gru_seq_fwd_kernel, 256, 63, P, st)
+        ABL_CASE(gru_seq_fwd_kernel, 256, 7, P, st) ABL_CASE(gru_seq_fwd_kernel, 256, 63, P, st) ABL_CASE(gru_seq_fwd_kernel, 256, 256, P, st)
         default: break;
     }
 #endif
@@ -553,7 +566,7 @@ static void launch_bwd(const GruBwdParams& P, hipStream_t st) {
     if (H == 256) switch (abl_env("VAME_ABL_BWD")) {
         ABL_CASE(gru_seq_bwd_kernel, 256, 1, P, st) ABL_CASE(gru_seq_bwd_kernel, 256, 2, P, st) ABL_CASE(gru_seq_bwd_kernel, 256, 3, P, st)
         ABL_CASE(gru_seq_bwd_kernel, 256, 16, P, st) ABL_CASE(gru_seq_bwd_kernel, 256, 32, P, st) ABL_CASE(gru_seq_bwd_kernel, 256, 51, P, st)
-        ABL_CASE(gru_seq_bwd_kernel, 256, 64, P, st) ABL_CASE(gru_seq_bwd_kernel, 256, 128, P, st)
+        ABL_CASE(gru_seq_bwd_kernel, 256, 64, P, st) ABL_CASE(gru_seq_bwd_kernel, 256, 128, P, st) ABL_CASE(gru_seq_bwd_kernel, 256, 256, P, st)
         default: break;
     }
 #endif
