@@ -60,6 +60,14 @@ int vame_gemm_group_f32(int count, int M, int N, int K, const float* const* A, i
  *   wp_bwd (3H*H, fragment order for dgh W_hh), bias_gi (3H) = b_ih + [b_hr, b_hz, 0], b_hn (H). */
 int vame_gru_pack_f32(const float* W_hh, const float* b_ih, const float* b_hh, int H,
                       float* wp_fwd, float* wp_bwd, float* bias_gi, float* b_hn, void* stream);
+/* The same for up to VAME_GRU_PACK_MAX layer-directions in one launch (all GRUs of the model after an optimizer step):
+ * items = n x VAME_GRU_PACK_FIELDS int64 on the HOST.  GP_W_IH != 0 also packs that item's layer-0 input projection
+ * (vame_gru_pack_x_f32: W_ih (3H,F), F <= 32 -> GP_WPX). */
+#define VAME_GRU_PACK_MAX 16
+enum vame_gru_pack_field { GP_W_HH = 0, GP_B_IH, GP_B_HH, GP_H, GP_WP_FWD, GP_WP_BWD, GP_BIAS_GI, GP_B_HN, GP_W_IH, GP_F, GP_WPX,
+                           VAME_GRU_PACK_FIELDS };
+int vame_gru_pack_batch_f32(const int64_t* items, int n, void* stream);
+
 
 /* GRU sequence forward for up to 8 independent (layer,direction) streams in one launch.
  * desc = nstreams x VAME_GRU_FWD_FIELDS int64 (see vame_gru_fwd_field).  Cell = torch.nn.GRU

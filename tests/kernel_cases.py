@@ -20,7 +20,7 @@ def check_gemm_group(dev, small=True):
     for bit when the split-K factor is the same (same per-tile k order, same partial-sum order), incl. the column gap of the
     dW_hh form and accumulation into C."""
     rng = np.random.default_rng(3)
-    for (M, Nn, K, akm, bkm, sk, n, gap, acc) in ([(96, 136, 512, 1, 1, 8, 3, 0, False), (70, 72, 512, 0, 1, 8, 2, 0, True), (64, 100, 640, 1, 1, 16, 5, 32, False)]
+    for (M, Nn, K, akm, bkm, sk, n, gap, acc) in ([(96, 136, 512, 1, 1, 8, 3, 0, False), (70, 72, 512, 0, 1, 8, 2, 0, True), (64, 100, 640, 1, 1, 16, 5, 32, False), (200, 30, 512, 1, 1, 8, 4, 0, False), (96, 48, 512, 1, 1, 8, 2, 0, True)]
                                                     + ([] if small else [(768, 256, 8192, 1, 1, 32, 6, 256, False)])):
         Mw = M + (gap or 0)                                    # stored width of a k-major A with a skipped column block
         As = [rng.standard_normal((K, Mw) if akm else (M, K)).astype(np.float32) for _ in range(n)]

@@ -635,7 +635,7 @@ extern "C" int vame_gemm_group_f32(int count, int M, int N, int K, const float* 
                                    int64_t b_seg_stride, float* const* C, int64_t ldc, int accumulate, int splitk, float* ws,
                                    int a_gap_at, int a_gap, void* stream) {
     VAME_CHECK_ARG(count >= 1 && count <= 8 && A && B && C && ws, VAME_E_BADARG, "gemm_group: count=%d (1..8) / null table", count);
-    VAME_CHECK_ARG(M >= 1 && N > 64 && K >= 1, VAME_E_SHAPE, "gemm_group: M=%d N=%d K=%d (needs N > 64)", M, N, K);
+    VAME_CHECK_ARG(M >= 1 && N >= 1 && K >= 1, VAME_E_SHAPE, "gemm_group: M=%d N=%d K=%d", M, N, K);
     VAME_CHECK_ARG(!(a_kmajor && !b_kmajor), VAME_E_UNSUPPORTED, "gemm_group: A k-major with B n-major is not provided");
     VAME_CHECK_ARG(a_gap == 0 || (a_kmajor && a_gap_at % 4 == 0 && a_gap % 4 == 0), VAME_E_BADARG,
                    "gemm_group: a column gap needs a k-major A and multiples of 4");
@@ -656,7 +656,10 @@ extern "C" int vame_gemm_group_f32(int count, int M, int N, int K, const float* 
     p.splitk = (int)cdiv64(K, p.kper);
     VAME_CHECK_ARG(p.splitk >= 8, VAME_E_SHAPE, "gemm_group: split-K %d < 8 (grouping is for large-K contractions)", p.splitk);
     hipStream_t st = (hipStream_t)stream;
-    const int rc = launch_gemm<128, 128, 2, 2>(p, a_kmajor, b_kmajor, st);
+    // same tile choice as vame_gemm_f32 for the output width (narrow outputs: the dW_ih of GRUs fed by the latent vector -- tiny
+    // problems that are grouped for their launch count, not for occupancy)
+    const int rc = N > 64 ? launch_gemm<128, 128, 2, 2>(p, a_kmajor, b_kmajor, st)
+                 : N > 32 ? launch_gemm<128, 64, 4, 1>(p, a_kmajor, b_kmajor, st) : launch_gemm<128, 32, 4, 1>(p, a_kmajor, b_kmajor, st);
     VAME_CHECK_ARG(rc == VAME_OK, rc, "gemm_group: unsupported layout");
     VAME_LAUNCH_CHECK("gemm_group");
     GemmGroupOut out;

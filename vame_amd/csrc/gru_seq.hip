@@ -74,10 +74,9 @@ static int grid_blocks(int nstreams, int ntiles) {
 // ------------------------------------------------------------------------------------------- pack
 // wp_fwd[(((w*(H/8)+c)*3+g)*64+l)*4+e] = W_hh[(g*H+32w+(l&31))*H + 8c+4(l>>5)+e]
 // wp_bwd[((w*(3H/8)+c)*64+l)*4+e]       = W_hh[(8c+4(l>>5)+e)*H + 32w+(l&31)]
-__global__ __launch_bounds__(256) void gru_pack_kernel(const float* __restrict__ W, const float* __restrict__ b_ih,
-                                                       const float* __restrict__ b_hh, int H, float* __restrict__ wpf,
-                                                       float* __restrict__ wpb, float* __restrict__ bias_gi,
-                                                       float* __restrict__ bhn) {
+__device__ __forceinline__ void gru_pack_body(const float* __restrict__ W, const float* __restrict__ b_ih,
+                                              const float* __restrict__ b_hh, int H, float* __restrict__ wpf,
+                                              float* __restrict__ wpb, float* __restrict__ bias_gi, float* __restrict__ bhn) {
     const int64_t n = (int64_t)3 * H * H;
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         {
@@ -97,6 +96,12 @@ __global__ __launch_bounds__(256) void gru_pack_kernel(const float* __restrict__
         if (i < H) bhn[i] = b_hh[2 * H + i];
     }
 }
+__global__ __launch_bounds__(256) void gru_pack_kernel(const float* __restrict__ W, const float* __restrict__ b_ih,
+                                                       const float* __restrict__ b_hh, int H, float* __restrict__ wpf,
+                                                       float* __restrict__ wpb, float* __restrict__ bias_gi,
+                                                       float* __restrict__ bhn) {
+    gru_pack_body(W, b_ih, b_hh, H, wpf, wpb, bias_gi, bhn);
+}
 
 extern "C" int vame_gru_pack_f32(const float* W_hh, const float* b_ih, const float* b_hh, int H, float* wp_fwd,
                                  float* wp_bwd, float* bias_gi, float* b_hn, void* stream) {
@@ -112,7 +117,7 @@ extern "C" int vame_gru_pack_f32(const float* W_hh, const float* b_ih, const flo
 
 // wpx[(((w*4+c)*3+g)*64+l)*4+e] = W_ih[(g*H+32w+(l&31))*F + k], k = 8c+4(l>>5)+e (< F, else 0): the K = 32 (zero padded)
 // input projection of a layer whose input has F <= 32 features, in the same B-fragment order as wp_fwd
-__global__ __launch_bounds__(256) void gru_pack_x_kernel(const float* __restrict__ W, int F, int H, float* __restrict__ wpx) {
+__device__ __forceinline__ void gru_pack_x_body(const float* __restrict__ W, int F, int H, float* __restrict__ wpx) {
     const int64_t n = (int64_t)3 * H * 32;
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         const int e = i & 3, l = (i >> 2) & 63;
@@ -122,6 +127,42 @@ __global__ __launch_bounds__(256) void gru_pack_x_kernel(const float* __restrict
         const int k = 8 * c + 4 * (l >> 5) + e;
         wpx[i] = k < F ? W[(int64_t)(g * H + 32 * w + (l & 31)) * F + k] : 0.0f;
     }
+}
+__global__ __launch_bounds__(256) void gru_pack_x_kernel(const float* __restrict__ W, int F, int H, float* __restrict__ wpx) {
+    gru_pack_x_body(W, F, H, wpx);
+}
+
+// All (layer, direction) packs of a model in ONE launch (the weights change every optimizer step: eight 3-us kernels and their
+// dispatch gaps otherwise open every train step).  blockIdx.y = item.
+struct GruPackItem { const float* W_hh; const float* b_ih; const float* b_hh; int H; float* wpf; float* wpb; float* bias_gi; float* bhn;
+                     const float* W_ih; int F; float* wpx; };
+struct GruPackBatch { GruPackItem it[VAME_GRU_PACK_MAX]; };
+__global__ __launch_bounds__(256) void gru_pack_batch_kernel(GruPackBatch P) {
+    const GruPackItem& I = P.it[blockIdx.y];
+    gru_pack_body(I.W_hh, I.b_ih, I.b_hh, I.H, I.wpf, I.wpb, I.bias_gi, I.bhn);
+    if (I.W_ih) gru_pack_x_body(I.W_ih, I.F, I.H, I.wpx);
+}
+
+extern "C" int vame_gru_pack_batch_f32(const int64_t* items, int n, void* stream) {
+    VAME_CHECK_ARG(items && n >= 1 && n <= VAME_GRU_PACK_MAX, VAME_E_BADARG, "gru_pack_batch: n=%d not in 1..%d", n, VAME_GRU_PACK_MAX);
+    GruPackBatch P;
+    int64_t most = 0;
+    for (int i = 0; i < n; ++i) {
+        const int64_t* r = items + (int64_t)i * VAME_GRU_PACK_FIELDS;
+        GruPackItem& I = P.it[i];
+        I.W_hh = (const float*)r[GP_W_HH]; I.b_ih = (const float*)r[GP_B_IH]; I.b_hh = (const float*)r[GP_B_HH]; I.H = (int)r[GP_H];
+        I.wpf = (float*)r[GP_WP_FWD]; I.wpb = (float*)r[GP_WP_BWD]; I.bias_gi = (float*)r[GP_BIAS_GI]; I.bhn = (float*)r[GP_B_HN];
+        I.W_ih = (const float*)r[GP_W_IH]; I.F = (int)r[GP_F]; I.wpx = (float*)r[GP_WPX];
+        VAME_CHECK_ARG(I.H >= 32 && I.H % 32 == 0, VAME_E_SHAPE, "gru_pack_batch: item %d: H=%d must be a multiple of 32", i, I.H);
+        VAME_CHECK_ARG(I.W_hh && I.b_ih && I.b_hh && I.wpf && I.wpb && I.bias_gi && I.bhn, VAME_E_BADARG, "gru_pack_batch: item %d: null pointer", i);
+        VAME_CHECK_ARG(!I.W_ih || (I.wpx && I.F >= 1 && I.F <= 32), VAME_E_SHAPE, "gru_pack_batch: item %d: fused input needs wpx and F <= 32 (F=%d)", i, I.F);
+        const int64_t e = (int64_t)3 * I.H * I.H;
+        most = e > most ? e : most;
+    }
+    const int blocks = (int)(cdiv64(most, 256) < 256 ? cdiv64(most, 256) : 256);
+    hipLaunchKernelGGL(gru_pack_batch_kernel, dim3(blocks, n), dim3(256), 0, (hipStream_t)stream, P);
+    VAME_LAUNCH_CHECK("gru_pack_batch");
+    return VAME_OK;
 }
 
 extern "C" int vame_gru_pack_x_f32(const float* W_ih, int F, int H, float* wpx, void* stream) {

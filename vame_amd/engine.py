@@ -165,12 +165,8 @@ class VAEEngine:
     def repack(self):
         if self.packed_version == self.version:
             return
-        t = self.table
-        for d in self._all_dirs():
-            ops.gru_pack(self._pv(d.w_hh), self._pv(d.b_ih), self._pv(d.b_hh), d.H, d.wp_fwd, d.wp_bwd, d.bias_gi, d.b_hn)
-        for d in self.enc[0]:
-            if d.wp_x is not None:
-                ops.gru_pack_x(self._pv(d.w_ih), d.I, d.H, d.wp_x)
+        ops.gru_pack_batch([(self._pv(d.w_hh), self._pv(d.b_ih), self._pv(d.b_hh), d.H, d.wp_fwd, d.wp_bwd, d.bias_gi, d.b_hn,
+                             self._pv(d.w_ih) if d.wp_x is not None else None, d.I, d.wp_x) for d in self._all_dirs()])
         self.packed_version = self.version
 
     def _pv(self, name):
@@ -199,7 +195,7 @@ class VAEEngine:
         groups, rest = {}, []
         for j in jobs:
             M, N, K, A, Bop, gname, row_off, gap_at, gap = j
-            if N > 64 and K >= 8 * 256 and row_off == 0:
+            if M > 32 and K >= 8 * 256 and row_off == 0:          # (M <= 32: the 24/30-row heads keep their own skinny-M tile)
                 key = (M, N, K, A.ld, A.seg, A.seg_stride, Bop.ld, Bop.seg, Bop.seg_stride, gap_at, gap)
                 groups.setdefault(key, []).append(j)
             else:
@@ -214,7 +210,7 @@ class VAEEngine:
                 if len(part) < 2:
                     rest += part
                     continue
-                tiles = ((M + 127) // 128) * ((N + 127) // 128) * len(part)
+                tiles = ((M + 127) // 128) * ((N + 127) // 128 if N > 64 else 1) * len(part)
                 # whole rounds of 3 workgroups per CU: the smallest multiple of 8 with >= 2 rounds (dynamic balancing between
                 # rounds), capped so that a workgroup keeps >= 8 k-tiles
                 cands = [k for k in range(8, 129, 8) if k * 8 * 32 <= K]

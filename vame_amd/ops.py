@@ -1,5 +1,7 @@
 """Thin tensor-level wrappers over the C ABI (include/vame_hip.h).  PyTorch is plumbing here:
 device memory, the current HIP stream and nothing else."""
+import ctypes
+
 import torch
 
 from . import _lib
@@ -89,6 +91,24 @@ def gru_pack(W_hh, b_ih, b_hh, H, wp_fwd, wp_bwd, bias_gi, b_hn):
     rc = _lib.lib().vame_gru_pack_f32(_ptr(W_hh), _ptr(b_ih), _ptr(b_hh), H, _ptr(wp_fwd), _ptr(wp_bwd), _ptr(bias_gi),
                                       _ptr(b_hn), _stream())
     _lib.check(rc, "vame_gru_pack_f32")
+
+
+GP = dict(W_HH=0, B_IH=1, B_HH=2, H=3, WP_FWD=4, WP_BWD=5, BIAS_GI=6, B_HN=7, W_IH=8, F=9, WPX=10, N=11)     # enum vame_gru_pack_field
+GRU_PACK_MAX = 16
+
+
+def gru_pack_batch(items):
+    """items: [(W_hh, b_ih, b_hh, H, wp_fwd, wp_bwd, bias_gi, b_hn, W_ih | None, F, wpx | None)] -- all of them in one launch."""
+    for i in range(0, len(items), GRU_PACK_MAX):
+        part = items[i:i + GRU_PACK_MAX]
+        tab = (ctypes.c_int64 * (len(part) * GP["N"]))()
+        for k, (W_hh, b_ih, b_hh, H, wpf, wpb, bgi, bhn, W_ih, F, wpx) in enumerate(part):
+            row = [_ptr(W_hh), _ptr(b_ih), _ptr(b_hh), H, _ptr(wpf), _ptr(wpb), _ptr(bgi), _ptr(bhn), _ptr(W_ih) if W_ih is not None else 0,
+                   F, _ptr(wpx) if wpx is not None else 0]
+            for f, v in enumerate(row):
+                tab[k * GP["N"] + f] = int(v or 0)
+        rc = _lib.lib().vame_gru_pack_batch_f32(ctypes.addressof(tab), len(part), _stream())
+        _lib.check(rc, "vame_gru_pack_batch_f32")
 
 
 def gru_pack_x(W_ih, F, H, wpx):
