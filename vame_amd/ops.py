@@ -53,7 +53,7 @@ def gemm(M, N, K, A, a_kmajor, B, b_kmajor, C, ldc, c_off=0, bias=None, accumula
     if splitk == 0:
         # auto: few output tiles but a long K (Lambda / latent_to_hidden / dz GEMMs, M = batch): spread K over more workgroups
         tiles = ((M + 127) // 128) * ((N + 127) // 128 if N > 64 else 1)
-        splitk = max(1, min(7, 192 // tiles, K // 128)) if tiles <= 64 else 1
+        splitk = max(1, min(7, 192 // tiles, K // 128)) if tiles <= 64 else 1       # (measured against 16 and never: +1.2 % / +6 % of the batch 4096 / 256 step)
         if splitk > 1:
             ws = _auto_ws(C.device, splitk * M * N)
     if splitk > 1:
