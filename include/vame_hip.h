@@ -50,7 +50,7 @@ int vame_gemm_f32(int M, int N, int K, const float* A, int64_t lda, int a_kmajor
 
 /* `count` (1..8) problems of identical shape / layout in one launch (split-K >= 8, N > 64): C[g] (+)= op(A[g]) op(B[g]).  A, B, C are
  * HOST arrays of device pointers; ws holds count * splitk * M * N floats.  Used for the weight gradients of a backward pass (the six
- * dW_hh contractions of equal shape run as one launch with a third of the partial sums and no kernel boundary between them). */
+ * dW_hh contractions of equal shape run as one launch with a third of the partial sums and no kernel boundary between them).  * If every C[g] is the same pointer the problems are summed into it: C (+)= sum_g A_g B_g. */
 int vame_gemm_group_f32(int count, int M, int N, int K, const float* const* A, int64_t lda, int a_kmajor, int64_t a_seg,
                         int64_t a_seg_stride, const float* const* B, int64_t ldb, int b_kmajor, int64_t b_seg, int64_t b_seg_stride,
                         float* const* C, int64_t ldc, int accumulate, int splitk, float* ws, int a_gap_at, int a_gap, void* stream);

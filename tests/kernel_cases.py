@@ -44,6 +44,20 @@ def check_gemm_group(dev, small=True):
         np.testing.assert_allclose(N_(Cg)[0], ref, atol=2e-4 * np.sqrt(K))
 
 
+def check_gemm_group_shared_output(dev):
+    """All problems of a group naming one C: C (+)= sum_g A_g B_g (dz of the decoders), against float64."""
+    rng = np.random.default_rng(4)
+    for (M, Nn, K, n, acc) in [(100, 30, 256, 4, False), (64, 30, 512, 2, True), (130, 72, 768, 3, True)]:
+        As = [rng.standard_normal((M, K)).astype(np.float32) for _ in range(n)]
+        Bs = [rng.standard_normal((K, Nn)).astype(np.float32) for _ in range(n)]
+        C0 = rng.standard_normal((M, Nn)).astype(np.float32)
+        At, Bt, C = [T_(a, dev) for a in As], [T_(b, dev) for b in Bs], T_(C0, dev)
+        ws = torch.zeros(n * 8 * M * Nn, device=dev)
+        ops.gemm_group(M, Nn, K, [Operand(a, K) for a in At], 0, [Operand(b, Nn) for b in Bt], 1, C, [0] * n, Nn, 8, ws, accumulate=acc)
+        ref = sum(a.astype(np.float64) @ b.astype(np.float64) for a, b in zip(As, Bs)) + (C0 if acc else 0)
+        np.testing.assert_allclose(N_(C), ref, atol=2e-4 * np.sqrt(K * n))
+
+
 def check_gemm_cases(dev, small=True):
     rng = np.random.default_rng(0)
     cases = [  # M, N, K, akm, bkm, splitk, bias, acc

@@ -1,7 +1,7 @@
 """The kernel checks of test_kernels_emu.py on the real MI355X through libvame_hip.so (C ABI)."""
 import pytest
 
-from kernel_cases import (check_gru_wide, check_gru_wide_small, check_hmm, check_adam, check_adam_abort_and_mask_scale, check_colsum, check_colsum_batch, check_kmeans, check_gather, check_gemm_cases, check_gemm_group, check_gru_bwd, check_gru_coop_bwd, check_gru_coop_fwd, check_gru_fwd, check_gru_fwd_fused,
+from kernel_cases import (check_gemm_group_shared_output, check_gru_wide, check_gru_wide_small, check_hmm, check_adam, check_adam_abort_and_mask_scale, check_colsum, check_colsum_batch, check_kmeans, check_gather, check_gemm_cases, check_gemm_group, check_gru_bwd, check_gru_coop_bwd, check_gru_coop_fwd, check_gru_fwd, check_gru_fwd_fused,
                           check_latent, check_mse, check_nuclear, check_prep_fill_rules, check_prepare_series_golden,
                           check_prepare_series_vs_oracle)
 
@@ -87,3 +87,7 @@ def test_gru_wide_hidden_sizes(hip, H, B, T):
 @pytest.mark.parametrize("H,B,T", [(128, 37, 3), (192, 64, 5), (256, 100, 30), (256, 4096, 4)])
 def test_gru_wide_kernels_at_small_hidden_sizes(hip, H, B, T):
     check_gru_wide_small(DEV, H, B, T)
+
+
+def test_gemm_group_shared_output(hip):
+    check_gemm_group_shared_output(DEV)

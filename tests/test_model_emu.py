@@ -81,3 +81,15 @@ def test_cooperative_launch_failure_is_contained(emu):
 def test_wide_hidden_size_model_step_vs_oracle(emu):
     """256 < H <= 512: persistent two-blocks-per-wave forward (gru_wide.hip) + step-wise BPTT on its fragment stash, whole train step."""
     check_odd_dims_vs_oracle("cpu", F=12, Z=7, H=320, T=3, FS=2, B=5)
+
+
+def test_headline_hidden_size_takes_the_grouped_dz_path(emu):
+    """H = 256 is where K = 3H and 2H split eight ways: the decoders' contributions to dz leave as shared-output grouped launches."""
+    from vame_amd import ops
+    calls, orig = [], ops.gemm_group
+    ops.gemm_group = lambda *a, **k: (calls.append((a[2], len(a[3]))), orig(*a, **k))[1]
+    try:
+        check_odd_dims_vs_oracle("cpu", F=12, Z=7, H=256, T=2, FS=2, B=3)
+    finally:
+        ops.gemm_group = orig
+    assert (768, 4) in calls and (512, 2) in calls

@@ -485,34 +485,66 @@ __global__ __launch_bounds__(WM * WN * 64, ((BM / WM) * (BN / WN) > 64 * 64 || (
 #endif
 }
 
-__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ ws, int splitk, int M, int N,
-                                                            const float* __restrict__ bias, float* __restrict__ C,
-                                                            int64_t ldc, int accumulate) {
+// Split-K reduction.  One summation order everywhere, so that a problem gives the same bits whether it ran alone or in a group and
+// whichever thread layout reduced it: four interleaved partial sums p_k = sum over slabs z = k (mod 4) in increasing z, then
+// (p0 + p1) + (p2 + p3).  SPREAD: few outputs and many slabs (the 24-row heads: 12288 outputs x 192 slabs) -- a block takes 64
+// outputs and gives each partial sum its own 64 threads, 4x the loads in flight; otherwise one thread per output.
+template <bool SPREAD>
+__device__ __forceinline__ void splitk_reduce_body(const float* __restrict__ ws, int splitk, int M, int N, const float* __restrict__ bias,
+                                                   float* __restrict__ C, int64_t ldc, int accumulate) {
     const int64_t n = (int64_t)M * N;
-    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-        float v = 0.f;
-        for (int z = 0; z < splitk; ++z) v += ws[(int64_t)z * n + i];
+    auto finish = [&](int64_t i, float v) {
         const int row = (int)(i / N), col = (int)(i % N);
         if (bias) v += bias[col];
         float* c = C + (int64_t)row * ldc + col;
         if (accumulate) v += *c;
         *c = v;
+    };
+    if (SPREAD) {
+        __shared__ float part[4][64];
+        const int o = threadIdx.x & 63, k = threadIdx.x >> 6;
+        for (int64_t i0 = (int64_t)blockIdx.x * 64; i0 < n; i0 += (int64_t)gridDim.x * 64) {
+            const int64_t i = i0 + o;
+            float p = 0.f;
+            if (i < n)
+                for (int z = k; z < splitk; z += 4) p += ws[(int64_t)z * n + i];
+            part[k][o] = p;
+            __syncthreads();
+            if (k == 0 && i < n) finish(i, (part[0][o] + part[1][o]) + (part[2][o] + part[3][o]));
+            __syncthreads();
+        }
+    } else {
+        for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+            float p0 = 0.f, p1 = 0.f, p2 = 0.f, p3 = 0.f;
+            int z = 0;
+            for (; z + 4 <= splitk; z += 4) {
+                p0 += ws[(int64_t)z * n + i]; p1 += ws[(int64_t)(z + 1) * n + i]; p2 += ws[(int64_t)(z + 2) * n + i]; p3 += ws[(int64_t)(z + 3) * n + i];
+            }
+            if (z < splitk) p0 += ws[(int64_t)z * n + i];
+            if (z + 1 < splitk) p1 += ws[(int64_t)(z + 1) * n + i];
+            if (z + 2 < splitk) p2 += ws[(int64_t)(z + 2) * n + i];
+            finish(i, (p0 + p1) + (p2 + p3));
+        }
     }
+}
+template <bool SPREAD>
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ ws, int splitk, int M, int N,
+                                                            const float* __restrict__ bias, float* __restrict__ C,
+                                                            int64_t ldc, int accumulate) {
+    splitk_reduce_body<SPREAD>(ws, splitk, M, N, bias, C, ldc, accumulate);
 }
 
 struct GemmGroupOut { float* C[8]; };
+template <bool SPREAD>
 __global__ __launch_bounds__(256) void splitk_reduce_group_kernel(const float* __restrict__ ws, int splitk, int M, int N, GemmGroupOut out,
                                                                   int64_t ldc, int accumulate) {
-    const int64_t n = (int64_t)M * N;
-    const float* w = ws + (int64_t)blockIdx.y * splitk * n;
-    float* C = out.C[blockIdx.y];
-    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-        float v = 0.f;
-        for (int z = 0; z < splitk; ++z) v += w[(int64_t)z * n + i];
-        float* c = C + (i / N) * ldc + (i % N);
-        if (accumulate) v += *c;
-        *c = v;
-    }
+    splitk_reduce_body<SPREAD>(ws + (int64_t)blockIdx.y * splitk * (int64_t)M * N, splitk, M, N, nullptr, out.C[blockIdx.y], ldc, accumulate);
+}
+// launch geometry of a reduction over n outputs: {spread, blocks}
+static inline bool reduce_spread(int64_t n, int splitk) { return splitk >= 16 && n < 256 * 256; }
+static inline int reduce_blocks(int64_t n, bool spread) {
+    const int64_t b = cdiv64(n, spread ? 64 : 256);
+    return (int)(b < 1024 ? b : 1024);
 }
 
 #include <stdlib.h>
@@ -618,9 +650,12 @@ extern "C" int vame_gemm_f32(int M, int N, int K, const float* A, int64_t lda, i
     VAME_LAUNCH_CHECK("gemm");
     if (p.splitk > 1) {
         const int64_t n = (int64_t)M * N;
-        const int blocks = (int)(cdiv64(n, 256) < 2048 ? cdiv64(n, 256) : 2048);
-        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, (const float*)ws, p.splitk, M, N, bias, C,
-                           ldc, accumulate);
+        if (reduce_spread(n, p.splitk))
+            hipLaunchKernelGGL(splitk_reduce_kernel<true>, dim3(reduce_blocks(n, true)), dim3(256), 0, st, (const float*)ws, p.splitk, M, N,
+                               bias, C, ldc, accumulate);
+        else
+            hipLaunchKernelGGL(splitk_reduce_kernel<false>, dim3(reduce_blocks(n, false)), dim3(256), 0, st, (const float*)ws, p.splitk, M, N,
+                               bias, C, ldc, accumulate);
         VAME_LAUNCH_CHECK("gemm splitk reduce");
     }
     return VAME_OK;
@@ -629,7 +664,8 @@ extern "C" int vame_gemm_f32(int M, int N, int K, const float* A, int64_t lda, i
 // Several weight-gradient style problems of one shape and layout in ONE launch: C_g = A_g^T B_g (or any supported layout) with
 // split-K >= 8.  The k-slabs of all problems are dealt to the XCDs together, so the launch has count x as many workgroups as a
 // single problem: fewer partial sums per problem for the same occupancy, no kernel boundary (and no idle tail) between the
-// problems, one reduction launch.  Only the operand base pointers differ between the problems.
+// problems, one reduction launch.  Only the operand base pointers differ between the problems.  Problems that all name the SAME C
+// are summed into it: C (+)= sum_g A_g B_g (the input gradient of a vector that feeds several layers).
 extern "C" int vame_gemm_group_f32(int count, int M, int N, int K, const float* const* A, int64_t lda, int a_kmajor, int64_t a_seg,
                                    int64_t a_seg_stride, const float* const* B, int64_t ldb, int b_kmajor, int64_t b_seg,
                                    int64_t b_seg_stride, float* const* C, int64_t ldc, int accumulate, int splitk, float* ws,
@@ -663,10 +699,24 @@ extern "C" int vame_gemm_group_f32(int count, int M, int N, int K, const float* 
     VAME_CHECK_ARG(rc == VAME_OK, rc, "gemm_group: unsupported layout");
     VAME_LAUNCH_CHECK("gemm_group");
     GemmGroupOut out;
-    for (int g = 0; g < 8; ++g) out.C[g] = C[g < count ? g : 0];
+    bool one_c = count > 1;
+    for (int g = 0; g < 8; ++g) { out.C[g] = C[g < count ? g : 0]; one_c = one_c && out.C[g] == C[0]; }
     const int64_t n = (int64_t)M * N;
-    const int blocks = (int)(cdiv64(n, 256) < 1024 ? cdiv64(n, 256) : 1024);
-    hipLaunchKernelGGL(splitk_reduce_group_kernel, dim3(blocks, count), dim3(256), 0, st, (const float*)ws, p.splitk, M, N, out, ldc, accumulate);
+    if (one_c) {        // every problem names the same C: C = sum_g A_g B_g, the problems' partial sums are one stack of count x splitk slabs
+        const int slabs = count * p.splitk;
+        if (reduce_spread(n, slabs))
+            hipLaunchKernelGGL(splitk_reduce_kernel<true>, dim3(reduce_blocks(n, true)), dim3(256), 0, st, (const float*)ws, slabs, M, N,
+                               (const float*)nullptr, C[0], ldc, accumulate);
+        else
+            hipLaunchKernelGGL(splitk_reduce_kernel<false>, dim3(reduce_blocks(n, false)), dim3(256), 0, st, (const float*)ws, slabs, M, N,
+                               (const float*)nullptr, C[0], ldc, accumulate);
+    } else if (reduce_spread(n, p.splitk)) {
+        hipLaunchKernelGGL(splitk_reduce_group_kernel<true>, dim3(reduce_blocks(n, true), count), dim3(256), 0, st, (const float*)ws, p.splitk, M, N,
+                           out, ldc, accumulate);
+    } else {
+        hipLaunchKernelGGL(splitk_reduce_group_kernel<false>, dim3(reduce_blocks(n, false), count), dim3(256), 0, st, (const float*)ws, p.splitk, M, N,
+                           out, ldc, accumulate);
+    }
     VAME_LAUNCH_CHECK("gemm_group reduce");
     return VAME_OK;
 }

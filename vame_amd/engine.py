@@ -221,6 +221,25 @@ class VAEEngine:
                                N, sk, ws, a_gap_at=key[9], a_gap=key[10])
         return rest
 
+    def _sum_into(self, C, M, N, jobs):
+        """C (M,N) = sum of A_j (M,K_j) @ B_j (K_j,N).  Products of one K go out as one grouped launch whose partial sums are reduced
+        straight into C (vame_gemm_group_f32 with a shared output): two launches instead of two per product."""
+        first = True
+        by_k = {}
+        for K, A, Bop in jobs:
+            by_k.setdefault((K, A.ld, Bop.ld), []).append((A, Bop))
+        for (K, _, _), members in by_k.items():
+            kper = -(-(-(-K // 8)) // 32) * 32
+            if self.group_wgrads and 2 <= len(members) <= 8 and -(-K // kper) >= 8:
+                ws = self.ws.get("splitk_sum", len(members) * 8 * M * N, self.dev)
+                ops.gemm_group(M, N, K, [m[0] for m in members], 0, [m[1] for m in members], 1, C, [0] * len(members), N, 8, ws,
+                               accumulate=not first)
+                first = False
+            else:
+                for A, Bop in members:
+                    ops.gemm(M, N, K, A, 0, Bop, 1, C, N, accumulate=not first, splitk=0)
+                    first = False
+
     def _splitk(self, M, N, K):
         # ~3 workgroups per CU on all 256 CUs; with split-K >= 8 a whole k-slab lives on one XCD (gemm.hip
         # map_tile), so keep split-K a multiple of 8 to load the 8 XCDs evenly
@@ -668,20 +687,20 @@ class VAEEngine:
             rows += rows_f
             groups.append(("decoder_future", per_f, Yf, dhid_f, FS))
         self._gru_bwd(rows, B)
-        first = True
         He = H
+        dz_jobs = []                                                # dz = sum of (B x K) @ (K x Z) products: issued together below
         for name, per, Y, dhid, steps in groups:
             H = per[0][0].H                                          # hidden size of this decoder
             for dirn, (d, dG, dbias, dgsum) in enumerate(per):
                 ops.timesum(dG, B, steps, 3 * H, 4 * H, dgsum)       # z is constant in time: sum_t dG first
                 self._gru_param_grads(d, dG, dbias, ntiles, B, steps, Y, dirn, None, Z, const_in=(dgsum, z))
-                ops.gemm(B, Z, 3 * H, Operand(dgsum, 3 * H), 0, self.P(d.w_ih, Z), 1, dz, Z, accumulate=not first, splitk=0)
-                first = False
+                dz_jobs.append((3 * H, Operand(dgsum, 3 * H), self.P(d.w_ih, Z)))
             if dhid is not None:
                 wl = f"{name}.latent_to_hidden.weight"
                 self._gemm_wgrad(2 * H, Z, B, Operand(dhid, 2 * H), Operand(z, Z), wl)
                 ops.colsum(dhid, 0, B, 2 * H, 2 * H, self.g, t.off(f"{name}.latent_to_hidden.bias"))
-                ops.gemm(B, Z, 2 * H, Operand(dhid, 2 * H), 0, self.P(wl, Z), 1, dz, Z, accumulate=True, splitk=0)
+                dz_jobs.append((2 * H, Operand(dhid, 2 * H), self.P(wl, Z)))
+        self._sum_into(dz, B, Z, dz_jobs)
         H = He
         if use_minv and kl_weight != 0:
             ops.gemm(B, Z, Z, Operand(z, Z), 0, Operand(self.buf("Minv", Z, Z), Z), 1, dz, Z, accumulate=True)
