@@ -409,6 +409,13 @@ def check_mse(dev):
     tgt = win[:, 24:24 + TF]
     np.testing.assert_allclose(N_(loss)[1], ((pred - tgt) ** 2).sum(), rtol=1e-5)
     np.testing.assert_allclose(N_(dp), 2 * (pred - tgt), atol=1e-6)
+    # unaligned rows (scalar path), more rows than workgroups, no dpred
+    B, TF, row = 2500, 9 * 10, 13 * 10 + 3
+    pred = rng.standard_normal((B, TF)).astype(np.float32)
+    win = rng.standard_normal((B, row)).astype(np.float32)
+    loss = torch.zeros(2, device=dev)
+    ops.mse_fwd_bwd(T_(pred, dev), T_(win, dev), 7, row, B, TF, 1.0, None, loss, 0)
+    np.testing.assert_allclose(N_(loss)[0], ((pred - win[:, 7:7 + TF]) ** 2).sum(), rtol=2e-5)
 
 
 def check_colsum(dev):
@@ -417,6 +424,11 @@ def check_colsum(dev):
     out = torch.ones(260, device=dev)
     ops.colsum(T_(a, dev), 5, 13, 260, 300, out, 0, accumulate=True)
     np.testing.assert_allclose(N_(out), 1 + a[:, 5:265].sum(0), atol=1e-5)
+    for (R, C) in ((5000, 24), (4100, 64), (4096, 12)):        # narrow contiguous matrices: the float4-stream kernel
+        b = rng.standard_normal((R, C)).astype(np.float32)
+        o = torch.zeros(C, device=dev)
+        ops.colsum(T_(b, dev), 0, R, C, C, o, 0)
+        np.testing.assert_allclose(N_(o), b.astype(np.float64).sum(0), atol=2e-3)
 
 
 def check_colsum_batch(dev):
