@@ -8,7 +8,14 @@ HDR := vame_amd/csrc/gru_wide_loop.inc vame_amd/csrc/vame_device.h vame_amd/csrc
 HIPFLAGS := --offload-arch=gfx950 -O3 -std=c++17 -fPIC
 EMUFLAGS := -DVAME_EMU -O2 -std=c++17 -fPIC -pthread -Itests/emu -Wno-unknown-attributes
 
+# identity of the kernel sources, compiled into the library (vame_source_id()): bench.py only quotes PMC traffic that was collected
+# with a library built from the same sources (the .so bytes themselves differ between build directories)
+SRC_ID := $(shell cat $(SRC) $(HDR) | sha256sum | cut -c1-64)
+
 all: vame_amd/libvame_hip.so tests/emu/libvame_emu.so
+
+build/hip/elementwise.o build/ab/elementwise.o build/probe/elementwise.o: HIPFLAGS += -DVAME_SRC_ID=\"$(SRC_ID)\"
+build/hip/elementwise.o build/ab/elementwise.o build/probe/elementwise.o: $(SRC)
 
 build/hip/%.o: vame_amd/csrc/%.hip $(HDR)
 	@mkdir -p build/hip

@@ -148,27 +148,26 @@ def bench_embed(args, dev, rank, world):
         dist.destroy_process_group()
 
 
-def lib_sha256():
-    import hashlib
+def lib_source_id():
+    """sha256 of the kernel sources the loaded libvame_hip.so was built from (compiled in by the Makefile)."""
     from vame_amd import _lib
-    with open(_lib.LIB_PATH, "rb") as f:
-        return hashlib.sha256(f.read()).hexdigest()
+    return _lib.lib().vame_source_id().decode()
 
 
 def pmc_traffic(dom_key):
     """HBM bytes per launch of the dominant kernel from a committed rocprofv3 PMC summary (tools/pmc_summary.py: FETCH_SIZE x2 +
     WRITE_SIZE in separate --pmc passes, corrected as MI355X_MICROARCH.md prescribes) -- but only from a summary that was
-    collected with THIS build of libvame_hip.so (its sha256 is stored in the summary); None otherwise: a number measured on an
+    collected with a libvame_hip.so built from THESE kernel sources (vame_source_id(), stored in the summary); None otherwise: a number measured on an
     older kernel says nothing about the current one."""
     import glob
-    sha = lib_sha256()
+    sha = lib_source_id()
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_hbm_traffic*.json")), reverse=True):
         try:
             with open(path) as f:
                 j = json.load(f)
         except (OSError, ValueError):
             continue
-        if j.get("lib_sha256") != sha:
+        if sha == "unidentified" or j.get("source_id") != sha:
             continue
         hit = j.get("by_bench_key", {}).get(dom_key)
         if hit is not None:

@@ -23,6 +23,9 @@ extern "C" {
 #define VAME_E_UNSUPPORTED (-4)
 
 int vame_version(void);
+/* sha256 of the kernel sources this library was built from (Makefile SRC_ID; "unidentified" for other builds): the key that
+ * binds committed rocprofv3 counter summaries to a build (profiles/, bench.py roofline.traffic). */
+const char* vame_source_id(void);
 const char* vame_last_error(void);
 
 /* Sliding-window batcher: out[b,l,f] = X[f*N + start_b + l]  (B,L,F).

@@ -17,6 +17,7 @@ class VameHipError(RuntimeError):
 
 
 _SIGS = {
+    "vame_source_id": (c_char_p, []),
     "vame_version": (c_int, []),
     "vame_last_error": (c_char_p, []),
     "vame_window_gather_f32": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p]),

@@ -12,6 +12,10 @@ void vame_set_error(const char* fmt, ...) {
 }
 extern "C" const char* vame_last_error(void) { return g_err; }
 extern "C" int vame_version(void) { return 100; }
+#ifndef VAME_SRC_ID
+#define VAME_SRC_ID "unidentified"          /* the emulator build, or a compile outside the Makefile */
+#endif
+extern "C" const char* vame_source_id(void) { return VAME_SRC_ID; }
 
 static inline int ew_blocks(int64_t n, int per_block = 256) {
     int64_t b = cdiv64(n, per_block);
