@@ -25,4 +25,8 @@ python tools/rocprof_digest.py pmc $O/raw_fetch $O/raw_write vame_amd/libvame_hi
 python tools/rocprof_digest.py sq $O/raw_sq $O/pmc_sq_cfg2.json "rocprofv3 --kernel-trace --pmc SQ_* GRBM_GUI_ACTIVE -- python bench.py --steps 2 --warmup 1 (BASELINE configs[1])"
 python tools/rocprof_digest.py sq $O/raw_sq4 $O/pmc_sq_cfg4.json "same counters, --hidden 512 --time-window 60 --batch 8192 (BASELINE configs[3])"
 rm -rf $O/raw_*
+# the headline line once more, now that a traffic summary of this very build exists (bench.py looks under profiles/)
+cp $O/pmc_hbm_traffic.json profiles/_this_run_pmc_hbm_traffic.json
+timeout 400 python bench.py > $O/bench.json 2> $O/bench.err; cut -c1-250 $O/bench.json
+rm -f profiles/_this_run_pmc_hbm_traffic.json
 ls -la $O
