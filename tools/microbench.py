@@ -125,10 +125,11 @@ def gemm_skinny(rounds=4):
         B = torch.randn((K, N) if bkm else (N, K), device=dev)
         C = torch.empty(M, N, device=dev)
         ws = torch.empty(sk * M * N, device=dev) if sk > 1 else None
-        res = {v: [] for v in (0, 3, 4)}
+        res = {v: [] for v in (0, 3, 4, 10, 11, 15)}            # 10 / 11 / 15: the 128x32 tile with loop variant 0 / 1 / 5
         for r in range(rounds):
             for v in res:
-                os.environ["VAME_GEMM_TILE"] = str(v)
+                os.environ["VAME_GEMM_TILE"] = str(v if v < 10 else 0)
+                os.environ["VAME_GEMM_VAR_SKINNY"] = str(v - 10) if v >= 10 else "-1"
                 ms = timeit(lambda: ops.gemm(M, N, K, Operand(A, A.shape[1]), akm, Operand(B, B.shape[1]), bkm, C, N, splitk=sk, ws=ws), reps=10)
                 res[v].append(ms * 1e3)
         print(f"M={M} N={N} K={K} akm={akm} bkm={bkm} sk={sk}: " + "  ".join(f"tile{v}: {statistics.median(t):7.1f} us" for v, t in res.items()), flush=True)
@@ -138,6 +139,8 @@ def gemm_ab(rounds=4):
     """Interleaved A/B of the GEMM kernel variants (library built with `make ab`)."""
     BT = 4096 * 30
     shapes = [(BT, 768, 512, 0, 0, 1), (BT, 512, 768, 0, 1, 1), (768, 512, BT, 1, 1, 32), (768, 256, BT, 1, 1, 64), (4096, 4096, 4096, 1, 1, 1)]
+    if len(sys.argv) > 3 and sys.argv[3] == "tinyk":      # the K = 24 / 30 forms (output-head dY, projections of z): epilogue-bound
+        shapes = [(BT, 512, 24, 0, 1, 1), (BT // 2, 512, 24, 0, 1, 1), (4096, 768, 30, 0, 0, 1), (4096, 512, 30, 0, 0, 1), (BT, 768, 24, 0, 0, 1)]
     import statistics
     for (M, N, K, akm, bkm, sk) in shapes:
         A = torch.randn((K, M) if akm else (M, K), device=dev)

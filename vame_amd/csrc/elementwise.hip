@@ -137,18 +137,33 @@ __global__ __launch_bounds__(256) void mse_kernel(const float* __restrict__ pred
                                                   int64_t tgt_row, int B, int TF, float gscale, float* __restrict__ dpred,
                                                   float* __restrict__ loss_out) {
     float part = 0.f;
-    for (int b = blockIdx.x; b < B; b += gridDim.x) {
-        const float* p = pred + (int64_t)b * TF;
-        const float* t = target + (int64_t)b * tgt_row;
-        float* d = dpred ? dpred + (int64_t)b * TF : nullptr;
-        if (VEC) {
-            for (int j = threadIdx.x; j < TF / 4; j += blockDim.x) {
-                const float4 pv = reinterpret_cast<const float4*>(p)[j], tv = reinterpret_cast<const float4*>(t)[j];
-                const float4 e = make_float4(pv.x - tv.x, pv.y - tv.y, pv.z - tv.z, pv.w - tv.w);
-                part += (e.x * e.x + e.y * e.y) + (e.z * e.z + e.w * e.w);
-                if (d) reinterpret_cast<float4*>(d)[j] = make_float4(gscale * e.x, gscale * e.y, gscale * e.z, gscale * e.w);
+    if (VEC) {
+        // four rows per pass: their eight loads are in flight together (one float atomic per workgroup ends the kernel, and atomics
+        // on one address serialise at ~15 ns each -- hence few workgroups with deep passes rather than one row per workgroup)
+        const int n4 = TF / 4;
+        for (int b0 = blockIdx.x * 4; b0 < B; b0 += gridDim.x * 4) {
+            for (int j = threadIdx.x; j < n4; j += blockDim.x) {
+                float4 pv[4], tv[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int b = b0 + r < B ? b0 + r : B - 1;
+                    pv[r] = reinterpret_cast<const float4*>(pred + (int64_t)b * TF)[j];
+                    tv[r] = reinterpret_cast<const float4*>(target + (int64_t)b * tgt_row)[j];
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    if (b0 + r >= B) break;
+                    const float4 e = make_float4(pv[r].x - tv[r].x, pv[r].y - tv[r].y, pv[r].z - tv[r].z, pv[r].w - tv[r].w);
+                    part += (e.x * e.x + e.y * e.y) + (e.z * e.z + e.w * e.w);
+                    if (dpred) reinterpret_cast<float4*>(dpred + (int64_t)(b0 + r) * TF)[j] = make_float4(gscale * e.x, gscale * e.y, gscale * e.z, gscale * e.w);
+                }
             }
-        } else {
+        }
+    } else {
+        for (int b = blockIdx.x; b < B; b += gridDim.x) {
+            const float* p = pred + (int64_t)b * TF;
+            const float* t = target + (int64_t)b * tgt_row;
+            float* d = dpred ? dpred + (int64_t)b * TF : nullptr;
             for (int j = threadIdx.x; j < TF; j += blockDim.x) {
                 const float e = p[j] - t[j];
                 part += e * e;
@@ -165,8 +180,8 @@ extern "C" int vame_mse_fwd_bwd_f32(const float* pred, const float* target, int6
     VAME_CHECK_ARG(pred && target, VAME_E_BADARG, "mse: null pointer");
     VAME_CHECK_ARG(B >= 1 && TF >= 1 && tgt_row >= TF, VAME_E_SHAPE, "mse: bad shape");
     const bool vec = TF % 4 == 0 && tgt_row % 4 == 0 && (uintptr_t)pred % 16 == 0 && (uintptr_t)target % 16 == 0 && (uintptr_t)dpred % 16 == 0;
-    const dim3 grid(B < 2048 ? B : 2048);
-    if (vec) hipLaunchKernelGGL(mse_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, pred, target, tgt_row, B, TF, gscale, dpred, loss_out);
+    const dim3 grid(B < 2048 ? B : 2048), grid4((B + 3) / 4 < 512 ? (B + 3) / 4 : 512);
+    if (vec) hipLaunchKernelGGL(mse_kernel<true>, grid4, dim3(256), 0, (hipStream_t)stream, pred, target, tgt_row, B, TF, gscale, dpred, loss_out);
     else hipLaunchKernelGGL(mse_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, pred, target, tgt_row, B, TF, gscale, dpred, loss_out);
     VAME_LAUNCH_CHECK("mse");
     return VAME_OK;
@@ -193,18 +208,22 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __rest
     __syncthreads();
     if (ty == 0 && c < C) part[(int64_t)blockIdx.y * C + c] = red[0][tx] + red[1][tx] + red[2][tx] + red[3][tx];
 }
-__global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restrict__ part, int nslabs, int C,
-                                                           float* __restrict__ out, int accumulate) {
-    __shared__ float red[4][64];
+// 16 row lanes per column: at most 8 dependent loads per thread over the <= 128 slab partials (with 4 lanes the single workgroup
+// of a narrow sum spent 8 us on 32 dependent loads); fixed summation order.
+__global__ __launch_bounds__(1024) void colsum_final_kernel(const float* __restrict__ part, int nslabs, int C,
+                                                            float* __restrict__ out, int accumulate) {
+    __shared__ float red[16][64];
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + tx;
     float s = 0.f;
     if (c < C)
-        for (int i = ty; i < nslabs; i += 4) s += part[(int64_t)i * C + c];
+        for (int i = ty; i < nslabs; i += 16) s += part[(int64_t)i * C + c];
     red[ty][tx] = s;
     __syncthreads();
     if (ty == 0 && c < C) {
-        const float t = (red[0][tx] + red[1][tx]) + (red[2][tx] + red[3][tx]);
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) t += red[k][tx];
         out[c] = accumulate ? out[c] + t : t;
     }
 }
@@ -256,7 +275,7 @@ extern "C" int vame_colsum_f32(const float* in, int64_t R, int C, int64_t ld, fl
                            (hipStream_t)stream, in, R, C, ld, rps, ws);
         VAME_LAUNCH_CHECK("colsum partial");
     }
-    hipLaunchKernelGGL(colsum_final_kernel, dim3((unsigned)cdiv64(C, 64)), dim3(256), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(colsum_final_kernel, dim3((unsigned)cdiv64(C, 64)), dim3(1024), 0, (hipStream_t)stream,
                        (const float*)ws, (int)nslabs, C, out, accumulate);
     VAME_LAUNCH_CHECK("colsum final");
     return VAME_OK;
