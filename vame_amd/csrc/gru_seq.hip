@@ -185,7 +185,8 @@ extern "C" int64_t vame_gru_stash_floats(int B, int T, int H) {
 //   float4 index ((((tile*T + t)*NW + w)*5 + k)*4 + rq)*64 + lane,  k = cA, cB, u, r, gh_n  with
 //   cA = (1-u)(1-n^2) (d a_n / d h'),  cB = (h_prev - n) u (1-u) (d a_z / d h'):  every BPTT gate gradient is
 //   d * {cA, cB, u} or a product with r / gh_n, so the backward kernel needs neither n nor h_prev.
-// ABL (ablation mask, 0 in production; tools/microbench.py VAME_ABL_FWD): 1 no stash stores, 2 no gi loads,
+// ABL (ablation mask, 0 in production; tools/microbench.py VAME_ABL_FWD): 1 no stash stores, 2 no gi loads, 256 gi loads mid-loop, 512 gi as
+// twelve wide loads (timing only),
 // 4 no y stores, 8 no gate transcendental math, 16 W fragments not re-streamed, 32 no per-step barrier
 // XIN: the input projection x_t W_ih^T (F <= 32 features, zero padded to K = 32) is computed in-kernel as four extra
 // MFMA chunks per step from an LDS-staged (32 x F) tile of x_t; no gi tensor exists (encoder layer 0).
@@ -267,6 +268,16 @@ __global__ __launch_bounds__(H / 32 * 64) void gru_seq_fwd_kernel(GruFwdParams P
     f32x16 gr, gu, gn;
     auto load_gi = [&](int t) {
         const float* gt = gi_base + (int64_t)t * S.gi_t;
+        if (ABL & 512) {        // timing experiment only (wrong values): the same 12 KB as twelve contiguous 16-byte loads per lane
+            const float4* gf = reinterpret_cast<const float4*>(S.gi + (int64_t)(row0 + (t % 16) * 2) * S.gi_row + w * 3072) + lane;   // 12 KB of its own per (tile, step, wave)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 a = gf[(0 * 4 + q) * 64], b = gf[(1 * 4 + q) * 64], c = gf[(2 * 4 + q) * 64];
+                gr[4 * q] = a.x; gr[4 * q + 1] = a.y; gr[4 * q + 2] = a.z; gr[4 * q + 3] = a.w;
+                gu[4 * q] = b.x; gu[4 * q + 1] = b.y; gu[4 * q + 2] = b.z; gu[4 * q + 3] = b.w;
+                gn[4 * q] = c.x; gn[4 * q + 1] = c.y; gn[4 * q + 2] = c.z; gn[4 * q + 3] = c.w;
+            }
+        } else
         if (!(ABL & 2) && full) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -594,7 +605,7 @@ static void launch_fwd(const GruFwdParams& P, hipStream_t st) {
     if (H == 256) switch (abl_env("VAME_ABL_FWD")) {      // profiling-only ablations, tuning build (make ab) only
         ABL_CASE(gru_seq_fwd_kernel, 256, 1, P, st) ABL_CASE(gru_seq_fwd_kernel, 256, 2, P, st) ABL_CASE(gru_seq_fwd_kernel, 256, 4, P, st)
         ABL_CASE(gru_seq_fwd_kernel, 256, 8, P, st) ABL_CASE(gru_seq_fwd_kernel, 256, 16, P, st) ABL_CASE(gru_seq_fwd_kernel, 256, 32, P, st)
-        ABL_CASE(gru_seq_fwd_kernel, 256, 7, P, st) ABL_CASE(gru_seq_fwd_kernel, 256, 63, P, st) ABL_CASE(gru_seq_fwd_kernel, 256, 256, P, st)
+        ABL_CASE(gru_seq_fwd_kernel, 256, 7, P, st) ABL_CASE(gru_seq_fwd_kernel, 256, 63, P, st) ABL_CASE(gru_seq_fwd_kernel, 256, 256, P, st) ABL_CASE(gru_seq_fwd_kernel, 256, 512, P, st)
         default: break;
     }
 #endif
