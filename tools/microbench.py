@@ -84,7 +84,7 @@ def bench_gru(H, B, T, nstreams, quiet=False, hook=None):
 
 def ablate():
     """GRU kernel ablations; needs the tuning build: make ab && VAME_LIB=tools/libvame_hip_ab.so python tools/microbench.py 10 ablate"""
-    for var, masks in (("VAME_ABL_FWD", (0, 512, 2, 0, 512, 2)), ("VAME_ABL_BWD", (0, 256, 1, 0, 256, 1))):
+    for var, masks in (("VAME_ABL_FWD", (0, 512, 2, 0, 512, 2)), ("VAME_ABL_BWD", (0, 256, 1024, 0, 256, 1024))):
         for m in masks:
             os.environ[var] = str(m)
             print(f"--- {var}={m}")

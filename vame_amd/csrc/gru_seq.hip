@@ -426,7 +426,7 @@ __global__ __launch_bounds__(H / 32 * 64) void gru_seq_fwd_kernel(GruFwdParams P
 }
 
 // ------------------------------------------------------------------------------------------- backward
-// ABL: 1 no dG stores, 2 no stash/dy loads (first step's reused), 16 W fragments not re-streamed, 32 no barriers, 256 dG copy-out after the loop
+// ABL: 1 no dG stores, 2 no stash/dy loads (first step's reused), 16 W fragments not re-streamed, 32 no barriers, 256 / 1024 dG copy-out placement (see the step loop)
 template <int H, int ABL = 0>
 __global__ __launch_bounds__(H / 32 * 64) void gru_seq_bwd_kernel(GruBwdParams P) {
     constexpr int NW = H / 32, K3 = 3 * H, LDG = 4 * H + 4, KC = K3 / 8;
@@ -506,6 +506,19 @@ __global__ __launch_bounds__(H / 32 * 64) void gru_seq_bwd_kernel(GruBwdParams P
                         *reinterpret_cast<const float4*>((i < 8 ? gs_copy : gs_copy + 16 * LDG) + 2 * (i & 7) * LDG);
         }
     };
+    // (ablation 256) the same copy by the first H threads alone (= the older wave of every SIMD pair, NW/2 waves): one full 4H-float row
+    // per pass, 32 passes.  Those waves win the MFMA arbitration, leave the loop ~4 k cycles before the others and then idle at barrier 2
+    // (per-wave probes, profiles/r02_gru_ablation.txt); letting them copy in that slack was measured 3 % slower than the default.
+    const int ecol = 4 * (tid % H), eblk = ecol / H;
+    float* dg_early = S.dg + ((int64_t)row0 * T) * 4 * H + (eblk == 2 ? 3 * H : eblk == 3 ? 2 * H : eblk * H) + ecol % H;
+    auto dg_copy_out_early = [&](int t) {
+        if (tid >= H) return;
+        float* dgt = dg_early + (int64_t)t * 4 * H;
+#pragma unroll 8
+        for (int i = 0; i < 32; ++i)
+            if (full || i < nvalid)
+                *reinterpret_cast<float4*>(dgt + (int64_t)i * T * 4 * H) = *reinterpret_cast<const float4*>(&gs[i * LDG + ecol]);
+    };
     GRU_PHASE_DECL();
     for (int step = 0; step < T; ++step) {
         const int fstep = T - 1 - step;
@@ -534,9 +547,12 @@ __global__ __launch_bounds__(H / 32 * 64) void gru_seq_bwd_kernel(GruBwdParams P
         GRU_PHASE(1);                 // coefficient math + LDS tile writes (incl. the wait for the stash loads)
         if (!(ABL & 32)) __syncthreads();
         GRU_PHASE(2);                 // barrier 1
-        // dG copy-out: BEFORE the MFMA loop, which covers its stores (ablation 256 = after the loop, where the stores delay barrier 2:
-        // measured 2-3 % slower although they then no longer sit in front of the loop's weight-fragment loads in the in-order queue)
-        if (!(ABL & 1) && (!(ABL & 256) || (step + 1 == T && S.dh0 == nullptr))) dg_copy_out(t);
+        // dG copy-out: BEFORE the MFMA loop by all waves -- the loop covers the stores.  Measured alternatives (ablations; a last step
+        // that skips the loop copies here in every form): 1024 = after the loop by all waves, 2-3 % slower (the stores delay barrier 2 for
+        // the waves that arrive last); 256 = after the loop by the early half of the waves only (dg_copy_out_early), also 3 % slower
+        // although those waves idle at barrier 2 for 8 k cycles: their stores then share the memory path with the late waves' loads.
+        if (!(ABL & 1) && !(ABL & (256 | 1024))) dg_copy_out(t);
+        else if (!(ABL & 1) && step + 1 == T && S.dh0 == nullptr) { if (ABL & 1024) dg_copy_out(t); else dg_copy_out_early(t); }
         GRU_PHASE(3);                 // dG copy-out
         if (!(ABL & 2) && (ABL & 128) && step + 1 < T) load_step(step + 1);      // (ablation: the old place, before the MFMA loop)
         GRU_PHASE(4);                 // next step's stash / dy loads (issue)
@@ -568,7 +584,7 @@ __global__ __launch_bounds__(H / 32 * 64) void gru_seq_bwd_kernel(GruBwdParams P
         // next step's stash / dy loads: issued AFTER the MFMA loop -- before it they sit in front of every weight-fragment load of the
         // loop in the in-order vmcnt queue (measured: 2-3 % slower); their latency overlaps barrier 2 and the other wave's loop tail
         if (!(ABL & 2) && !(ABL & 192) && step + 1 < T) load_step(step + 1);
-        if (!(ABL & 1) && (ABL & 256)) dg_copy_out(t);            // (gs is intact until barrier 2)
+        if (!(ABL & 1) && (ABL & (256 | 1024))) { if (ABL & 1024) dg_copy_out(t); else dg_copy_out_early(t); }     // (gs is intact until barrier 2)
 #pragma unroll
         for (int r = 0; r < 16; ++r) dh[r] = acc0[r] + acc1[r];
         GRU_PHASE(5);                 // MFMA loop
@@ -618,7 +634,7 @@ static void launch_bwd(const GruBwdParams& P, hipStream_t st) {
     if (H == 256) switch (abl_env("VAME_ABL_BWD")) {
         ABL_CASE(gru_seq_bwd_kernel, 256, 1, P, st) ABL_CASE(gru_seq_bwd_kernel, 256, 2, P, st) ABL_CASE(gru_seq_bwd_kernel, 256, 3, P, st)
         ABL_CASE(gru_seq_bwd_kernel, 256, 16, P, st) ABL_CASE(gru_seq_bwd_kernel, 256, 32, P, st) ABL_CASE(gru_seq_bwd_kernel, 256, 51, P, st)
-        ABL_CASE(gru_seq_bwd_kernel, 256, 64, P, st) ABL_CASE(gru_seq_bwd_kernel, 256, 128, P, st) ABL_CASE(gru_seq_bwd_kernel, 256, 256, P, st)
+        ABL_CASE(gru_seq_bwd_kernel, 256, 64, P, st) ABL_CASE(gru_seq_bwd_kernel, 256, 128, P, st) ABL_CASE(gru_seq_bwd_kernel, 256, 256, P, st) ABL_CASE(gru_seq_bwd_kernel, 256, 1024, P, st)
         default: break;
     }
 #endif
