@@ -2,7 +2,7 @@
 # Objects are compiled per source file (make -j parallelises; only changed files rebuild).
 HIPCC ?= /opt/rocm/bin/hipcc
 HOSTCXX ?= /opt/rocm/lib/llvm/bin/clang++
-NAMES := gru_seq gemm elementwise prep gru_coop hmm gru_wide
+NAMES := gru_seq gemm elementwise prep gru_coop hmm gru_wide heads
 SRC := $(foreach n,$(NAMES),vame_amd/csrc/$(n).hip)
 HDR := vame_amd/csrc/gru_wide_loop.inc vame_amd/csrc/vame_device.h vame_amd/csrc/vame_common.h vame_amd/csrc/gru_desc.h include/vame_hip.h
 HIPFLAGS := --offload-arch=gfx950 -O3 -std=c++17 -fPIC

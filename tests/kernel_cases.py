@@ -418,6 +418,37 @@ def check_mse(dev):
     np.testing.assert_allclose(N_(loss)[0], ((pred - win[:, 7:7 + TF]) ** 2).sum(), rtol=2e-5)
 
 
+def check_head_fused(dev, B=7, T=9, F=24, K=64, pad=2):
+    """Fused output head (Linear -> MSE(sum) -> dpred -> dY) vs float64 numpy, on the decoder-state layout (B, T+pad, K) with a row
+    offset, a ragged last 32-row tile and a target window inside a wider row."""
+    rng = np.random.default_rng(21)
+    Y = rng.standard_normal((B, T + pad, K)).astype(np.float32)
+    W = (rng.standard_normal((F, K)) / np.sqrt(K)).astype(np.float32)
+    bias = rng.standard_normal(F).astype(np.float32)
+    row, off = (T + 5) * F + 4, 8
+    win = rng.standard_normal((B, row)).astype(np.float32)
+    gs = 1.7
+    Yt, Wt = T_(Y, dev), T_(W, dev)
+    pred, dpred = torch.zeros(B * T, F, device=dev), torch.zeros(B * T, F, device=dev)
+    dY = torch.full((B * T, K + 8), 7.0, device=dev)
+    loss = torch.full((3,), 0.5, device=dev)
+    assert ops.head_fused_ok(F, K)
+    o1 = 1 if pad else 0
+    ops.head_fused(Operand(Yt, K, off=o1 * K, seg=T, seg_stride=(T + pad) * K), B * T, F, K, Operand(Wt, K), T_(bias, dev), T_(win, dev), off, row, gs,
+                   pred, dpred, dY, K + 8, loss, 1)
+    y = Y[:, o1:o1 + T].reshape(B * T, K).astype(np.float64)
+    p = y @ W.astype(np.float64).T + bias
+    tgt = win[:, off:off + T * F].reshape(B * T, F)
+    e = p - tgt
+    np.testing.assert_allclose(N_(pred), p, atol=2e-5)
+    np.testing.assert_allclose(N_(dpred), gs * e, atol=5e-5)
+    np.testing.assert_allclose(N_(loss)[1], 0.5 + (e ** 2).sum(), rtol=2e-5)
+    assert N_(loss)[0] == 0.5 and N_(loss)[2] == 0.5
+    out = N_(dY)
+    np.testing.assert_allclose(out[:, :K], (gs * e) @ W.astype(np.float64), atol=1e-4)
+    assert (out[:, K:] == 7.0).all()
+
+
 def check_colsum(dev):
     rng = np.random.default_rng(6)
     a = rng.standard_normal((13, 300)).astype(np.float32)

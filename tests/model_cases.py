@@ -3,6 +3,7 @@ import numpy as np
 import torch
 
 from conftest import golden_weights, load_golden
+from vame_amd import ops
 from vame_amd.model.rnn_model import RNN_VAE
 
 
@@ -260,6 +261,33 @@ def check_model_options(dev, name):
     np.testing.assert_allclose(ep.cpu().numpy(), g["eval_pred"], atol=3e-5)
     np.testing.assert_allclose(ef.cpu().numpy(), g["eval_fut"], atol=3e-5)
     np.testing.assert_allclose(emu.cpu().numpy(), g["eval_mu"], atol=1e-5)
+
+
+def check_fused_heads_match(dev):
+    """VAME_AMD_FUSE_HEADS=1 (one kernel per decoder for output Linear + MSE + their backward) gives the losses and gradients of the
+    default three-launch path."""
+    rng = np.random.default_rng(31)
+    T, F, Z, H, FS, B = 7, 12, 6, 32, 3, 37
+    outs = []
+    for fuse in (False, True):
+        torch.manual_seed(5)
+        model = RNN_VAE(2 * T, Z, F, 1, FS, H, H, H, H, 0, 0, 0, False).to(dev).train()
+        eng = model._ensure_engine()
+        eng.fuse_heads = fuse
+        win = torch.from_numpy(np.random.default_rng(2).standard_normal((B, T + FS, F)).astype(np.float32)).to(dev)
+        eps = torch.from_numpy(np.random.default_rng(3).standard_normal((B, Z)).astype(np.float32)).to(dev)
+        calls, orig = [], ops.head_fused
+        ops.head_fused = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]
+        try:
+            terms = model.loss_step(win, 0.8, beta=1.5, kloss=Z, klmbda=0.2, bsize=B, eps=eps).cpu().numpy()
+        finally:
+            ops.head_fused = orig
+        assert len(calls) == (2 if fuse else 0)
+        outs.append((terms, model.flat_parameters()[1].clone().cpu().numpy(), eng.buf("pred", B, T, F)[:B * T * F].cpu().numpy()))
+    (t0, g0, p0), (t1, g1, p1) = outs
+    np.testing.assert_allclose(t1, t0, rtol=2e-5)
+    np.testing.assert_allclose(p1, p0, atol=2e-5)
+    np.testing.assert_allclose(g1, g0, atol=3e-5 * max(1.0, float(np.abs(g0).max())))
 
 
 def check_stale_backward_guard(dev):

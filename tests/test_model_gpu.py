@@ -5,7 +5,7 @@ import pytest
 import torch
 
 from conftest import load_golden
-from model_cases import check_adam_trajectory, check_coop_failure_is_contained, check_odd_dims_vs_oracle, check_eval_and_submodules, check_evaluate_and_generative_cores, check_h0_view, check_device_window_loader, check_legacy_step, check_model_options, check_noise_input, check_stale_backward_guard, check_step
+from model_cases import check_fused_heads_match, check_adam_trajectory, check_coop_failure_is_contained, check_odd_dims_vs_oracle, check_eval_and_submodules, check_evaluate_and_generative_cores, check_h0_view, check_device_window_loader, check_legacy_step, check_model_options, check_noise_input, check_stale_backward_guard, check_step
 from oracle import vame_oracle as vo
 from vame_amd.model.rnn_model import RNN_VAE
 
@@ -271,3 +271,7 @@ def test_cfg4_full_batch_properties(hip):
     model.loss_step(win, 1.0, beta=1.0, kloss=Z, klmbda=0.1, bsize=B, eps=eps)
     g_step = model.flat_parameters()[1]
     assert float((g_wide - g_step).abs().max()) <= 2e-4 * float(g_step.abs().max())
+
+
+def test_fused_output_heads_match_the_default_path(hip):
+    check_fused_heads_match("cuda")

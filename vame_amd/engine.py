@@ -122,6 +122,11 @@ class VAEEngine:
         self.ws = Workspace()
         self._wgrad_queue = None
         self.group_wgrads = os.environ.get("VAME_AMD_GROUP_WGRADS", "1") != "0"
+        # training step: output Linear + MSE + their backward per decoder in ONE kernel (vame_head_fused_f32).  Off by default: measured
+        # 159 us against 149 us for the three launches it replaces at batch 4096 (tools/head_bench.py; both stream their 2 x 252 MB at
+        # 3.3-4 TB/s) and +-0 on the whole step; the parity tests run it both ways.
+        self.fuse_heads = os.environ.get("VAME_AMD_FUSE_HEADS", "0") != "0"
+        self._heads_deferred = False
         self._B_bwd = None
         self._side_streams = []
         self.small_streams = int(os.environ.get("VAME_AMD_SMALL_STREAMS", "3"))   # independent small GEMMs before the decoder launch
@@ -541,7 +546,7 @@ class VAEEngine:
             rows.append(self._gru_fwd_stream(d, gi, 3 * H, 0, hid, dirn * B * H, Y, 2 * H, steps, dirn, None, 0, 0, st, steps))
         return Y
 
-    def decode(self, z, B, training, which="both"):
+    def decode(self, z, B, training, which="both", heads=True):
         """Decoder (+ Decoder_Future) from z.  which = "dec" / "fut" runs only that one (the sub-module call patterns
         model.decoder(ins, z) / model.decoder_future(ins, z) of generative_functions.py:39)."""
         s, H, F, T, FS = self.spec, self.spec.H, self.spec.F, self.spec.T, self.spec.FS
@@ -555,6 +560,10 @@ class VAEEngine:
         self._gru_fwd(rows, B)
         H, Hf = s.Hd, s.Hf
         pred = None
+        self._heads_deferred = not heads
+        self._dY_ready = False
+        if not heads:          # loss() runs the fused output heads (ops.head_fused): prediction, loss, dpred and dY in one pass over Y
+            return self.buf("pred", B, T, F) if want_d else None, self.buf("futp", B, FS, F) if want_f else None
         if want_d:
             pred = self.buf("pred", B, T, F)
             Kd = len(self.dec) * H             # H for the uni-directional legacy decoder: only the first half of each Y row
@@ -580,7 +589,7 @@ class VAEEngine:
         ops.nuclear(G, Z, kloss, B, klmbda, bsize, self.buf("losses", 8), LOSS_KMEANS, self.buf("Minv", Z, Z), gscale=kl_weight,
                     vstate=self._nuc_state)
 
-    def forward(self, win, win_row, B, eps, training, cluster=None, enc_in=None, drop_mask=None):
+    def forward(self, win, win_row, B, eps, training, cluster=None, enc_in=None, drop_mask=None, defer_heads=False):
         """Full RNN_VAE.forward (rnn_model.py:162-179).  Returns workspace views pred, fut, z, mu, logvar.
         cluster = (kl_weight, kloss, klmbda, bsize) also evaluates the nuclear-norm loss as soon as z exists.
         enc_in (B,T,F contiguous) replaces the first T steps of `win` as the encoder input (input-noise option)."""
@@ -591,7 +600,7 @@ class VAEEngine:
         if cluster is not None:
             self.cluster_terms(B, *cluster)
         self._cluster_done = cluster is not None
-        pred, fut = self.decode(z, B, training)
+        pred, fut = self.decode(z, B, training, heads=not (defer_heads and training and self._heads_fusable()))
         self._B = B
         self._win, self._win_row, self._eps = xin, xin_row, eps
         sh = lambda t, *shape: t[:_numel(shape)].view(*shape)
@@ -599,17 +608,37 @@ class VAEEngine:
                 sh(logvar, B, s.Z))
 
     # ------------------------------------------------------------------ loss (fused fwd + grad seeds)
+    def _heads_fusable(self):
+        s = self.spec
+        return (self.fuse_heads and ops.head_fused_ok(s.F, len(self.dec) * s.Hd) and (not s.future or ops.head_fused_ok(s.F, 2 * s.Hf)))
+
+    def _head(self, tag, name, dirs, steps, B, tgt, tgt_off, tgt_row, gscale, pred, dpred, losses, slot):
+        """One decoder's output head on the training path: hidden_to_output, MSE(sum), dpred and dY = dpred W in one kernel."""
+        H, F = dirs[0].H, self.spec.F
+        Ko = len(dirs) * H
+        Y = self.buf(f"Y_{tag}", B, steps + 2, 2 * H)
+        ops.head_fused(Operand(Y, 2 * H, off=2 * H, seg=steps, seg_stride=(steps + 2) * 2 * H), B * steps, F, Ko,
+                       self.P(f"{name}.hidden_to_output.weight", Ko), self._pv(f"{name}.hidden_to_output.bias"), tgt, tgt_off, tgt_row, gscale,
+                       pred, dpred, self.buf(f"dY_{tag}", B, steps, 2 * H), 2 * H, losses, slot)
+
     def loss(self, B, tgt, tgt_row, fut_tgt_off, kl_weight, kloss, klmbda, bsize, mse_red="sum", mse_pred="sum", with_future=True):
         """rnn_vae.py:124-129.  Fills losses[REC,FUT,KLSUM,KMEANS] and the gradient seeds dpred/dfut/Minv."""
         s, T, F, FS, Z = self.spec, self.spec.T, self.spec.F, self.spec.FS, self.spec.Z
         losses = self.buf("losses", 8)
         dpred = self.buf("dpred", B, T, F)
         sc = 2.0 if mse_red == "sum" else 2.0 / (B * T * F)
-        ops.mse_fwd_bwd(self.buf("pred", B, T, F), tgt, 0, tgt_row, B, T * F, sc, dpred, losses, LOSS_REC)
+        if self._heads_deferred:
+            self._head("dec", "decoder", self.dec, T, B, tgt, 0, tgt_row, sc, self.buf("pred", B, T, F), dpred, losses, LOSS_REC)
+        else:
+            ops.mse_fwd_bwd(self.buf("pred", B, T, F), tgt, 0, tgt_row, B, T * F, sc, dpred, losses, LOSS_REC)
         if s.future and with_future:
             dfut = self.buf("dfut", B, FS, F)
             sc = 2.0 if mse_pred == "sum" else 2.0 / (B * FS * F)
-            ops.mse_fwd_bwd(self.buf("futp", B, FS, F), tgt, fut_tgt_off, tgt_row, B, FS * F, sc, dfut, losses, LOSS_FUT)
+            if self._heads_deferred:
+                self._head("fut", "decoder_future", self.fut, FS, B, tgt, fut_tgt_off, tgt_row, sc, self.buf("futp", B, FS, F), dfut, losses, LOSS_FUT)
+            else:
+                ops.mse_fwd_bwd(self.buf("futp", B, FS, F), tgt, fut_tgt_off, tgt_row, B, FS * F, sc, dfut, losses, LOSS_FUT)
+        self._dY_ready = self._heads_deferred and (not s.future or with_future)
         if not getattr(self, "_cluster_done", False):
             self.cluster_terms(B, kl_weight, kloss, klmbda, bsize)
         self._cluster_done = False
@@ -655,7 +684,8 @@ class VAEEngine:
         dY = self.buf(f"dY_{tag}", B, steps, 2 * H)
         wo = f"{name}.hidden_to_output.weight"
         Ko = len(dirs) * H
-        ops.gemm(B * steps, Ko, F, Operand(dpred, F), 0, self.P(wo, Ko), 1, dY, 2 * H)
+        if not getattr(self, "_dY_ready", False):             # (the fused head of loss() already wrote dY)
+            ops.gemm(B * steps, Ko, F, Operand(dpred, F), 0, self.P(wo, Ko), 1, dY, 2 * H)
         self._gemm_wgrad(F, Ko, B * steps, Operand(dpred, F), Yrows, wo)
         ops.colsum(dpred, 0, B * steps, F, F, self.g, t.off(f"{name}.hidden_to_output.bias"))
         dhid = self.buf(f"dhid_{tag}", B, 2 * H) if self.h0_from_z else None

@@ -322,7 +322,7 @@ class RNN_VAE(nn.Module):
                 enc_in = enc_in.to(device=eng.dev, dtype=torch.float32).contiguous()
                 _check(tuple(enc_in.shape) == (B, s.T, F), f"enc_in {tuple(enc_in.shape)} != {(B, s.T, F)}")
             eng.forward(win, L * F, B, eps, training, cluster=(kl_weight, kloss, klmbda, bsize), enc_in=enc_in,
-                        drop_mask=self._dropout_mask(B, drop_mask, eng.dev))
+                        drop_mask=self._dropout_mask(B, drop_mask, eng.dev), defer_heads=True)
             # test(): no future term (rnn_vae.py:183-198)
             losses = eng.loss(B, win, L * F, s.T * F, kl_weight, kloss, klmbda, bsize, mse_red, mse_pred,
                               with_future=training and s.future)

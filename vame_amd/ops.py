@@ -302,6 +302,19 @@ def mse_fwd_bwd(pred, target, tgt_off, tgt_row, B, TF, gscale, dpred, loss_out, 
     _lib.check(rc, "vame_mse_fwd_bwd_f32")
 
 
+def head_fused_ok(F, K):
+    """Whether the fused output head covers this Linear (F outputs from K state columns)."""
+    return 1 <= F <= 32 and K >= 32 and K % 32 == 0 and int(_lib.lib().vame_head_fused_lds_bytes(F, K)) <= 160 * 1024
+
+
+def head_fused(Y, M, F, K, W, bias, tgt, tgt_off, tgt_row, gscale, pred, dpred, dY, dy_ld, loss_out, loss_off):
+    """Y: Operand over the decoder states (two-level rows (b,t): seg = T, seg_stride); W: Operand (F x K); see vame_head_fused_f32."""
+    rc = _lib.lib().vame_head_fused_f32(_ptr(Y.t, Y.off), Y.ld, Y.seg, Y.seg_stride, M, F, K, _ptr(W.t, W.off), _ptr(bias), _ptr(tgt),
+                                        tgt_row, tgt_off, float(gscale), _ptr(pred), _ptr(dpred), _ptr(dY), dy_ld, _ptr(loss_out, loss_off),
+                                        _stream())
+    _lib.check(rc, "vame_head_fused_f32")
+
+
 def nuclear_state_doubles(Z):
     return int(_lib.lib().vame_nuclear_state_doubles(int(Z)))
 
