@@ -92,3 +92,25 @@ def test_cpu_tensors_rejected_by_product_path():
         _lib._lib = None
         if was_installed:
             harness.install()
+
+
+def test_bench_quotes_pmc_traffic_only_for_the_same_kernel_sources(tmp_path, monkeypatch):
+    """bench.py's roofline.traffic comes from a committed rocprofv3 summary only if that summary carries the source id compiled into
+    the library that is running (vame_source_id()); another build's number is not quoted."""
+    import importlib
+    import json
+    import sys
+    sys.path.insert(0, ROOT)
+    bench = importlib.import_module("bench")
+    key = "gemm_kernel TN M=768 N=256 K=122880 x6 grouped"
+    prof = tmp_path / "profiles"
+    prof.mkdir()
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    monkeypatch.setattr(bench, "lib_source_id", lambda: "abc123")
+    (prof / "r09_pmc_hbm_traffic.json").write_text(json.dumps({"source_id": "other", "by_bench_key": {key: {"hbm_bytes_per_launch_corrected": 1}}}))
+    assert bench.pmc_traffic(key) is None
+    (prof / "r10_pmc_hbm_traffic.json").write_text(json.dumps({"source_id": "abc123", "by_bench_key": {key: {"hbm_bytes_per_launch_corrected": 42}}}))
+    assert bench.pmc_traffic(key) == 42
+    assert bench.pmc_traffic("some other kernel") is None
+    monkeypatch.setattr(bench, "lib_source_id", lambda: "unidentified")
+    assert bench.pmc_traffic(key) is None
