@@ -9,10 +9,14 @@ This file restates its published algorithm -- hmmlearn 0.2.8, `hmmlearn/base.py`
 `hmmlearn/stats.py` (`_log_multivariate_normal_density_full`) and `hmmlearn/_hmmc.pyx` (`_viterbi`) -- in plain numpy float64,
 log domain, exactly as hmmlearn computes it.
 
-PARITY UNPINNED: there is no hmmlearn in the container to generate golden vectors from, and the reference ships none.
-The anchors are (a) this restatement, (b) properties every correct Baum-Welch / Viterbi implementation has (monotone
-log-likelihood, posteriors summing to one, Viterbi path score >= any other path's) and (c) the reference's call site
-(constructor arguments, fit-then-predict on the concatenated latents).  Only tests/ may import this module.
+PARITY UNPINNED against hmmlearn itself: there is no hmmlearn in the container to generate golden vectors from, and the reference
+ships none.  What IS pinned (tests/test_oracle.py::test_hmm_oracle_vs_exhaustive_enumeration): the density against
+scipy.stats.multivariate_normal; likelihood, state posteriors, expected transition counts and the Viterbi path against a brute-force
+enumeration of all K^N state paths of tiny chains (no recursion shared with this file); the M step against its closed forms with
+hmmlearn 0.2.8's published prior defaults.  Not pinned: that those defaults (covars_prior 1e-2, covars_weight 1, tol 1e-2, k-means
+initialisation of the means, min_covar 1e-3) are the ones the installed hmmlearn of a user would apply -- they are restated from
+the published source, as is the reference's call site (constructor arguments, fit-then-predict on the concatenated latents).
+Only tests/ (and tools/hmm_bench.py's CPU leg) import this module.
 """
 import numpy as np
 from scipy import linalg

@@ -188,3 +188,57 @@ def test_model_options_dropout_and_hidden_sizes(name):
     ep, ef, ez, emu, elv = vo.model_forward(p, g["x"], None, spec, training=False, drop_mask=mask)     # eval: no dropout
     np.testing.assert_allclose(emu, g["eval_mu"], atol=1e-5)
     np.testing.assert_allclose(ep, g["eval_pred"], atol=2e-5)
+
+
+@pytest.mark.parametrize("K,N,D,seed", [(2, 6, 2, 0), (3, 5, 1, 1), (2, 7, 3, 2)])
+def test_hmm_oracle_vs_exhaustive_enumeration(K, N, D, seed):
+    """hmmlearn is not available to pin oracle/hmm_oracle.py against, so its recursions are pinned against the definition instead: on a
+    tiny chain every one of the K^N state paths is enumerated -- likelihood, state posteriors, expected transition counts and the best
+    path follow by brute force, with no recursion shared with the restatement."""
+    import itertools
+    from scipy.special import logsumexp
+    from oracle import hmm_oracle as ho
+    rng = np.random.default_rng(seed)
+    X = rng.standard_normal((N, D))
+    o = ho.GaussianHMMOracle(K)
+    o.startprob_ = rng.dirichlet(np.ones(K))
+    o.transmat_ = rng.dirichlet(np.ones(K), size=K)
+    o.means_ = rng.standard_normal((K, D))
+    A = rng.standard_normal((K, D, D))
+    o.covars_ = A @ A.transpose(0, 2, 1) + 0.5 * np.eye(D)
+    logB = ho.log_mvn_density_full(X, o.means_, o.covars_)
+    # the density itself against scipy's multivariate normal
+    from scipy.stats import multivariate_normal
+    for k in range(K):
+        np.testing.assert_allclose(logB[:, k], multivariate_normal(o.means_[k], o.covars_[k]).logpdf(X).reshape(N), rtol=1e-10, atol=1e-10)
+    paths = list(itertools.product(range(K), repeat=N))
+    lp = np.array([np.log(o.startprob_[p[0]]) + logB[0, p[0]] + sum(np.log(o.transmat_[p[t - 1], p[t]]) + logB[t, p[t]] for t in range(1, N))
+                   for p in paths])
+    logL = logsumexp(lp)
+    w = np.exp(lp - logL)                                            # posterior of every path
+    gamma = np.zeros((N, K)); xi = np.zeros((K, K))
+    for p, wp in zip(paths, w):
+        for t in range(N):
+            gamma[t, p[t]] += wp
+        for t in range(1, N):
+            xi[p[t - 1], p[t]] += wp
+    logprob, stats, post = o.e_step(X)
+    np.testing.assert_allclose(logprob, logL, rtol=1e-12)
+    np.testing.assert_allclose(post, gamma, atol=1e-12)
+    np.testing.assert_allclose(stats["trans"], xi, atol=1e-12)
+    np.testing.assert_allclose(stats["obs"], gamma.T @ X, atol=1e-12)
+    np.testing.assert_allclose(o.score(X), logL, rtol=1e-12)
+    vlp, vpath = ho.viterbi_log(np.log(o.startprob_), np.log(o.transmat_), logB)
+    best = int(np.argmax(lp))
+    np.testing.assert_allclose(vlp, lp[best], rtol=1e-12)
+    assert tuple(int(v) for v in vpath) == paths[best]
+    # one M step: the closed forms with hmmlearn 0.2.8's priors (means_weight 0, covars_prior 1e-2, covars_weight 1 -> max(1 - D, 0) = 0)
+    o.m_step(stats)
+    np.testing.assert_allclose(o.startprob_, gamma[0] / gamma[0].sum(), atol=1e-12)
+    np.testing.assert_allclose(o.transmat_, xi / xi.sum(1, keepdims=True), atol=1e-12)
+    mu = (gamma.T @ X) / gamma.sum(0)[:, None]
+    np.testing.assert_allclose(o.means_, mu, atol=1e-12)
+    for k in range(K):
+        d = X - mu[k]
+        cv = (1e-2 + (gamma[:, k, None, None] * (d[:, :, None] * d[:, None, :])).sum(0)) / gamma[:, k].sum()
+        np.testing.assert_allclose(o.covars_[k], cv, atol=1e-10)
