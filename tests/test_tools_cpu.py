@@ -1,0 +1,38 @@
+"""The profile pipeline (tools/rocprof_digest.py) on synthetic rocprofv3 CSVs: the files under profiles/ are what the roofline numbers
+are checked against, so the digest itself is tested."""
+import csv
+import os
+import subprocess
+import sys
+
+from conftest import ROOT
+
+DIGEST = os.path.join(ROOT, "tools", "rocprof_digest.py")
+
+
+def _write(path, header, rows):
+    os.makedirs(os.path.dirname(path), exist_ok=True)
+    with open(path, "w", newline="") as fh:
+        w = csv.writer(fh)
+        w.writerow(header)
+        w.writerows(rows)
+
+
+def test_kernel_trace_digest_separates_launches_of_one_kernel_by_grid(tmp_path):
+    hdr = ["Kind", "Kernel_Name", "Start_Timestamp", "End_Timestamp", "Grid_Size_X", "Grid_Size_Y", "Grid_Size_Z", "Workgroup_Size_X"]
+    g = "void gemm_kernel<128, 128, 2, 2, true, true, 5, 2>(GemmParams)"
+    rows = [["KERNEL_DISPATCH", g, 1000, 3500, 589824, 1, 1, 256],                       # the grouped launch: 2.5 us here
+            ["KERNEL_DISPATCH", g, 4000, 4400, 393216, 1, 1, 256],
+            ["KERNEL_DISPATCH", "void gru_seq_bwd_kernel<256, 0>(GruBwdParams)", 5000, 6000, 131072, 1, 1, 512],
+            ["KERNEL_DISPATCH", g, 7000, 9700, 589824, 1, 1, 256]]
+    _write(str(tmp_path / "raw" / "pid" / "1_kernel_trace.csv"), hdr, rows)
+    out_t, out_s = str(tmp_path / "trace.csv"), str(tmp_path / "stats.csv")
+    subprocess.run([sys.executable, DIGEST, "trace", str(tmp_path / "raw"), out_t], check=True, capture_output=True)
+    subprocess.run([sys.executable, DIGEST, "stats", str(tmp_path / "raw"), out_s], check=True, capture_output=True)
+    tr = list(csv.DictReader(open(out_t)))
+    assert [r["kernel"] for r in tr] == ["gemm_kernel<128,128,2,2,true,true,5,2>"] * 2 + ["gru_seq_bwd_kernel<256,0>", "gemm_kernel<128,128,2,2,true,true,5,2>"]
+    assert [float(r["start_us"]) for r in tr] == [0.0, 3.0, 4.0, 6.0] and [float(r["duration_us"]) for r in tr] == [2.5, 0.4, 1.0, 2.7]
+    st = {(r["kernel"], int(r["grid_threads"])): r for r in csv.DictReader(open(out_s))}
+    big = st[("gemm_kernel<128,128,2,2,true,true,5,2>", 589824)]
+    assert int(big["calls"]) == 2 and float(big["avg_us"]) == 2.6 and float(big["min_us"]) == 2.5 and float(big["max_us"]) == 2.7
+    assert int(st[("gemm_kernel<128,128,2,2,true,true,5,2>", 393216)]["calls"]) == 1

@@ -8,8 +8,9 @@
   pmc    <fetch_dir> <write_dir> <lib.so> <out.json> [--key "<bench key>=><kernel substring>@<grid>"]...
                                     HBM traffic per call from two separate --pmc passes (FETCH_SIZE, WRITE_SIZE; KB units),
                                     corrected as MI355X_MICROARCH.md prescribes (gfx950 FETCH_SIZE reports 1/2 of wide coalesced
-                                    reads -> x2); stores the sha256 of the library the counters were taken with, and the
-                                    traffic of the launches bench.py names (`by_bench_key`) for its roofline.traffic field.
+                                    reads -> x2); stores `vame_source_id()` of the library the counters were taken with (the sha256
+                                    of its kernel sources) and the traffic of the launches bench.py names (`by_bench_key`) for
+                                    its roofline.traffic field.
 """
 import csv
 import glob
