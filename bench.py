@@ -4,18 +4,25 @@
     python bench.py [--gpus N] [--steps K] [--warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
+`python bench.py --gpus N` without a torchrun environment launches the N ranks itself (re-exec under
+torch.distributed.run, 127.0.0.1 rendezvous); it never falls back to fewer ranks than asked for.
+
 A "step" is one pass of the hot path over one batch of synthetic temporal windows: window gather
 (sliding-window batcher) -> RNN-VAE forward -> MSE + future-MSE + KL + nuclear-norm loss -> BPTT
 -> one RCCL all-reduce of the flat gradient bucket (N > 1) -> fused Adam-AMSGrad.  Workload =
-BASELINE.json config 2: T=30, F=24, H=256, Z=30, FS=15, batch 4096 windows per GPU, fp32.
+BASELINE.json configs[1]: T=30, F=24, H=256, Z=30, FS=15, batch 4096 windows per GPU, fp32.
 The series is already resident in HBM when the timed region starts.
 
 Prints ONE JSON line (rank 0): metric/value/unit + roofline (dominant kernel, measured with HIP
-events on the launch stream) + cpu_baseline (reference-equivalent torch-CPU model, oracle/torch_ref.py).
+events on the launch stream; HBM-bound kernels of the step next to it) + cpu_baseline
+(reference-equivalent torch-CPU model, oracle/torch_ref.py) + `repeat_spread` (two more timed regions
+of the same length) + `also` (N = 1: BASELINE configs[3] shape and a configs[4]-shape embedding pass,
+each with its own roofline) + `distributed` (N > 1: proof of the RCCL path and a same-run 1-rank leg).
 """
 import argparse
 import json
 import os
+import socket
 import sys
 import time
 
@@ -26,12 +33,19 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
-T, F, Z, H, FS = 30, 24, 30, 256, 15
-B_LOCAL = 4096
+F, Z, FS = 24, 30, 15
 N_SERIES = 1_000_000
-MFLOP_PER_WINDOW_TRAIN = 400.343          # matmul flops, 2/MAC, bwd = 2x fwd, decoder input projection once
 PEAK_F32_MFMA_TFLOPS = 157.3              # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 PEAK_HBM_GBS = 8000.0
+MFLOP_PER_WINDOW_EMBED = 96.707           # encoder + Lambda mean, H=256, T=30
+
+
+def train_mflop_per_window(H, T):
+    """matmul flops, 2/MAC, bwd = 2x fwd, decoder input projection once (400.343 at H=256,T=30; 3012.526 at 512/60)."""
+    fwd = 2 * T * 2 * 3 * H * (F + H) + 2 * T * 2 * 3 * H * (2 * H + H) + 2 * 2 * 4 * H * Z         # encoder L0 + L1, Lambda
+    for st in (T, FS):                                                                             # decoder, future decoder
+        fwd += 2 * Z * 2 * H + 2 * 2 * 3 * H * Z + 2 * st * 2 * 3 * H * H + 2 * st * 2 * H * F
+    return 3 * fwd / 1e6
 
 
 def synth_series(n, seed=0):
@@ -41,13 +55,32 @@ def synth_series(n, seed=0):
     return ((X - X.mean()) / X.std()).astype(np.float32)
 
 
+def free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def self_launch(args):
+    """--gpus N > 1 outside a torchrun environment: become `python -m torch.distributed.run --nproc-per-node N ... bench.py <same args>`
+    (one process per GPU, RCCL).  VAME_BENCH_LAUNCHER (tests only) names a wrapper script that is run in place of bench.py and
+    receives bench.py as its first argument -- the CPU test-suite passes its emulator harness there."""
+    wrapper = os.environ.get("VAME_BENCH_LAUNCHER")
+    script = [wrapper, os.path.abspath(__file__)] if wrapper else [os.path.abspath(__file__)]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port())] + script + sys.argv[1:]
+    sys.stdout.flush()
+    os.execv(sys.executable, cmd)
+
+
+# ------------------------------------------------------------------------------------------------ per-kernel timing (HIP events)
 class KernelTimer:
     """HIP-event timing of each C-ABI launch group on the stream it is launched on (torch's current stream)."""
 
     def __init__(self):
         self.records = []
 
-    def wrap(self, ops_mod, name, flops_fn):
+    def wrap(self, ops_mod, name, work_fn):
         inner = getattr(ops_mod, name)
 
         def timed(*a, **k):
@@ -55,7 +88,7 @@ class KernelTimer:
             e0.record()
             r = inner(*a, **k)
             e1.record()
-            self.records.append((name, flops_fn(*a, **k), e0, e1))
+            self.records.append((name, work_fn(*a, **k), e0, e1))
             return r
         setattr(ops_mod, name, timed)
         return inner
@@ -63,23 +96,24 @@ class KernelTimer:
     def summary(self):
         torch.cuda.synchronize()
         agg = {}
-        for name, (key, flops), e0, e1 in self.records:
-            d = agg.setdefault(key, dict(api=name, launches=0, ms=0.0, flops=0.0))
+        for name, (key, work), e0, e1 in self.records:
+            d = agg.setdefault(key, dict(api=name, launches=0, ms=0.0, work=0.0))
             d["launches"] += 1
             d["ms"] += e0.elapsed_time(e1)
-            d["flops"] += flops
+            d["work"] += work
         return agg
 
 
-def profile_kernels(model, loader, steps=3):
-    """Per-kernel-class time + algorithmic flops over `steps` train steps (separate from the timed region)."""
+def profile_kernels(model, loader, B, steps=3):
+    """Per-kernel-class time + algorithmic flops (MFMA classes) or algorithmic HBM bytes (gather / mse / timesum) over `steps` train
+    steps, separate from the timed region."""
     from vame_amd import ops
     kt = KernelTimer()
 
     def gru_flops(tag):
-        def f(streams, B, Hh):
+        def f(streams, B_, Hh):
             key_t = ops.GF["T"] if tag == "fwd" else ops.GB["T"]
-            fl = sum(2.0 * 3 * Hh * Hh * B * int(s[key_t]) for s in streams)
+            fl = sum(2.0 * 3 * Hh * Hh * B_ * int(s[key_t]) for s in streams)
             name = "gru_seq" if Hh <= 256 else "gru_wide"
             return (f"{name}_{tag}_kernel<{Hh}> x{len(streams)} streams", fl)
         return f
@@ -87,16 +121,29 @@ def profile_kernels(model, loader, steps=3):
     def gemm_flops(M, N, K, A, akm, Bm, bkm, *a, **k):
         kind = "NT" if (not akm and not bkm) else ("NN" if not akm else "TN")
         return (f"gemm_kernel {kind} M={M} N={N} K={K}", 2.0 * M * N * K)
+
     def group_flops(M, N, K, As, akm, Bs, bkm, *a, **k):
         kind = "NT" if (not akm and not bkm) else ("NN" if not akm else "TN")
         return (f"gemm_kernel {kind} M={M} N={N} K={K} x{len(As)} grouped", 2.0 * M * N * K * len(As))
+
+    # HBM-bound kernels: algorithmic bytes = every element read once + every element written once
+    def gather_bytes(X, N, F_, starts, start0, B_, L, out):
+        return ("hbm window_gather_kernel", 2.0 * 4 * B_ * L * F_)
+
+    def mse_bytes(pred, target, tgt_off, tgt_row, B_, TF, *a, **k):
+        return ("hbm mse_kernel", 3.0 * 4 * B_ * TF)                       # prediction + target in, dpred out
+
+    def timesum_bytes(inp, B_, T_, C, ld, out):
+        return ("hbm timesum_kernel", 4.0 * B_ * C * (T_ + 1))             # C of ld columns of every (b, t) row in, (B, C) out
+
     saved = {n: kt.wrap(ops, n, fn) for n, fn in (("gru_seq_fwd", gru_flops("fwd")), ("gru_seq_bwd", gru_flops("bwd")),
                                                   ("gru_wide_fwd", gru_flops("fwd")), ("gru_wide_bwd", gru_flops("bwd")),
-                                                  ("gemm", gemm_flops), ("gemm_group", group_flops))}
+                                                  ("gemm", gemm_flops), ("gemm_group", group_flops),
+                                                  ("window_gather", gather_bytes), ("mse_fwd_bwd", mse_bytes), ("timesum", timesum_bytes))}
     try:
         for _ in range(steps):
             win = loader.gather(loader.draw_starts())
-            model.loss_step(win, 1.0, beta=1.0, kloss=Z, klmbda=0.1, bsize=B_LOCAL)
+            model.loss_step(win, 1.0, beta=1.0, kloss=Z, klmbda=0.1, bsize=B)
         agg = kt.summary()
     finally:
         for n, fn in saved.items():
@@ -104,48 +151,40 @@ def profile_kernels(model, loader, steps=3):
     for d in agg.values():
         d["launches"] /= steps
         d["ms"] /= steps
-        d["flops"] /= steps
+        d["work"] /= steps
     return agg
 
 
-def bench_embed(args, dev, rank, world):
-    """Encoder-only latent embedding of a synthetic series, window index range sharded over ranks (no collective)."""
-    from vame_amd.analysis.pose_segmentation import embed_series
-    from vame_amd.model.rnn_model import RNN_VAE
-    model = RNN_VAE(2 * T, Z, F, 1, FS, H, H, H, H, 0, 0, 0, False).to(dev).eval()
-    n_win = args.embed_windows * world
-    data = synth_series(n_win + T)
-    embed_series(model, data[:, :70000], batch=16384)                      # warm-up (allocations, clocks)
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    out, (lo, hi) = embed_series(model, data, batch=16384, rank=rank, world=world)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
-    assert torch.isfinite(out).all()
-    if rank == 0:
-        value = n_win / dt
-        out = dict(metric="latent-embedding windows/sec (encoder + Lambda mean) T=30,F=24,h=256", value=round(value, 1),
-                   unit="windows/s", n_gpus=world, higher_is_better=True, scaling="weak", dtype="f32", data="synthetic",
-                   seconds=round(dt, 3), includes="host->device upload of the series + window gather + encoder + mean",
-                   config=dict(workload=f"BASELINE.json configs[4] shape: {args.embed_windows} stride-1 windows per GPU, batch 16384",
-                               parallelism=f"shard{world}"),
-                   roofline=dict(bound="mfma", unit="TFLOP/s", peak=PEAK_F32_MFMA_TFLOPS,
-                                 achieved=round(value / world * 96.707e6 / 1e12, 2),
-                                 frac=round(value / world * 96.707e6 / 1e12 / PEAK_F32_MFMA_TFLOPS, 4), traffic=None))
-        if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline_embed()
-        print(json.dumps(out))
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+def roofline_block(agg, value_per_gpu, mflop_per_window, ms_per_step, dump=False):
+    mf = {k: d for k, d in agg.items() if not k.startswith("hbm ")}
+    hb = {k: d for k, d in agg.items() if k.startswith("hbm ")}
+    mfma_ms = sum(d["ms"] for d in mf.values())
+    if dump:
+        for k, d in sorted(agg.items(), key=lambda kv: -kv[1]["ms"]):
+            unit = "GB/s" if k.startswith("hbm ") else "TF"
+            rate = d["work"] / max(d["ms"], 1e-9) / (1e6 if k.startswith("hbm ") else 1e9)
+            print(f"{k:60s} x{d['launches']:4.0f} {d['ms']*1e3:9.1f} us/step {rate:8.1f} {unit}", file=sys.stderr)
+    dom_key = max(mf, key=lambda k: mf[k]["ms"])
+    dom = mf[dom_key]
+    per_launch_ms = dom["ms"] / dom["launches"]
+    achieved = dom["work"] / dom["launches"] / (per_launch_ms * 1e-3) / 1e12
+    classes = {}
+    for k, d in mf.items():
+        c = k.split(" ")[0] + (" " + k.split(" ")[1] if k.startswith("gemm") else "")
+        e = classes.setdefault(c, dict(ms=0.0, work=0.0))
+        e["ms"] += d["ms"]
+        e["work"] += d["work"]
+    by_class = {c: dict(ms_per_step=round(e["ms"], 3), tflops=round(e["work"] / (e["ms"] * 1e-3) / 1e12, 2)) for c, e in classes.items()}
+    for k, d in hb.items():                       # the bandwidth-bound kernels of the step against the 8 TB/s HBM roofline
+        gbs = d["work"] / (d["ms"] * 1e-3) / 1e9
+        by_class[k[4:]] = dict(bound="hbm", ms_per_step=round(d["ms"], 4), launches_per_step=d["launches"],
+                               algorithmic_mb_per_step=round(d["work"] / 1e6, 2), gbs=round(gbs, 1), frac=round(gbs / PEAK_HBM_GBS, 4))
+    return dict(bound="mfma", kernel=dom_key, achieved=round(achieved, 3), peak=PEAK_F32_MFMA_TFLOPS, unit="TFLOP/s",
+                frac=round(achieved / PEAK_F32_MFMA_TFLOPS, 4), traffic=pmc_traffic(dom_key),
+                launch_ms=round(per_launch_ms, 4), launches_per_step=dom["launches"],
+                step_frac=round(value_per_gpu * mflop_per_window * 1e6 / (PEAK_F32_MFMA_TFLOPS * 1e12), 4),
+                by_class=by_class, timed_kernel_ms_per_step=round(sum(d["ms"] for d in agg.values()), 3),
+                mfma_kernel_ms_per_step=round(mfma_ms, 3), non_mfma_ms_per_step=round(ms_per_step - mfma_ms, 3))
 
 
 def lib_source_id():
@@ -155,10 +194,10 @@ def lib_source_id():
 
 
 def pmc_traffic(dom_key):
-    """HBM bytes per launch of the dominant kernel from a committed rocprofv3 PMC summary (tools/pmc_summary.py: FETCH_SIZE x2 +
+    """HBM bytes per launch of a kernel from a committed rocprofv3 PMC summary (tools/rocprof_digest.py pmc: FETCH_SIZE x2 +
     WRITE_SIZE in separate --pmc passes, corrected as MI355X_MICROARCH.md prescribes) -- but only from a summary that was
-    collected with a libvame_hip.so built from THESE kernel sources (vame_source_id(), stored in the summary); None otherwise: a number measured on an
-    older kernel says nothing about the current one."""
+    collected with a libvame_hip.so built from THESE kernel sources (vame_source_id(), stored in the summary); None otherwise: a
+    number measured on an older kernel says nothing about the current one."""
     import glob
     sha = lib_source_id()
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_hbm_traffic*.json")), reverse=True):
@@ -175,6 +214,7 @@ def pmc_traffic(dom_key):
     return None
 
 
+# ------------------------------------------------------------------------------------------------ CPU baselines (oracle/torch_ref.py)
 def _cpu_subprocess(fn_call, threads, timeout):
     """Run `oracle.torch_ref.<fn_call>` in a subprocess (own thread pool, hard time limit) and return its dict."""
     import subprocess
@@ -208,6 +248,8 @@ def cpu_baseline():
     if best is not None:
         best["host_cpus_visible"] = avail
         best["thread_counts_tried"] = tried
+        best["note"] = ("cores = the thread count at which stock torch-CPU runs this model fastest on this host (its nn.GRU stops "
+                        "scaling around 16 threads; the larger count is probed and listed), not a choice to use few cores")
         return best
     return dict(value=None, unit="windows/s", cores=0, kind="port", sample="timed out on this host")
 
@@ -235,76 +277,27 @@ def cpu_baseline_embed():
                 host_cpus_visible=avail)
 
 
-def main():
-    global B_LOCAL, H, T, MFLOP_PER_WINDOW_TRAIN
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--batch", type=int, default=B_LOCAL)
-    ap.add_argument("--dump-kernels", action="store_true", help="per-launch-group table on stderr")
-    ap.add_argument("--mode", choices=["train", "embed"], default="train",
-                    help="train = the headline metric; embed = encoder-only embedd_latent_vectors sweep (BASELINE config 5)")
-    ap.add_argument("--embed-windows", type=int, default=2_000_000)
-    ap.add_argument("--hidden", type=int, default=H, help="exploration only (BASELINE config 4 uses 512)")
-    ap.add_argument("--time-window", type=int, default=T, help="exploration only (BASELINE config 4 uses 60)")
-    args = ap.parse_args()
+# ------------------------------------------------------------------------------------------------ legs
+class _SynthDataset:
+    """Synthetic stand-in for SEQUENCE_DATASET: an already z-scored (F, N) series."""
+    data_points = N_SERIES
+    X = np.empty((F, 1))
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    from vame_amd import _lib
-    from vame_amd.model.rnn_vae import _maybe_init_distributed
-    dev = _lib.device(local)                         # raises without an MI355X: the measured path has no CPU fallback
-    on_gpu = dev.type == "cuda"                      # (False only under the CPU test-suite's harness, tests/emu/harness.py, which
-    sync = torch.cuda.synchronize if on_gpu else (lambda: None)      # checks the rank / JSON plumbing and measures nothing)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        _maybe_init_distributed()                    # one process per GPU: backend nccl (= RCCL over xGMI)
-    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    def __init__(self, T):
+        self.temporal_window = 2 * T
 
-    from vame_amd.model.dataloader import DeviceWindowLoader
-    from vame_amd.model.rnn_model import RNN_VAE
-    from vame_amd.model.rnn_vae import FusedAdamAMSGrad, allreduce_gradients
+    @staticmethod
+    def normalised_f32():
+        return synth_series(N_SERIES)
 
-    B_LOCAL = args.batch
-    if (args.hidden, args.time_window) != (H, T):          # non-headline shape: recompute the algorithmic flops per window
-        H, T = args.hidden, args.time_window
-        fwd = 2 * T * 2 * 3 * H * (F + H) + 2 * T * 2 * 3 * H * (2 * H + H) + 2 * 2 * 4 * H * Z     # encoder L0 + L1, Lambda
-        for st in (T, FS):                                                                         # decoder, future decoder
-            fwd += 2 * Z * 2 * H + 2 * 2 * 3 * H * Z + 2 * st * 2 * 3 * H * H + 2 * st * 2 * H * F
-        MFLOP_PER_WINDOW_TRAIN = 3 * fwd / 1e6
-    torch.manual_seed(19)
-    if args.mode == "embed":
-        return bench_embed(args, dev, rank, world)
-    model = RNN_VAE(2 * T, Z, F, 1, FS, H, H, H, H, 0, 0, 0, False).to(dev).train()
-    opt = FusedAdamAMSGrad(model, lr=5e-4)
 
-    class _DS:   # synthetic stand-in for SEQUENCE_DATASET: already z-scored (F,N) series
-        data_points, temporal_window = N_SERIES, 2 * T
-        X = np.empty((F, 1))
-
-        @staticmethod
-        def normalised_f32():
-            return synth_series(N_SERIES)
-    loader = DeviceWindowLoader(_DS, B_LOCAL, T + FS, dev, rank=0, world=1)
-    np.random.seed(1000 + rank)
-
-    def step():
-        win = loader.gather(loader.draw_starts())
-        terms = model.loss_step(win, 1.0, beta=1.0, kloss=Z, klmbda=0.1, bsize=B_LOCAL)
-        gs = allreduce_gradients(model)
-        opt.step(gscale=gs)
-        return terms
-
-    for _ in range(args.warmup):
-        terms = step()
+def timed_region(step, steps, world, sync, dev):
+    """EXACTLY `steps` steps bracketed by barrier + device sync on both sides; the MAX over ranks."""
     if world > 1:
         dist.barrier()
     sync()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         terms = step()
     sync()
     if world > 1:
@@ -314,47 +307,221 @@ def main():
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
+    return dt, terms
+
+
+def train_leg(dev, H, T, B, steps, warmup, rank, world, repeats=1, profile=True, dump=False, one_rank_leg=False):
+    """Build the model at (H, T), run `warmup` untimed + `repeats` timed regions of `steps` steps.  Returns a dict with the region
+    times, the last loss terms, the roofline block (GPU only) and -- several ranks -- the collective's own numbers."""
+    from vame_amd.model.dataloader import DeviceWindowLoader
+    from vame_amd.model.rnn_model import RNN_VAE
+    from vame_amd.model.rnn_vae import FusedAdamAMSGrad, allreduce_gradients
+    on_gpu = dev.type == "cuda"
+    sync = torch.cuda.synchronize if on_gpu else (lambda: None)
+    torch.manual_seed(19)
+    model = RNN_VAE(2 * T, Z, F, 1, FS, H, H, H, H, 0, 0, 0, False).to(dev).train()
+    opt = FusedAdamAMSGrad(model, lr=5e-4)
+    loader = DeviceWindowLoader(_SynthDataset(T), B, T + FS, dev, rank=0, world=1)
+    np.random.seed(1000 + rank)
+
+    def step(reduce=True):
+        win = loader.gather(loader.draw_starts())
+        terms = model.loss_step(win, 1.0, beta=1.0, kloss=Z, klmbda=0.1, bsize=B)
+        gs = allreduce_gradients(model) if reduce else 1.0
+        opt.step(gscale=gs)
+        return terms
+
+    for _ in range(warmup):
+        terms = step()
+    dts = []
+    for _ in range(repeats):
+        dt, terms = timed_region(step, steps, world, sync, dev)
+        dts.append(dt)
     last = [float(v) for v in terms.cpu()]
     assert all(np.isfinite(last)), f"non-finite loss terms {last}"
+    res = dict(dts=dts, last=last, mflop=train_mflop_per_window(H, T), roofline=None, distributed=None)
+    if world > 1:
+        res["distributed"] = collective_block(model, step, steps, rank, world, sync, dev, dts[0], one_rank_leg)
+    if profile and on_gpu and rank == 0:
+        agg = profile_kernels(model, loader, B)
+        res["roofline"] = roofline_block(agg, B * steps / dts[0], res["mflop"], dts[0] / steps * 1e3, dump)
+    del model, opt, loader
+    if on_gpu:
+        torch.cuda.empty_cache()
+    return res
 
-    if rank == 0:
-        value = B_LOCAL * world * args.steps / dt
-        roof = None
-        if on_gpu:
-            agg = profile_kernels(model, loader)
-            total_ms = sum(d["ms"] for d in agg.values())
-            if args.dump_kernels:
-                for k, d in sorted(agg.items(), key=lambda kv: -kv[1]["ms"]):
-                    print(f"{k:60s} x{d['launches']:4.0f} {d['ms']*1e3:9.1f} us/step {d['flops']/max(d['ms'],1e-9)/1e9:7.1f} TF", file=sys.stderr)
-            dom_key = max(agg, key=lambda k: agg[k]["ms"])
-            dom = agg[dom_key]
-            per_launch_ms = dom["ms"] / dom["launches"]
-            achieved = dom["flops"] / dom["launches"] / (per_launch_ms * 1e-3) / 1e12
-            classes = {}
-            for k, d in agg.items():
-                c = k.split(" ")[0] + (" " + k.split(" ")[1] if k.startswith("gemm") else "")
-                e = classes.setdefault(c, dict(ms=0.0, flops=0.0))
-                e["ms"] += d["ms"]
-                e["flops"] += d["flops"]
-            roof = dict(bound="mfma", kernel=dom_key, achieved=round(achieved, 3), peak=PEAK_F32_MFMA_TFLOPS, unit="TFLOP/s",
-                        frac=round(achieved / PEAK_F32_MFMA_TFLOPS, 4), traffic=pmc_traffic(dom_key),
-                        launch_ms=round(per_launch_ms, 4), launches_per_step=dom["launches"],
-                        step_frac=round(value / world * MFLOP_PER_WINDOW_TRAIN * 1e6 / (PEAK_F32_MFMA_TFLOPS * 1e12), 4),
-                        by_class={c: dict(ms_per_step=round(e["ms"], 3), tflops=round(e["flops"] / (e["ms"] * 1e-3) / 1e12, 2))
-                                  for c, e in classes.items()},
-                        timed_kernel_ms_per_step=round(total_ms, 3))
-        out = dict(metric=f"temporal windows/sec (train) T={T},F={F},h={H}", value=round(value, 1), unit="windows/s", n_gpus=world,
-                   steps=args.steps, warmup=args.warmup, ms_per_step=round(dt / args.steps * 1e3, 3), higher_is_better=True,
-                   scaling="weak", vs_baseline=None, dtype="f32", data="synthetic",
-                   config=dict(workload=((("BASELINE.json configs[1]" if (H, T, B_LOCAL) == (256, 30, 4096) else ("BASELINE.json configs[3]" if (H, T, B_LOCAL) == (512, 60, 8192) else "non-headline shape (BASELINE.json configs[3] is H=512,T=60,batch 8192)"))
-                                          if world == 1 else f"BASELINE.json configs[2] shape on {world} GPUs (data-parallel)")
-                                         + f": T={T},F={F},zdims={Z},hidden={H},FS={FS}, batch={B_LOCAL}/GPU fp32 train step "
-                                         "(gather+fwd+loss+bwd+allreduce+Adam-amsgrad)"), global_batch=B_LOCAL * world,
-                               parallelism=f"dp{world}", last_loss_terms=last),
-                   roofline=roof)
-        if not args.no_cpu_baseline and world == 1 and on_gpu:
-            out["cpu_baseline"] = cpu_baseline()
-        print(json.dumps(out))
+
+def collective_block(model, step, steps, rank, world, sync, dev, dt_n, one_rank_leg):
+    """Evidence that the N-rank line really went through the collective library: backend, library version, the all-reduce of the
+    real gradient bucket timed on its own, and a 1-rank leg of the same step in the same run (rank 0 alone, no all-reduce) for
+    the weak-scaling efficiency.  Every rank takes part in the collectives; rank 0 keeps the numbers."""
+    bucket = model._flat_g_comm
+    on_gpu = dev.type == "cuda"
+    for _ in range(3):
+        dist.all_reduce(bucket, op=dist.ReduceOp.SUM)
+    dist.barrier()
+    sync()
+    reps = 20
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        dist.all_reduce(bucket, op=dist.ReduceOp.SUM)
+    sync()
+    ar_us = (time.perf_counter() - t0) / reps * 1e6
+    tt = torch.tensor([ar_us], device=dev, dtype=torch.float64)
+    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    ar_us = float(tt.item())
+    nbytes = bucket.numel() * 4
+    out = dict(world_size=dist.get_world_size(), backend=dist.get_backend(), allreduce_bucket_bytes=nbytes,
+               allreduce_us=round(ar_us, 1), allreduce_algbw_gbs=round(nbytes / ar_us / 1e3, 2),
+               allreduce_busbw_gbs=round(nbytes / ar_us / 1e3 * 2 * (world - 1) / world, 2),
+               collective_library=(("RCCL (torch nccl backend) " + ".".join(str(v) for v in torch.cuda.nccl.version())) if on_gpu else "gloo (CPU test harness)"),
+               devices=[torch.cuda.get_device_name(i) for i in range(torch.cuda.device_count())] if on_gpu else [])
+    if one_rank_leg:
+        dist.barrier()
+        dt1 = None
+        if rank == 0:                                  # the other ranks wait in the barrier below with an idle GPU
+            step(reduce=False)
+            sync()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                step(reduce=False)
+            sync()
+            dt1 = time.perf_counter() - t0
+        dist.barrier()
+        if rank == 0:
+            out["one_rank_leg_ms_per_step"] = round(dt1 / steps * 1e3, 3)
+            out["weak_scaling_eff"] = round(dt1 / dt_n, 4)          # same per-GPU work: t(1 rank) / t(N ranks)
+    return out
+
+
+def embed_leg(dev, n_win_per_rank, rank, world, H=256, T=30):
+    """Encoder-only latent embedding of a synthetic series, window index range sharded over ranks (no collective on the data path)."""
+    from vame_amd.analysis.pose_segmentation import embed_series
+    from vame_amd.model.rnn_model import RNN_VAE
+    torch.manual_seed(19)
+    model = RNN_VAE(2 * T, Z, F, 1, FS, H, H, H, H, 0, 0, 0, False).to(dev).eval()
+    n_win = n_win_per_rank * world
+    data = synth_series(n_win + T)
+    embed_series(model, data[:, :70000], batch=16384)                      # warm-up (allocations, clocks)
+    if world > 1:
+        dist.barrier()
+    if dev.type == "cuda":
+        torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    out, (lo, hi) = embed_series(model, data, batch=16384, rank=rank, world=world)
+    if dev.type == "cuda":
+        torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    assert torch.isfinite(out).all()
+    value = n_win / dt
+    tf = value / world * MFLOP_PER_WINDOW_EMBED * 1e6 / 1e12
+    del model, out
+    if dev.type == "cuda":
+        torch.cuda.empty_cache()
+    return dict(metric="latent-embedding windows/sec (encoder + Lambda mean) T=30,F=24,h=256", value=round(value, 1), unit="windows/s",
+                n_gpus=world, seconds=round(dt, 3), windows=n_win,
+                includes="host->device upload of the series + window gather + encoder + mean",
+                config=dict(workload=f"BASELINE.json configs[4] shape: {n_win_per_rank} stride-1 windows per GPU, batch 16384",
+                            parallelism=f"shard{world}"),
+                roofline=dict(bound="mfma", unit="TFLOP/s", peak=PEAK_F32_MFMA_TFLOPS, achieved=round(tf, 2),
+                              frac=round(tf / PEAK_F32_MFMA_TFLOPS, 4),
+                              traffic=pmc_traffic("gru_seq_fwd_kernel<256> x2 streams embed") if dev.type == "cuda" else None))
+
+
+def workload_name(H, T, B, world):
+    if world > 1:
+        head = f"BASELINE.json configs[2] shape on {world} GPUs (data-parallel)"
+    elif (H, T, B) == (256, 30, 4096):
+        head = "BASELINE.json configs[1]"
+    elif (H, T, B) == (512, 60, 8192):
+        head = "BASELINE.json configs[3]"
+    else:
+        head = "non-headline shape (BASELINE.json configs[3] is H=512,T=60,batch 8192)"
+    return head + f": T={T},F={F},zdims={Z},hidden={H},FS={FS}, batch={B}/GPU fp32 train step (gather+fwd+loss+bwd+allreduce+Adam-amsgrad)"
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-also", action="store_true", help="skip the configs[3] / configs[4] legs and the two extra timed regions")
+    ap.add_argument("--batch", type=int, default=4096)
+    ap.add_argument("--dump-kernels", action="store_true", help="per-launch-group table on stderr")
+    ap.add_argument("--mode", choices=["train", "embed"], default="train",
+                    help="train = the headline metric; embed = encoder-only embedd_latent_vectors sweep (BASELINE config 5)")
+    ap.add_argument("--embed-windows", type=int, default=2_000_000)
+    ap.add_argument("--hidden", type=int, default=256, help="exploration only (BASELINE config 4 uses 512)")
+    ap.add_argument("--time-window", type=int, default=30, help="exploration only (BASELINE config 4 uses 60)")
+    args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args)                            # does not return
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with --nproc-per-node {args.gpus} "
+                         f"(or run `python bench.py --gpus {args.gpus}` without a torchrun environment: it starts the ranks itself)")
+    from vame_amd import _lib
+    from vame_amd.model.rnn_vae import _maybe_init_distributed
+    dev = _lib.device(local)                         # raises without an MI355X: the measured path has no CPU fallback
+    on_gpu = dev.type == "cuda"                      # (False only under the CPU test-suite's harness, tests/emu/harness.py, which
+    if on_gpu and torch.cuda.device_count() < world:                 # checks the rank / JSON plumbing and measures nothing)
+        raise SystemExit(f"bench.py: --gpus {world} but only {torch.cuda.device_count()} GPU(s) are visible")
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        _maybe_init_distributed()                    # one process per GPU: backend nccl (= RCCL over xGMI)
+        assert dist.get_world_size() == world
+
+    H, T, B = args.hidden, args.time_window, args.batch
+    if args.mode == "embed":
+        out = embed_leg(dev, args.embed_windows, rank, world, H, T)
+        if rank == 0:
+            out.update(higher_is_better=True, scaling="weak", dtype="f32", data="synthetic")
+            if not args.no_cpu_baseline and world == 1 and on_gpu:
+                out["cpu_baseline"] = cpu_baseline_embed()
+            print(json.dumps(out))
+    else:
+        headline = (H, T, B) == (256, 30, 4096)
+        extras = headline and not args.no_also
+        res = train_leg(dev, H, T, B, args.steps, args.warmup, rank, world, repeats=3 if extras else 1,
+                        dump=args.dump_kernels, one_rank_leg=True)
+        also = None
+        if extras and world == 1 and on_gpu:
+            # the other two single-GPU configurations of BASELINE.json under the same clock, each with its own roofline
+            c4 = train_leg(dev, 512, 60, 8192, 5, 2, 0, 1)
+            c4_line = dict(metric="temporal windows/sec (train) T=60,F=24,h=512", value=round(8192 * 5 / c4["dts"][0], 1), unit="windows/s",
+                           steps=5, warmup=2, ms_per_step=round(c4["dts"][0] / 5 * 1e3, 3), config=dict(workload=workload_name(512, 60, 8192, 1)),
+                           roofline=c4["roofline"])
+            also = dict(configs3_h512_t60_b8192=c4_line, configs4_embed_1gpu=embed_leg(dev, 2_000_000, 0, 1))
+        if rank == 0:
+            dt = res["dts"][0]
+            value = B * world * args.steps / dt
+            out = dict(metric=f"temporal windows/sec (train) T={T},F={F},h={H}", value=round(value, 1), unit="windows/s", n_gpus=world,
+                       steps=args.steps, warmup=args.warmup, ms_per_step=round(dt / args.steps * 1e3, 3), higher_is_better=True,
+                       scaling="weak", vs_baseline=None, dtype="f32", data="synthetic",
+                       config=dict(workload=workload_name(H, T, B, world), global_batch=B * world, parallelism=f"dp{world}",
+                                   last_loss_terms=res["last"]),
+                       roofline=res["roofline"])
+            if len(res["dts"]) > 1:                  # `value` is the first region; the other two only show the spread
+                vals = sorted(B * world * args.steps / d for d in res["dts"])
+                out["repeat_spread"] = dict(regions=len(vals), steps_each=args.steps, min=round(vals[0], 1), median=round(vals[len(vals) // 2], 1),
+                                            max=round(vals[-1], 1), unit="windows/s")
+            if res["distributed"] is not None:
+                out["distributed"] = res["distributed"]
+            if also is not None:
+                out["also"] = also
+            if not args.no_cpu_baseline and world == 1 and on_gpu:
+                out["cpu_baseline"] = cpu_baseline()
+            print(json.dumps(out))
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -181,9 +181,13 @@ int vame_colsum_batch_f32(const int64_t* desc, int njobs, void* stream);
 /* Fused Adam with AMSGrad over a flat parameter buffer (torch.optim.Adam(amsgrad=True), rnn_vae.py:332,143).
  * gscale multiplies the gradient first (1/world_size after an all-reduce SUM).  abort_flag (optional device word): when it is
  * non-zero at execution time the launch changes nothing -- the status word of the cooperative GRU launches goes here, so a step
- * whose gradients are undefined never reaches the weights (the host raises when it next reads the word). */
+ * whose gradients are undefined never reaches the weights (the host raises when it next reads the word).  Any non-zero 32-bit
+ * pattern aborts, so the word may also be a float that an all-reduce SUM left > 0 (the multi-rank case: one rank's failure drops
+ * the step on every rank).  dropped (optional device counter) is incremented by each launch that was aborted, so the host can
+ * keep its bias-correction step count equal to the number of updates actually applied. */
 int vame_adam_amsgrad_f32(float* p, const float* g, float* m, float* v, float* vmax, int64_t n, float lr,
-                          float beta1, float beta2, float eps, int step, float gscale, const int* abort_flag, void* stream);
+                          float beta1, float beta2, float eps, int step, float gscale, const int* abort_flag, int* dropped,
+                          void* stream);
 
 /* Encoder inter-layer dropout (torch.nn.GRU(dropout=p) at rnn_model.py:34-35, training only): out[r][c] = x[row(r)][c] * mask[r][c] * scale
  * over R x C, mask in {0,1}, scale = 1/(1-p).  x rows: seg = 0 -> r*ld + off, else (r/seg)*seg_stride + (r%seg)*ld + off (the padded

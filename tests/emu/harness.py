@@ -49,6 +49,7 @@ def build():
 if __name__ == "__main__":
     import runpy
     install()
+    os.environ["VAME_BENCH_LAUNCHER"] = os.path.abspath(__file__)      # bench.py --gpus N re-launches itself through this wrapper
     script = sys.argv[1]
     sys.argv = sys.argv[1:]
     runpy.run_path(script, run_name="__main__")

@@ -88,23 +88,114 @@ def test_two_rank_gradient_allreduce_and_sharded_embedding(emu, tmp_path):
     np.testing.assert_allclose(np.concatenate([rows[0][2], rows[1][2]]), emb["latent"][:40], atol=1e-5)
 
 
-def test_bench_script_under_torchrun_two_ranks(emu):
-    """The driver's multi-GPU invocation of bench.py (`python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`):
-    rank / barrier / max-over-ranks / rank-0 JSON plumbing, here with 2 gloo ranks on the host emulator build and a tiny model."""
+def _failure_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), VAME_EMU_THREADS="2")
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sys.path.insert(0, os.path.join(ROOT, "tests", "emu"))
+    import harness
+    harness.install()
+    from vame_amd import _lib, ops
+    from vame_amd.model.rnn_model import RNN_VAE
+    from vame_amd.model.rnn_vae import FusedAdamAMSGrad, allreduce_gradients
+    F, Z, H, T, FS, B = 10, 7, 128, 4, 2, 5                       # this shape runs the cooperative (column-split) GRU kernels
+    torch.manual_seed(3)
+    model = RNN_VAE(2 * T, Z, F, 1, FS, H, H, H, H, 0, 0, 0, False).train()
+    opt = FusedAdamAMSGrad(model, lr=5e-4)
+    rng = np.random.default_rng(9 + rank)
+    win = torch.from_numpy(rng.standard_normal((B, T + FS, F)).astype(np.float32))
+
+    def step():
+        model.loss_step(win, 1.0, beta=1.0, kloss=4, klmbda=0.3, bsize=B)
+        opt.step(gscale=allreduce_gradients(model))
+    step()
+    assert model._engine._coop_state is not None and model._engine._coop_state.dirty
+    w_good = model.flat_parameters()[0].clone()
+    t_good = opt.t
+    if rank == 1:
+        ops.gru_coop_set_poll_limit(-1)                           # ONLY this rank's cooperative launches report a timeout
+    raised = False
+    try:
+        step()                                                    # the failed step: must be dropped on BOTH ranks
+        ops.gru_coop_set_poll_limit(0)
+        step()                                                    # the host notices here or one step later -- on both ranks
+        step()
+        model._engine.check_async_errors()
+    except _lib.VameHipError as e:
+        raised = "hand-off" in str(e)
+    finally:
+        ops.gru_coop_set_poll_limit(0)
+    w_after = model.flat_parameters()[0].clone()
+    np.save(os.path.join(out_dir, f"fail{rank}.npy"), np.concatenate([[float(raised), float(torch.equal(w_after, w_good)), opt.t - t_good],
+                                                                      w_after.numpy()]))
+    dist.barrier()
+    # both ranks raised, so both are here: training continues in lock-step
+    step()
+    model._engine.check_async_errors()
+    np.save(os.path.join(out_dir, f"cont{rank}.npy"), model.flat_parameters()[0].numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_failed_cooperative_launch_on_one_rank_is_dropped_and_raised_on_all(emu, tmp_path):
+    """the status word of the cooperative GRU launches rides the gradient all-reduce, so a launch that
+    failed on ONE rank drops the optimizer step on EVERY rank (no undefined gradients in the healthy ranks' weights, no
+    divergence), every rank raises, and the optimizer's step count excludes the dropped launches."""
+    world = 2
+    mp.spawn(_failure_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    f0, f1 = np.load(tmp_path / "fail0.npy"), np.load(tmp_path / "fail1.npy")
+    for f in (f0, f1):
+        assert f[0] == 1.0, "every rank must raise"
+        assert f[1] == 1.0, "the failed step (and the ones behind it) never reached the weights"
+        assert f[2] == 0.0, "dropped launches are not counted as optimizer steps"
+    np.testing.assert_array_equal(f0[3:], f1[3:])
+    np.testing.assert_array_equal(np.load(tmp_path / "cont0.npy"), np.load(tmp_path / "cont1.npy"))
+    assert np.abs(np.load(tmp_path / "cont0.npy") - f0[3:]).max() > 0
+
+
+def _bench_line(cmd):
     import json
     import subprocess
-    env = dict(os.environ, VAME_EMU_THREADS="2", OMP_NUM_THREADS="1")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "emu", "harness.py"), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
-           "--batch", "8", "--hidden", "32", "--time-window", "4"]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(VAME_EMU_THREADS="2", OMP_NUM_THREADS="1")
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout                                         # rank 0 prints exactly one JSON line
-    out = json.loads(lines[0])
+    return json.loads(lines[0])
+
+
+def _check_two_rank_line(out):
     assert out["n_gpus"] == 2 and out["steps"] == 2 and out["warmup"] == 1 and out["value"] > 0
     assert all(np.isfinite(out["config"]["last_loss_terms"]))
     assert out["roofline"] is None and "cpu_baseline" not in out           # nothing measured off the GPU
+    d = out["distributed"]                                                   # proof that two ranks went through the collective
+    assert d["world_size"] == 2 and d["backend"] == "gloo" and d["allreduce_us"] > 0 and d["allreduce_bucket_bytes"] > 0
+    assert 0 < d["weak_scaling_eff"] and d["one_rank_leg_ms_per_step"] > 0
+
+
+BENCH_TINY = ["--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "8", "--hidden", "32", "--time-window", "4"]
+
+
+def test_bench_script_under_torchrun_two_ranks(emu):
+    """The driver's multi-GPU invocation of bench.py (`python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`):
+    rank / barrier / max-over-ranks / rank-0 JSON plumbing, here with 2 gloo ranks on the host emulator build and a tiny model."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "emu", "harness.py"), os.path.join(ROOT, "bench.py")] + BENCH_TINY
+    _check_two_rank_line(_bench_line(cmd))
+
+
+def test_bench_script_launches_its_own_ranks(emu):
+    """`python bench.py --gpus 2` with no torchrun environment must start the two ranks itself (never a silent 1-rank run), and a
+    WORLD_SIZE that contradicts --gpus is an error."""
+    import subprocess
+    _check_two_rank_line(_bench_line([sys.executable, os.path.join(ROOT, "tests", "emu", "harness.py"), os.path.join(ROOT, "bench.py")] + BENCH_TINY))
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "emu", "harness.py"), os.path.join(ROOT, "bench.py")] + BENCH_TINY,
+                       capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
+    assert r.returncode != 0 and "WORLD_SIZE=1" in r.stderr
 
 
 def _driver_worker(rank, world, port, root):

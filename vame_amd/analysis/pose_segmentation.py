@@ -113,16 +113,18 @@ def _kmeans_cls(cfg):
 
 
 def _hmm_cls(cfg):
-    """hmmlearn's GaussianHMM (the reference's exact behaviour) when it is installed and cfg['amd_gpu_hmm'] is not set; otherwise the
-    same Baum-Welch / Viterbi on the MI355X (vame_amd/analysis/hmm_hip.py)."""
-    if not cfg.get('amd_gpu_hmm', False):
-        try:
-            from hmmlearn import hmm
-            return hmm.GaussianHMM
-        except ImportError:
-            print("hmmlearn is not installed: using the MI355X Gaussian HMM (vame_amd.analysis.hmm_hip)")
-    from .hmm_hip import GaussianHMMHIP
-    return GaussianHMMHIP
+    """hmmlearn's GaussianHMM (the reference's exact behaviour, pose_segmentation.py:20,145-158) unless cfg['amd_gpu_hmm'] is set;
+    then the same Baum-Welch / Viterbi on the MI355X (vame_amd/analysis/hmm_hip.py).  The GPU model is never chosen silently: its
+    parity with hmmlearn is unpinned and its pickle is not loadable by the reference."""
+    if cfg.get('amd_gpu_hmm', False):
+        from .hmm_hip import GaussianHMMHIP
+        return GaussianHMMHIP
+    try:
+        from hmmlearn import hmm
+    except ImportError as e:
+        raise ImportError("parameterization 'hmm' needs hmmlearn (as in the reference); to run the MI355X Gaussian HMM instead set "
+                          "amd_gpu_hmm: True in config.yaml (results/hmm_trained.pkl is then a vame_amd model)") from e
+    return hmm.GaussianHMM
 
 
 def same_parameterization(cfg, files, latent_vector_files, states, parameterization):
@@ -144,6 +146,8 @@ def same_parameterization(cfg, files, latent_vector_files, states, parameterizat
             label = hmm_model.predict(latent_vector_cat)
             with open(save_data + "hmm_trained.pkl", "wb") as file:
                 pickle.dump(hmm_model, file)
+            with open(save_data + "hmm_trained.impl.txt", "w") as file:         # which implementation wrote the pickle
+                file.write(type(hmm_model).__module__ + "." + type(hmm_model).__name__ + "\n")
         else:
             print("Using a pretrained HMM as parameterization!")
             with open(save_data + "hmm_trained.pkl", "rb") as file:
@@ -177,6 +181,26 @@ def individual_parameterization(cfg, files, latent_vector_files, cluster):
     return labels, cluster_centers, motif_usages
 
 
+def _ask(prompt, rank, world):
+    """input() for one process; with several ranks (torchrun: the other ranks have no usable stdin, and different answers would
+    leave them in different collectives) rank 0 asks and broadcasts the answer."""
+    import builtins
+    if world == 1:
+        return builtins.input(prompt)
+    box = [builtins.input(prompt) if rank == 0 else None]
+    dist.broadcast_object_list(box, src=0)
+    return box[0]
+
+
+def _same_on_all_ranks(value, world):
+    """Rank 0's view of a file-system test, so that every rank takes the same branch."""
+    if world == 1:
+        return value
+    box = [value]
+    dist.broadcast_object_list(box, src=0)
+    return box[0]
+
+
 def pose_segmentation(config):
     config_file = Path(config).resolve()
     cfg = read_config(config_file)
@@ -196,6 +220,9 @@ def pose_segmentation(config):
     is_main = rank == 0                              # parameterises and writes the result files
     for folders in cfg['video_sets']:
         os.makedirs(os.path.join(pp, "results", folders, model_name, ""), exist_ok=True)
+
+    def input(prompt):                               # noqa: A001  several ranks: ask on rank 0 only, every rank gets the answer
+        return _ask(prompt, rank, world)
 
     files = []
     if cfg['all_data'] == 'No':
@@ -219,7 +246,7 @@ def pose_segmentation(config):
         return os.path.join(pp, "results", f, model_name, parameterization + '-' + str(n_cluster), "")
 
     new = True
-    if not os.path.exists(res_dir(file)):
+    if not _same_on_all_ranks(os.path.exists(res_dir(file)), world):
         model = load_model(cfg, model_name, fixed)
         latent_vectors = embedd_latent_vectors(cfg, files, model, fixed)
     else:

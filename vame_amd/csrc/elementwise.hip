@@ -355,10 +355,14 @@ extern "C" int vame_timesum_f32(const float* in, int B, int T, int C, int64_t ld
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                    float* __restrict__ v, float* __restrict__ vmax, int64_t n, float step_size,
                                                    float beta1, float beta2, float eps, float inv_sqrt_bc2, float gscale,
-                                                   const int* __restrict__ abort_flag) {
+                                                   const int* __restrict__ abort_flag, int* __restrict__ dropped) {
     // a device-side failure upstream (a cooperative GRU launch that gave up waiting: gru_coop.hip) must not reach the weights:
-    // the step is dropped here, on the device, and the host raises when it next looks at the same word
-    if (abort_flag && *abort_flag != 0) return;
+    // the step is dropped here, on the device, and the host raises when it next looks at the same word; `dropped` counts the
+    // launches that did nothing, so the host can take them out of its bias-correction step count
+    if (abort_flag && *abort_flag != 0) {
+        if (dropped && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(dropped, 1);
+        return;
+    }
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         const float gi = g[i] * gscale;
         const float mi = beta1 * m[i] + (1.0f - beta1) * gi;
@@ -371,11 +375,12 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
 }
 
 extern "C" int vame_adam_amsgrad_f32(float* p, const float* g, float* m, float* v, float* vmax, int64_t n, float lr,
-                                     float beta1, float beta2, float eps, int step, float gscale, const int* abort_flag, void* stream) {
+                                     float beta1, float beta2, float eps, int step, float gscale, const int* abort_flag, int* dropped,
+                                     void* stream) {
     VAME_CHECK_ARG(p && g && m && v && vmax && n >= 1 && step >= 1, VAME_E_BADARG, "adam: bad argument");
     const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
     hipLaunchKernelGGL(adam_kernel, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, vmax, n,
-                       (float)(lr / bc1), beta1, beta2, eps, (float)(1.0 / sqrt(bc2)), gscale, abort_flag);
+                       (float)(lr / bc1), beta1, beta2, eps, (float)(1.0 / sqrt(bc2)), gscale, abort_flag, dropped);
     VAME_LAUNCH_CHECK("adam");
     return VAME_OK;
 }

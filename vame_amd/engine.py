@@ -335,14 +335,25 @@ class VAEEngine:
         if self._coop_state is not None:
             self._coop_state.poll()
 
-    def snapshot_async_errors(self):
-        """End of a step: enqueue the 4-byte status copy that poll_async_errors() of the next steps looks at."""
-        if self._coop_state is not None:
+    def snapshot_async_errors(self, reduced=False):
+        """End of a step: enqueue the 4-byte status copy that poll_async_errors() of the next steps looks at.  With several ranks
+        the word to look at is the all-reduced one (share_status), so the copy is enqueued by allreduce_gradients (reduced=True) and
+        the per-rank call at the end of loss_step does nothing."""
+        if self._coop_state is not None and (reduced or self._coop_state.shared is None):
             self._coop_state.snapshot()
 
     def abort_flag(self):
         """Device word the optimizer kernel tests before it touches the weights (None: no cooperative launch so far)."""
-        return self._coop_state.status if self._coop_state is not None else None
+        if self._coop_state is None:
+            return None
+        return self._coop_state.status if self._coop_state.shared is None else self._coop_state.shared
+
+    def share_status(self, word):
+        """Several ranks: copy this rank's status into `word` (one float behind the gradient bucket) so that the gradient all-reduce
+        carries it; from then on `word` is the abort flag and the snapshot source on every rank (ops.CoopState)."""
+        if self._coop_state is not None:
+            self._coop_state.shared = word
+            word.copy_(self._coop_state.status)
 
     def _coop_parts(self, rows, B, tkey=None, H=None):
         """[(streams, (row0, nrows))] cooperative launches that cover this GRU launch, each fitting one workgroup per CU; at

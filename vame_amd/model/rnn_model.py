@@ -228,7 +228,9 @@ class RNN_VAE(nn.Module):
         if not ok:
             self._table = ParamTable([(n, p.shape) for n, p in plist])
             flat_p = torch.zeros(self._table.numel, device=dev)
-            flat_g = torch.zeros(self._table.numel, device=dev)
+            # four floats behind the gradients: slot 0 is the status word that rides the same all-reduce (rnn_vae.allreduce_gradients)
+            self._flat_g_comm = torch.zeros(self._table.numel + 4, device=dev)
+            flat_g = self._flat_g_comm[:self._table.numel]
             for n, p in plist:
                 o, k = self._table.off(n), p.numel()
                 flat_p[o:o + k].copy_(p.data.detach().reshape(-1).to(torch.float32))

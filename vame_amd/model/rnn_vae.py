@@ -101,6 +101,14 @@ class FusedAdamAMSGrad(torch.optim.Optimizer):
         self.v = torch.zeros_like(self.flat_p)
         self.vmax = torch.zeros_like(self.flat_p)
         self.t = 0
+        self.dropped = torch.zeros(1, dtype=torch.int32, device=self.flat_p.device)   # launches the abort word turned into no-ops
+        self._hooked = None
+
+    def _forget_dropped_steps(self):
+        """Runs when a device-side failure is raised (ops.CoopState.on_error; the host is synchronised there): the launches that
+        did nothing must not count as steps of the bias correction, should the caller catch the error and go on training."""
+        self.t -= int(self.dropped.item())
+        self.dropped.zero_()
 
     @torch.no_grad()
     def step(self, closure=None, gscale=1.0):
@@ -110,9 +118,13 @@ class FusedAdamAMSGrad(torch.optim.Optimizer):
         self.t += 1
         g = self.param_groups[0]
         eng = self.model._engine
+        flag = eng.abort_flag() if eng is not None else None
+        if flag is not None and self._hooked is not eng._coop_state:
+            eng._coop_state.on_error.append(self._forget_dropped_steps)
+            self._hooked = eng._coop_state
         ops.adam_amsgrad(flat_p, flat_g, self.m, self.v, self.vmax, flat_p.numel(), g["lr"], self.t, gscale=gscale,
-                         beta1=g["betas"][0], beta2=g["betas"][1], eps=g["eps"],
-                         abort_flag=eng.abort_flag() if eng is not None else None)
+                         beta1=g["betas"][0], beta2=g["betas"][1], eps=g["eps"], abort_flag=flag,
+                         dropped=self.dropped if flag is not None else None)
 
     def zero_grad(self, set_to_none=False):
         pass  # every backward overwrites the whole bucket
@@ -138,7 +150,14 @@ def allreduce_gradients(model):
     into the Adam kernel.  2,618,476 floats = 10.5 MB at the default model size."""
     _, world = _world()
     if world > 1:
-        dist.all_reduce(model.flat_parameters()[1], op=dist.ReduceOp.SUM)
+        n = model.flat_parameters()[1].numel()
+        bucket, eng = model._flat_g_comm, model._engine
+        # the status word of this rank's cooperative launches rides the same all-reduce (slot n): afterwards it is non-zero on
+        # EVERY rank if any rank failed, and it is what the optimizer kernel tests -- so a failed step is dropped everywhere and
+        # every rank raises, instead of one rank's undefined gradients reaching the healthy ranks' weights
+        eng.share_status(bucket[n:n + 1])
+        dist.all_reduce(bucket, op=dist.ReduceOp.SUM)
+        eng.snapshot_async_errors(reduced=True)
     return 1.0 / world
 
 

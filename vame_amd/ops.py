@@ -142,11 +142,19 @@ class CoopState:
     Failure handling: a launch that gives up waiting for a group member increments `status` on the device.  The optimizer
     kernel reads the same word and drops the step (vame_adam_amsgrad_f32 abort_flag), so undefined gradients never reach
     the weights; the host learns about it from `poll()` -- an asynchronous 4-byte copy into pinned memory after every step,
-    looked at when the next step is enqueued (no stall) -- or from `check()` wherever it synchronises anyway."""
+    looked at when the next step is enqueued (no stall) -- or from `check()` wherever it synchronises anyway.
+
+    Several ranks: `shared` is the float word behind the gradient bucket that travels through the SAME all-reduce (SUM) as the
+    gradients (rnn_vae.allreduce_gradients writes `status` into it first).  It is then the optimizer's abort word and the word the
+    snapshots copy, so one rank's failure drops the step on EVERY rank and every rank raises -- replicas never diverge and nobody
+    is left waiting in the next collective.  `on_error` callbacks run (host synchronised, status already cleared) just before the
+    exception: the optimizer takes the dropped launches out of its bias-correction step count there."""
 
     def __init__(self, dev, ints=1 << 16):
         self.flags = torch.zeros(ints, dtype=torch.int32, device=dev)
         self.status = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.shared = None
+        self.on_error = []
         self.epoch = 1
         self.dirty = False                                   # cooperative launches since the last check()
         self._host = [torch.zeros(1, dtype=torch.int32, pin_memory=dev.type == "cuda") for _ in range(2)]
@@ -161,7 +169,7 @@ class CoopState:
         if self._ev[k] is not None:
             self._ev[k].synchronize()                        # the copy that used this buffer two steps ago (long finished)
             self._raise_if(int(self._host[k][0]))
-        self._host[k].copy_(self.status, non_blocking=True)
+        self._host[k].copy_(self.status if self.shared is None else self.shared, non_blocking=True)
         if self.status.is_cuda:
             self._ev[k] = torch.cuda.Event()
             self._ev[k].record()
@@ -169,7 +177,11 @@ class CoopState:
             self._raise_if(int(self._host[k][0]))
 
     def poll(self):
-        """Look at the snapshots that have already arrived (start of a step); never blocks."""
+        """Look at the snapshots that have already arrived (start of a step); never blocks.  Not with several ranks: WHEN a copy
+        arrives differs between ranks, and a rank that raised here would leave the others waiting in the next all-reduce -- there
+        every rank examines the same (all-reduced) word at the same program point, in snapshot() two steps later or in check()."""
+        if self.shared is not None:
+            return
         for k in (0, 1):
             ev = self._ev[k]
             if ev is not None and ev.query():
@@ -179,8 +191,12 @@ class CoopState:
     def _raise_if(self, n):
         if n:
             self.status.zero_()
+            if self.shared is not None:
+                self.shared.zero_()
             self._ev = [None, None]
             self.dirty = False
+            for cb in self.on_error:
+                cb()
             raise _lib.VameHipError(f"cooperative GRU kernel: {n} hand-off wait(s) timed out (workgroups of a group were not co-resident); "
                                     "the affected optimizer step was dropped on the device; set engine.coop = False "
                                     "(VAME_AMD_COOP=0) to use the batch-tile-persistent kernels")
@@ -195,7 +211,10 @@ class CoopState:
         if not self.dirty:
             return
         self.dirty = False
-        self._raise_if(int(self.status.item()))
+        n = int(self.status.item())
+        if self.shared is not None:
+            n = max(n, int(self.shared.item() != 0))
+        self._raise_if(n)
 
 
 def gru_coop_set_poll_limit(polls):
@@ -363,9 +382,9 @@ def colsum_batch(jobs):
         _lib.check(rc, "vame_colsum_batch_f32")
 
 
-def adam_amsgrad(p, g, m, v, vmax, n, lr, step, gscale=1.0, beta1=0.9, beta2=0.999, eps=1e-8, abort_flag=None):
+def adam_amsgrad(p, g, m, v, vmax, n, lr, step, gscale=1.0, beta1=0.9, beta2=0.999, eps=1e-8, abort_flag=None, dropped=None):
     rc = _lib.lib().vame_adam_amsgrad_f32(_ptr(p), _ptr(g), _ptr(m), _ptr(v), _ptr(vmax), n, lr, beta1, beta2, eps, step,
-                                          gscale, _ptr(abort_flag), _stream())
+                                          gscale, _ptr(abort_flag), _ptr(dropped), _stream())
     _lib.check(rc, "vame_adam_amsgrad_f32")
 
 
