@@ -189,6 +189,12 @@ int vame_adam_amsgrad_f32(float* p, const float* g, float* m, float* v, float* v
                           float beta1, float beta2, float eps, int step, float gscale, const int* abort_flag, int* dropped,
                           void* stream);
 
+/* dst[dst_idx[i]] = src[src_idx[i]], i < n (element indices, no duplicates in dst_idx).  torch.nn.GRU accepts any hidden_size
+ * (rnn_model.py:34,91,125) while the GRU kernels tile hidden units by 32: for other sizes the model keeps its parameters in the
+ * reference's shapes (state_dict / optimizer) and this kernel copies them into a zero-padded image the kernels run on -- padded
+ * units stay exactly 0 through the GRU recurrence -- and the padded gradients back (vame_amd/padding.py). */
+int vame_index_copy_f32(float* dst, const int64_t* dst_idx, const float* src, const int64_t* src_idx, int64_t n, void* stream);
+
 /* Encoder inter-layer dropout (torch.nn.GRU(dropout=p) at rnn_model.py:34-35, training only): out[r][c] = x[row(r)][c] * mask[r][c] * scale
  * over R x C, mask in {0,1}, scale = 1/(1-p).  x rows: seg = 0 -> r*ld + off, else (r/seg)*seg_stride + (r%seg)*ld + off (the padded
  * sequence layout); mask / out dense (R, C); C % 4 == 0; in-place on a dense x is allowed (the backward of the same op). */

@@ -158,18 +158,19 @@ def lambda_forward(p, h, eps, spec, training, cache=None):
     return z, mu, lv
 
 
-def decoder_forward(p, z, steps, name, rnn, cache=None):
+def decoder_forward(p, z, steps, name, rnn, cache=None, inputs=None):
     """rnn_model.py:99-109 / 133-144.
 
     hidden = Linear(z) (B,2H) ; hidden.view(2,B,H) is a raw reinterpretation of the
     contiguous buffer (rnn_model.py:104,137) -- reproduced by reshape on a C-contiguous array.
-    The GRU input is z at every step (rnn_model.py:169-170, 139).
+    The GRU input is z at every step (rnn_model.py:169-170, 139) unless the caller hands the module its own `inputs` (B, >=steps, Z)
+    (the modules run the GRU over whatever they are given, rnn_model.py:106 / :139 `inputs[:, :future_steps, :]`).
     """
     B = z.shape[0]
     hid = _f32(z @ p[f"{name}.latent_to_hidden.weight"].T + p[f"{name}.latent_to_hidden.bias"])
     H = hid.shape[1] // 2
     h0 = hid.reshape(2, B, H)
-    ins = np.repeat(z[:, None, :], steps, 1)
+    ins = np.repeat(z[:, None, :], steps, 1) if inputs is None else _f32(inputs[:, :steps, :])
     pre = f"{name}.{rnn}"
     of, _, cf = gru_dir_forward(ins, h0[0], *_gru_params(p, pre, 0, False), reverse=False)
     ob, _, cb = gru_dir_forward(ins, h0[1], *_gru_params(p, pre, 0, True), reverse=True)

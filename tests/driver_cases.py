@@ -13,6 +13,33 @@ import yaml
 from conftest import load_golden
 
 
+def _vame():
+    """`import vame` exactly as the reference's scripts write it (examples/demo.py:8,48,56), resolved to vame_amd by the opt-in
+    alias (vame_amd/compat.py): every driver check below runs the reference's call order through the reference's names."""
+    from vame_amd import compat
+    compat.install_alias()
+    import vame
+    assert compat.is_alias(vame)
+    return vame
+
+
+def check_alias_surface():
+    """The dotted imports the reference's own modules use for the hot path resolve to the build's classes."""
+    import vame_amd
+    vame = _vame()
+    from vame.model.rnn_vae import RNN_VAE as from_vae                    # vame/model/evaluate.py:20
+    from vame.model.rnn_model import RNN_VAE as from_model                # vame/analysis/pose_segmentation.py:24
+    from vame.model import SEQUENCE_DATASET, train_model                  # vame/model/__init__.py:16-17
+    from vame.analysis import pose_segmentation                           # vame/analysis/__init__.py:14
+    from vame.analysis.pose_segmentation import embedd_latent_vectors, load_model          # noqa: F401
+    from vame.util.auxiliary import read_config                           # noqa: F401
+    assert from_vae is from_model is vame_amd.model.rnn_model.RNN_VAE
+    assert train_model is vame.train_model is vame_amd.train_model and pose_segmentation is vame.pose_segmentation
+    assert SEQUENCE_DATASET is vame_amd.model.dataloader.SEQUENCE_DATASET
+    with pytest.raises(AttributeError, match="not part of the MI355X"):
+        vame.motif_videos
+
+
 def make_project(tmp_path_factory):
     g = load_golden("train_model_run")
     cfg = json.loads(str(g["cfg_json"]))
@@ -32,7 +59,7 @@ def make_project(tmp_path_factory):
 
 
 def check_train_model_files_and_losses(project):
-    import vame_amd as vame
+    vame = _vame()
     root, cfg, g = project
     np.random.seed(0)
     vame.train_model(str(root / "config.yaml"))
@@ -56,7 +83,7 @@ def check_train_model_files_and_losses(project):
 
 
 def check_pose_segmentation_outputs(project):
-    import vame_amd as vame
+    vame = _vame()
     root, cfg, g = project
     vame.pose_segmentation(str(root / "config.yaml"))
     out = root / "results" / "vid1" / "VAME" / "kmeans-4"
@@ -85,7 +112,7 @@ def _oracle_params(root, cfg):
 def check_evaluate_model_outputs(project):
     """vame.evaluate_model (evaluate.py:169-215): PNGs under model/evaluate/ and the plotted numbers = eval-mode forward
     of 64 random z-scored test windows (mu feeds both decoders)."""
-    import vame_amd as vame
+    vame = _vame()
     from vame_amd.model import evaluate as ev
     root, cfg, g = project
     vame.evaluate_model(str(root / "config.yaml"))
@@ -149,7 +176,7 @@ def check_generative_model_modes(project):
 def check_train_model_legacy_topology(project, tmp_path):
     """cfg['legacy'] = True trains RNN_VAE_LEGACY (rnn_vae.py:294-297): checkpoint keys / shapes of the legacy model."""
     import shutil
-    import vame_amd as vame
+    vame = _vame()
     from vame_amd.model.rnn_model import RNN_VAE_LEGACY
     root, cfg, g = project
     lroot = tmp_path / "legacy"
@@ -174,7 +201,7 @@ def check_train_model_legacy_topology(project, tmp_path):
 def check_create_trainset_files(tmp_path):
     """vame.create_trainset (create_training.py:267-300): train/test split + per-video clean files, equal to the files the
     REFERENCE wrote for the same inputs (tests/golden/prep_*.npz)."""
-    import vame_amd as vame
+    vame = _vame()
     for name, fixed in (("prep_aligned", False), ("prep_fixed", True)):
         g = load_golden(name)
         root = tmp_path / name
@@ -228,7 +255,7 @@ def check_pose_segmentation_hmm(project):
     """cfg['parameterization'] = 'hmm' (pose_segmentation.py:145-158): Gaussian HMM over the latents (GaussianHMMHIP when hmmlearn is absent or
     cfg['amd_gpu_hmm']), labels / motif usage files, results/hmm_trained.pkl, and the hmm_trained = True reload path."""
     import pickle
-    import vame_amd as vame
+    vame = _vame()
     root, cfg, g = project
     hcfg = dict(cfg, parameterization="hmm", n_cluster=3, amd_gpu_hmm=True, hmm_trained=False)
     with open(root / "config_hmm.yaml", "w") as f:

@@ -203,6 +203,38 @@ def h0view_fixture(rnn_model):
     print("wrote h0view")
 
 
+def decoder_inputs_fixture(rnn_model):
+    """Decoder / Decoder_Future run over ARBITRARY `inputs` (rnn_model.py:99-109,132-144: the GRU consumes whatever sequence it is
+    given; only RNN_VAE.forward tiles z).  Random inputs that are not z tiled over time."""
+    T, Z, F, H, FS = 6, 30, 24, 32, 3
+    torch.manual_seed(11)
+    dec = rnn_model.Decoder(T, Z, F, H, 0)
+    fut = rnn_model.Decoder_Future(T, Z, F, FS, H, 0)
+    dec.eval(), fut.eval()
+    out = {"w/decoder." + k: v.detach().numpy().copy() for k, v in dec.state_dict().items()}
+    out.update({"w/decoder_future." + k: v.detach().numpy().copy() for k, v in fut.state_dict().items()})
+    for B in (1, 5):
+        torch.manual_seed(20 + B)
+        z = torch.randn(B, Z)
+        ins = torch.randn(B, T, Z)
+        with torch.no_grad():
+            out[f"B{B}/z"], out[f"B{B}/ins"] = z.numpy().copy(), ins.numpy().copy()
+            out[f"B{B}/pred"] = dec(ins, z).numpy().copy()
+            out[f"B{B}/fut"] = fut(ins, z).numpy().copy()            # reads ins[:, :FS] (rnn_model.py:139)
+    out["spec"] = np.array([T, F, Z, H, FS])
+    np.savez_compressed(os.path.join(OUT, "decoder_inputs.npz"), **out)
+    print("wrote decoder_inputs")
+
+
+def round3_fixtures(rnn_model, rnn_vae):
+    """Round 3: mse='mean' pinned at a second KL weight and at H=64 (every gradient of such a step is < 0.1: the checks are relative
+    to each tensor's own scale), a hidden size that is not a multiple of 32, and decoders over non-tiled inputs."""
+    step_fixture(rnn_model, rnn_vae, "step_tiny_mean_kw025", mse="mean", adam_steps=0, kl_weights=(0.25,))
+    step_fixture(rnn_model, rnn_vae, "step_h64_mean", H=64, B=40, T=12, FS=5, adam_steps=0, kl_weights=(0.5,), mse="mean")
+    step_fixture(rnn_model, rnn_vae, "step_h40", H=40, B=6, T=8, FS=4, adam_steps=0, kl_weights=(1.0,))
+    decoder_inputs_fixture(rnn_model)
+
+
 def anneal_fixture(rnn_vae):
     tab = {fn: [float(rnn_vae.kl_annealing(e, 2, 4, fn)) for e in range(1, 12)] for fn in ("linear", "sigmoid")}
     with open(os.path.join(OUT, "kl_annealing.json"), "w") as f:
@@ -390,6 +422,11 @@ def main():
         load_reference()
         prep_fixture()
         return
+    if len(sys.argv) > 1 and sys.argv[1] == "round3":
+        rnn_model, dataloader, rnn_vae, pose = load_reference()
+        torch.set_num_threads(4)
+        round3_fixtures(rnn_model, rnn_vae)
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "legacy":
         rnn_model, dataloader, rnn_vae, pose = load_reference()
         legacy_fixture(rnn_model, rnn_vae)
@@ -412,6 +449,7 @@ def main():
     legacy_fixture(rnn_model, rnn_vae)
     options_fixture(rnn_model, rnn_vae)
     prep_fixture()
+    round3_fixtures(rnn_model, rnn_vae)
 
 
 if __name__ == "__main__":

@@ -326,9 +326,9 @@ def check_gru_coop_bwd(dev, H, B, T, launches=2):
     for it in range(launches):
         got = _run_gru_bwd(dev, H, B, T, st, Y, dYt, dhNt, coop=state, coop_chunks=chunks[it % len(chunks)])
         for (dG, dh0, dbias, _), (dGr, dh0r, dbiasr, _) in zip(got, ref):
-            np.testing.assert_allclose(N_(dG), N_(dGr), atol=2e-5 * max(1.0, float(np.abs(N_(dGr)).max())))
-            np.testing.assert_allclose(N_(dh0), N_(dh0r), atol=2e-5 * max(1.0, float(np.abs(N_(dh0r)).max())))
-            np.testing.assert_allclose(N_(dbias).sum(0), N_(dbiasr).sum(0), atol=1e-4 * max(1.0, float(np.abs(N_(dbiasr).sum(0)).max())))
+            np.testing.assert_allclose(N_(dG), N_(dGr), atol=2e-5 * float(np.abs(N_(dGr)).max()))
+            np.testing.assert_allclose(N_(dh0), N_(dh0r), atol=2e-5 * float(np.abs(N_(dh0r)).max()))
+            np.testing.assert_allclose(N_(dbias).sum(0), N_(dbiasr).sum(0), atol=1e-4 * float(np.abs(N_(dbiasr).sum(0)).max()))
     assert int(state.status.item()) == 0
 
 
@@ -498,9 +498,9 @@ def check_nuclear(dev, B, Z, k):
     loss, Minv = torch.zeros(1, device=dev), torch.zeros(Z, Z, device=dev)
     ops.nuclear(T_(G, dev), Z, k, B, 0.1, B, loss, 0, Minv)
     ref_loss, ref_dz = vo.cluster_loss_gram(z, k, 0.1, B)
-    assert abs(N_(loss)[0] - ref_loss) <= 1e-5 * max(1, abs(ref_loss))
-    assert abs(N_(loss)[0] - vo.cluster_loss_svd(z, k, 0.1, B)) <= 1e-4 * max(1, abs(ref_loss))
-    np.testing.assert_allclose(z @ N_(Minv), ref_dz, atol=2e-5 * max(1, np.abs(ref_dz).max()))
+    assert abs(N_(loss)[0] - ref_loss) <= 1e-5 * abs(ref_loss)
+    assert abs(N_(loss)[0] - vo.cluster_loss_svd(z, k, 0.1, B)) <= 1e-4 * abs(ref_loss)
+    np.testing.assert_allclose(z @ N_(Minv), ref_dz, atol=2e-5 * np.abs(ref_dz).max())
     # warm start: a second, slightly perturbed Gram solved from the stored eigenvectors gives the same answer as a cold solve
     vst = torch.zeros(ops.nuclear_state_doubles(Z), device=dev, dtype=torch.float64)
     ops.nuclear(T_(G, dev), Z, k, B, 0.1, B, loss, 0, Minv, vstate=vst)
@@ -508,8 +508,8 @@ def check_nuclear(dev, B, Z, k):
     G2 = (z2.astype(np.float64).T @ z2.astype(np.float64)).astype(np.float32)
     ops.nuclear(T_(G2, dev), Z, k, B, 0.1, B, loss, 0, Minv, vstate=vst)
     ref_loss2, ref_dz2 = vo.cluster_loss_gram(z2, k, 0.1, B)
-    assert abs(N_(loss)[0] - ref_loss2) <= 1e-5 * max(1, abs(ref_loss2))
-    np.testing.assert_allclose(z2 @ N_(Minv), ref_dz2, atol=2e-5 * max(1, np.abs(ref_dz2).max()))
+    assert abs(N_(loss)[0] - ref_loss2) <= 1e-5 * abs(ref_loss2)
+    np.testing.assert_allclose(z2 @ N_(Minv), ref_dz2, atol=2e-5 * np.abs(ref_dz2).max())
 
 
 def check_kmeans(dev, N=3000, K=6, D=30, n_init=3):

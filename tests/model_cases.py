@@ -3,6 +3,7 @@ import numpy as np
 import torch
 
 from conftest import golden_weights, load_golden
+from tolerances import TINY_REL, assert_grad_close, assert_loss_close, step_scale_of
 from vame_amd import ops
 from vame_amd.model.rnn_model import RNN_VAE
 
@@ -16,7 +17,7 @@ def build_model(g, dev):
     return model.to(dev), (T, F, Z, H, FS, fut, sp)
 
 
-def check_step(dev, name, kw, mse="sum", tol_grad=3e-4, via_autograd=False, stepwise=False):
+def check_step(dev, name, kw, mse="sum", tol_grad=TINY_REL, via_autograd=False, stepwise=False):
     g = load_golden(name)
     model, (T, F, Z, H, FS, fut, sp) = build_model(g, dev)
     model.train()
@@ -30,7 +31,7 @@ def check_step(dev, name, kw, mse="sum", tol_grad=3e-4, via_autograd=False, step
         win = torch.cat([x, xfut], 1).contiguous()
         out = model.loss_step(win, kw, beta=1.0, kloss=Z, klmbda=0.1, bsize=B, mse_red=mse, mse_pred=mse, eps=eps).cpu().numpy()
         for i, k in enumerate(["rec", "fut", "kl", "kmeans"]):
-            assert abs(out[i] - ref[i]) <= 1e-4 * max(1.0, abs(ref[i])), (k, out[i], ref[i])
+            assert_loss_close(out[i], ref[i], name=k)
     else:
         from vame_amd.model import rnn_vae as rv
         res = model(x, eps=eps)
@@ -41,14 +42,14 @@ def check_step(dev, name, kw, mse="sum", tol_grad=3e-4, via_autograd=False, step
         for p in model.parameters():
             p.grad = None
         loss.backward()
-        assert abs(loss.item() - ref[4]) <= 1e-4 * max(1.0, abs(ref[4]))
+        assert_loss_close(loss.item(), ref[4], name="total")
     if "pred" in g and (tag + "losses") == max(k for k in g if k.endswith("/losses")):
         eng = model._engine
         np.testing.assert_allclose(eng.buf("mu", B, Z)[:B * Z].view(B, Z).cpu().numpy(), g["mu"], atol=1e-5)
         np.testing.assert_allclose(eng.buf("pred", B, T, F)[:B * T * F].view(B, T, F).cpu().numpy(), g["pred"], atol=3e-5)
+    sscale = step_scale_of(g[tag + "g/" + k] for k, _ in model.named_parameters())
     for k, p in model.named_parameters():
-        r = g[tag + "g/" + k]
-        np.testing.assert_allclose(p.grad.cpu().numpy(), r, atol=tol_grad * max(1.0, np.abs(r).max()), err_msg=k)
+        assert_grad_close(p.grad.cpu().numpy(), g[tag + "g/" + k], tol_grad, k, sscale)      # relative to each tensor's own max
     return model
 
 
@@ -105,6 +106,68 @@ def check_h0_view(dev):
         np.testing.assert_allclose(pred.cpu().numpy(), g[f"B{B}/pred"], atol=2e-5)
 
 
+def check_decoder_inputs(dev):
+    """model.decoder(inputs, z) / model.decoder_future(inputs, z) with inputs that are NOT z tiled over time (the reference's
+    modules run their GRU over any sequence, rnn_model.py:99-109,132-144): against the reference's own outputs."""
+    g = load_golden("decoder_inputs")
+    T, F, Z, H, FS = [int(v) for v in g["spec"]]
+    model = RNN_VAE(2 * T, Z, F, 1, FS, H, H, H, H, 0, 0, 0, False)
+    sd = model.state_dict()
+    for k, v in golden_weights(g).items():
+        sd[k] = torch.from_numpy(v)
+    model.load_state_dict(sd)
+    model = model.to(dev).eval()
+    for B in (1, 5):
+        z, ins = torch.from_numpy(g[f"B{B}/z"]).to(dev), torch.from_numpy(g[f"B{B}/ins"]).to(dev)
+        np.testing.assert_allclose(model.decoder(ins, z).cpu().numpy(), g[f"B{B}/pred"], atol=2e-5)
+        np.testing.assert_allclose(model.decoder_future(ins, z).cpu().numpy(), g[f"B{B}/fut"], atol=2e-5)
+        tiled = z.unsqueeze(2).repeat(1, 1, T).permute(0, 2, 1)                 # the usual call still takes the z-only path
+        assert not np.allclose(model.decoder(tiled, z).cpu().numpy(), g[f"B{B}/pred"], atol=1e-3)
+    import pytest
+    with pytest.raises(ValueError):
+        model.decoder(torch.zeros(1, T + 2, Z), torch.zeros(1, Z))
+
+
+def check_padded_hidden_sizes(dev):
+    """Hidden sizes that are not multiples of 32 (torch.nn.GRU accepts any): the reference's own step at H = 40 (step_h40.npz, all
+    gradients), the sub-module call pattern and state_dict shapes, then H = 100 with different decoder sizes and encoder dropout
+    against the numpy oracle."""
+    from oracle import vame_oracle as vo
+    model = check_step(dev, "step_h40", 1.0)
+    check_step(dev, "step_h40", 1.0, via_autograd=True)
+    g = load_golden("step_h40")
+    assert all(tuple(v.shape) == golden_weights(g)[k].shape for k, v in model.state_dict().items())
+    model.eval()
+    x = torch.from_numpy(g["x"]).to(dev)
+    h = model.encoder(x)
+    assert tuple(h.shape) == (x.shape[0], 4 * 40)
+    np.testing.assert_allclose(model.lmbda(h)[1].cpu().numpy(), g["eval_mu"], atol=1e-5)
+    np.testing.assert_allclose(model(x)[0].cpu().numpy(), g["eval_pred"], atol=3e-5)
+    # H = 100 encoder, 72 / 24 decoders, inter-layer dropout with an injected mask
+    T, F, Z, FS, B = 7, 12, 10, 3, 9
+    torch.manual_seed(23)
+    model = RNN_VAE(2 * T, Z, F, 1, FS, 100, 100, 72, 24, 0.2, 0, 0, False)
+    p = {k: v.numpy().copy() for k, v in model.state_dict().items()}
+    model = model.to(dev).train()
+    rng = np.random.default_rng(12)
+    win = rng.standard_normal((B, T + FS, F)).astype(np.float32)
+    eps = rng.standard_normal((B, Z)).astype(np.float32)
+    mask = (rng.random((B, T, 200)) > 0.2).astype(np.float32)
+    out = model.loss_step(torch.from_numpy(win).to(dev), 0.6, beta=1.0, kloss=Z, klmbda=0.1, bsize=B, eps=torch.from_numpy(eps).to(dev),
+                          drop_mask=torch.from_numpy(mask).to(dev)).cpu().numpy()
+    spec = vo.Spec(T=T, F=F, Z=Z, H=100, FS=FS, future=True, softplus=False, dropout=0.2)
+    cache = vo.FwdCache()
+    x, xf = win[:, :T], win[:, T:]
+    res = vo.model_forward(p, x, eps, spec, True, cache, drop_mask=mask)
+    L = vo.total_loss(*res, x, xf, spec, 0.6)
+    for i, k in enumerate(["rec", "fut", "kl", "kmeans"]):
+        assert_loss_close(out[i], L[k], name=k)
+    grads = vo.model_backward(p, cache, spec, x, xf, 0.6)
+    for k, prm in model.named_parameters():
+        assert tuple(prm.grad.shape) == p[k].shape
+        assert_grad_close(prm.grad.cpu().numpy(), grads[k], TINY_REL, k, step_scale_of(grads.values()))
+
+
 def check_noise_input(dev):
     """cfg['noise']: the encoder sees a perturbed input while the reconstruction target stays clean (rnn_vae.py:116-124)."""
     from oracle import vame_oracle as vo
@@ -123,11 +186,11 @@ def check_noise_input(dev):
     res = vo.model_forward(p, xin, eps, spec, True, cache)
     L = vo.total_loss(*res, x, xfut, spec, 1.0)
     for i, k in enumerate(["rec", "fut", "kl", "kmeans"]):
-        assert abs(out[i] - L[k]) <= 1e-4 * max(1.0, abs(L[k])), (k, out[i], L[k])
+        assert_loss_close(out[i], L[k], name=k)
     grads = vo.model_backward(p, cache, spec, x, xfut, 1.0)
     for k, prm in model.named_parameters():
         r = grads[k]
-        np.testing.assert_allclose(prm.grad.cpu().numpy(), r, atol=3e-4 * max(1.0, np.abs(r).max()), err_msg=k)
+        assert_grad_close(prm.grad.cpu().numpy(), r, TINY_REL, k, step_scale_of(grads.values()))
 
 
 def check_adam_trajectory(dev):
@@ -168,11 +231,11 @@ def check_odd_dims_vs_oracle(dev, F=10, Z=7, H=32, T=9, FS=4, B=5):
     res = vo.model_forward(p, x, eps, spec, True, cache)
     L = vo.total_loss(*res, x, xf, spec, 0.7, beta=2.0, kloss=4, klmbda=0.3)
     for i, k in enumerate(["rec", "fut", "kl", "kmeans"]):
-        assert abs(out[i] - L[k]) <= 1e-4 * max(1.0, abs(L[k])), (k, out[i], L[k])
+        assert_loss_close(out[i], L[k], name=k)
     grads = vo.model_backward(p, cache, spec, x, xf, 0.7, beta=2.0, kloss=4, klmbda=0.3)
     for k, prm in model.named_parameters():
         r = grads[k]
-        np.testing.assert_allclose(prm.grad.cpu().numpy(), r, atol=3e-4 * max(1.0, np.abs(r).max()), err_msg=k)
+        assert_grad_close(prm.grad.cpu().numpy(), r, TINY_REL, k, step_scale_of(grads.values()))
 
 
 def check_legacy_step(dev):
@@ -192,14 +255,14 @@ def check_legacy_step(dev):
     out = model.loss_step(win, kw, beta=1.0, kloss=Z, klmbda=0.1, bsize=B, eps=eps).cpu().numpy()
     ref = g["losses"]
     for i in range(4):
-        assert abs(out[i] - ref[i]) <= 1e-4 * max(1.0, abs(ref[i])), (i, out[i], ref[i])
+        assert_loss_close(out[i], ref[i], name=str(i))
     eng = model._engine
     for name, ref_v in (("pred", g["pred"]), ("futp", g["fut"]), ("z", g["z"]), ("mu", g["mu"]), ("logvar", g["logvar"])):
         got = eng.ws.t[name][:ref_v.size].view(*ref_v.shape).cpu().numpy()
         np.testing.assert_allclose(got, ref_v, atol=3e-5, err_msg=name)
     for k, p in model.named_parameters():
         gr = g["g/" + k]
-        np.testing.assert_allclose(p.grad.cpu().numpy(), gr, atol=3e-4 * max(np.abs(gr).max(), 1e-3), err_msg=k)
+        assert_grad_close(p.grad.cpu().numpy(), gr, TINY_REL, k, step_scale_of(g["g/" + kk] for kk, _ in model.named_parameters()))
     assert set(g["no_grad"]) == {"lmbda.hidden_to_linear.weight", "lmbda.hidden_to_linear.bias"}
     # autograd path through model(x)
     model.zero_grad(set_to_none=False)
@@ -239,14 +302,14 @@ def check_model_options(dev, name):
     kw = float(g["kw"][0])
     out = model.loss_step(win, kw, beta=1.0, kloss=Z, klmbda=0.1, bsize=B, eps=eps, drop_mask=mask).cpu().numpy()
     for i in range(4):
-        assert abs(out[i] - g["losses"][i]) <= 1e-4 * max(1.0, abs(g["losses"][i])), (i, out[i], g["losses"][i])
+        assert_loss_close(out[i], g["losses"][i], name=str(i))
     eng = model._engine
     for nm, ref_v in (("pred", g["pred"]), ("futp", g["fut"]), ("z", g["z"]), ("mu", g["mu"]), ("logvar", g["logvar"])):
         got = eng.ws.t[nm][:ref_v.size].view(*ref_v.shape).cpu().numpy()
         np.testing.assert_allclose(got, ref_v, atol=3e-5, err_msg=nm)
     for k, p in model.named_parameters():
         gr = g["g/" + k]
-        np.testing.assert_allclose(p.grad.cpu().numpy(), gr, atol=3e-4 * max(np.abs(gr).max(), 1e-3), err_msg=k)
+        assert_grad_close(p.grad.cpu().numpy(), gr, TINY_REL, k, step_scale_of(g["g/" + kk] for kk, _ in model.named_parameters()))
     # autograd path with the same injected draws
     model.zero_grad(set_to_none=False)
     res = model(x, eps=eps, drop_mask=mask)
@@ -287,7 +350,7 @@ def check_fused_heads_match(dev):
     (t0, g0, p0), (t1, g1, p1) = outs
     np.testing.assert_allclose(t1, t0, rtol=2e-5)
     np.testing.assert_allclose(p1, p0, atol=2e-5)
-    np.testing.assert_allclose(g1, g0, atol=3e-5 * max(1.0, float(np.abs(g0).max())))
+    np.testing.assert_allclose(g1, g0, atol=3e-5 * float(np.abs(g0).max()))
 
 
 def check_stale_backward_guard(dev):

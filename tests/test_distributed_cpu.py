@@ -198,6 +198,22 @@ def test_bench_script_launches_its_own_ranks(emu):
     assert r.returncode != 0 and "WORLD_SIZE=1" in r.stderr
 
 
+def test_collective_path_single_rank_forced(emu, tmp_path_factory):
+    """The one-rank run of the whole collective path that `-m gpu` executes through RCCL (tests/test_distributed_gpu.py), here
+    through gloo on the host emulator: same script."""
+    import json
+    import subprocess
+    import driver_cases as dc
+    root, cfg, g = dc.make_project(tmp_path_factory)
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(VAME_EMU_THREADS="4")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "dist_world1_script.py"), str(root), "emu"], capture_output=True,
+                       text=True, timeout=900, env=env, cwd=ROOT)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("WORLD1_OK ")]
+    assert len(line) == 1 and json.loads(line[0][len("WORLD1_OK "):])["backend"] == "gloo"
+
+
 def _driver_worker(rank, world, port, root):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))

@@ -2,18 +2,29 @@
 reference's golden vectors (tiny model).  The same bodies run on the GPU in test_model_gpu.py."""
 import pytest
 
-from model_cases import check_fused_heads_match, check_adam_trajectory, check_coop_failure_is_contained, check_odd_dims_vs_oracle, check_eval_and_submodules, check_evaluate_and_generative_cores, check_h0_view, check_device_window_loader, check_legacy_step, check_model_options, check_noise_input, check_stale_backward_guard, check_step
+from model_cases import check_decoder_inputs, check_padded_hidden_sizes, check_fused_heads_match, check_adam_trajectory, check_coop_failure_is_contained, check_odd_dims_vs_oracle, check_eval_and_submodules, check_evaluate_and_generative_cores, check_h0_view, check_device_window_loader, check_legacy_step, check_model_options, check_noise_input, check_stale_backward_guard, check_step
 
 
 @pytest.mark.parametrize("name,kw,mse", [("step_tiny", 1.0, "sum"), ("step_tiny", 0.25, "sum"), ("step_tiny_oddB", 1.0, "sum"),
                                          ("step_tiny_nofut", 1.0, "sum"), ("step_tiny_softplus", 1.0, "sum"),
-                                         ("step_tiny_mean", 1.0, "mean"), ("step_h64", 0.5, "sum")])
+                                         ("step_tiny_mean", 1.0, "mean"), ("step_h64", 0.5, "sum"),
+                                         ("step_tiny_mean_kw025", 0.25, "mean"), ("step_h64_mean", 0.5, "mean")])
 def test_fused_step_matches_reference(emu, name, kw, mse):
     check_step("cpu", name, kw, mse)
 
 
 def test_autograd_path_matches_reference(emu):
     check_step("cpu", "step_tiny", 1.0, via_autograd=True)
+
+
+def test_hidden_sizes_not_multiple_of_32(emu):
+    """VERDICT r2 #8: nn.GRU takes any hidden_size; the kernels run on a zero-padded parameter image (vame_amd/padding.py)."""
+    check_padded_hidden_sizes("cpu")
+
+
+def test_decoders_over_arbitrary_inputs(emu):
+    """VERDICT r2 #8: Decoder.forward(inputs, z) with inputs that are not z tiled over time (rnn_model.py:99-109)."""
+    check_decoder_inputs("cpu")
 
 
 def test_eval_and_submodules(emu):

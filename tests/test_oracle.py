@@ -6,6 +6,7 @@ import numpy as np
 import pytest
 
 from conftest import GOLDEN, golden_weights, load_golden
+from tolerances import TINY_REL, assert_grad_close, assert_loss_close, step_scale_of
 from oracle import vame_oracle as vo
 
 
@@ -18,6 +19,7 @@ def spec_of(g):
     ("step_tiny", 0.0, "sum"), ("step_tiny", 0.25, "sum"), ("step_tiny", 1.0, "sum"),
     ("step_tiny_oddB", 1.0, "sum"), ("step_tiny_nofut", 1.0, "sum"), ("step_tiny_softplus", 1.0, "sum"),
     ("step_tiny_mean", 1.0, "mean"), ("step_h64", 0.5, "sum"),
+    ("step_tiny_mean_kw025", 0.25, "mean"), ("step_h64_mean", 0.5, "mean"), ("step_h40", 1.0, "sum"),
 ])
 def test_step_forward_losses_grads(name, kw, mse):
     g = load_golden(name)
@@ -36,14 +38,24 @@ def test_step_forward_losses_grads(name, kw, mse):
     L = vo.total_loss(pred, fut, z, mu, lv, g["x"], g["xfut"], spec, kw, mse_red=mse, mse_pred=mse)
     ref = g[tag + "losses"]
     for i, k in enumerate(["rec", "fut", "kl", "kmeans", "total"]):
-        assert abs(L[k] - ref[i]) <= 1e-4 * max(1.0, abs(ref[i])), (k, L[k], ref[i])
+        assert_loss_close(L[k], ref[i], name=k)
     # the reference's (B,B)-SVD form equals the (Z,Z)-Gram form
-    assert abs(vo.cluster_loss_svd(z, spec.Z, 0.1, z.shape[0]) - ref[3]) <= 1e-4 * max(1, abs(ref[3]))
+    assert_loss_close(vo.cluster_loss_svd(z, spec.Z, 0.1, z.shape[0]), ref[3], name="svd form")
     grads = vo.model_backward(p, cache, spec, g["x"], g["xfut"], kw, mse_red=mse, mse_pred=mse)
+    sscale = step_scale_of(g[tag + "g/" + k] for k in grads)
     for k, gv in grads.items():
-        r = g[tag + "g/" + k]
-        tol = 2e-4 * max(1.0, np.abs(r).max())
-        np.testing.assert_allclose(gv, r, atol=tol, err_msg=k)
+        assert_grad_close(gv, g[tag + "g/" + k], TINY_REL, k, sscale)            # relative to each tensor's own max
+
+
+def test_decoders_over_arbitrary_inputs():
+    """Decoder / Decoder_Future called with inputs that are NOT z tiled over time (rnn_model.py:99-109,132-144)."""
+    g = load_golden("decoder_inputs")
+    T, F, Z, H, FS = [int(v) for v in g["spec"]]
+    p = golden_weights(g)
+    for B in (1, 5):
+        z, ins = g[f"B{B}/z"], g[f"B{B}/ins"]
+        np.testing.assert_allclose(vo.decoder_forward(p, z, T, "decoder", "rnn_rec", inputs=ins), g[f"B{B}/pred"], atol=2e-6)
+        np.testing.assert_allclose(vo.decoder_forward(p, z, FS, "decoder_future", "rnn_pred", inputs=ins), g[f"B{B}/fut"], atol=2e-6)
 
 
 def test_eval_mode_forward():
@@ -122,10 +134,10 @@ def test_torch_cpu_baseline_model_matches_reference():
     loss.backward()
     ref = g["kw1/losses"]
     for v, r in zip(list(terms) + [loss], ref):
-        assert abs(v.item() - r) <= 1e-5 * max(1, abs(r))
+        assert_loss_close(v.item(), r, rel=1e-5)
     for k, gr in m.reference_named_grads().items():
         r = g["kw1/g/" + k]
-        np.testing.assert_allclose(gr.numpy(), r, atol=1e-5 * max(1, np.abs(r).max()), err_msg=k)
+        assert_grad_close(gr.numpy(), r, 1e-5, k)
 
 
 @pytest.mark.parametrize("name,fixed", [("prep_aligned", False), ("prep_fixed", True)])
@@ -161,7 +173,7 @@ def test_torch_legacy_restatement_matches_reference():
     for k, p in m.named_parameters():
         ref = g["g/" + k]
         got = p.grad.numpy() if p.grad is not None else np.zeros_like(ref)
-        np.testing.assert_allclose(got, ref, atol=2e-4 * max(np.abs(ref).max(), 1e-3), err_msg=k)
+        assert_grad_close(got, ref, TINY_REL, k, step_scale_of(g["g/" + kk] for kk, _ in m.named_parameters()))
 
 
 @pytest.mark.parametrize("name", ["step_tiny_dropout", "step_tiny_hsizes"])
@@ -180,11 +192,10 @@ def test_model_options_dropout_and_hidden_sizes(name):
     kw = float(g["kw"][0])
     L = vo.total_loss(pred, futp, z, mu, lv, g["x"], g["xfut"], spec, kw)
     for i, k in enumerate(["rec", "fut", "kl", "kmeans"]):
-        assert abs(L[k] - g["losses"][i]) <= 1e-4 * max(1.0, abs(g["losses"][i])), (k, L[k], g["losses"][i])
+        assert_loss_close(L[k], g["losses"][i], name=k)
     grads = vo.model_backward(p, cache, spec, g["x"], g["xfut"], kw)
     for k, gv in grads.items():
-        r = g["g/" + k]
-        np.testing.assert_allclose(gv, r, atol=2e-4 * max(1.0, np.abs(r).max()), err_msg=k)
+        assert_grad_close(gv, g["g/" + k], TINY_REL, k, step_scale_of(g["g/" + kk] for kk in grads))
     ep, ef, ez, emu, elv = vo.model_forward(p, g["x"], None, spec, training=False, drop_mask=mask)     # eval: no dropout
     np.testing.assert_allclose(emu, g["eval_mu"], atol=1e-5)
     np.testing.assert_allclose(ep, g["eval_pred"], atol=2e-5)

@@ -36,3 +36,18 @@ def test_kernel_trace_digest_separates_launches_of_one_kernel_by_grid(tmp_path):
     big = st[("gemm_kernel<128,128,2,2,true,true,5,2>", 589824)]
     assert int(big["calls"]) == 2 and float(big["avg_us"]) == 2.6 and float(big["min_us"]) == 2.5 and float(big["max_us"]) == 2.7
     assert int(st[("gemm_kernel<128,128,2,2,true,true,5,2>", 393216)]["calls"]) == 1
+
+
+def test_vame_alias_shim_installer(tmp_path):
+    """tools/install_vame_alias.py writes a `vame` package whose import turns into the vame_amd alias -- checked in a fresh interpreter
+    with only that directory added to sys.path (the reference's own script header `import vame` then works unmodified)."""
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "install_vame_alias.py"), str(tmp_path)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    code = ("import sys; sys.path[:0] = [%r, %r]; import vame; import vame_amd; from vame.model.rnn_vae import RNN_VAE; "
+            "assert vame.train_model is vame_amd.train_model and vame.__vame_amd_alias__; print('ALIAS_OK')" % (str(tmp_path), ROOT))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True)
+    assert "ALIAS_OK" in r.stdout, r.stderr[-1500:]
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "install_vame_alias.py"), str(tmp_path)], capture_output=True, text=True)
+    assert r.returncode != 0 and "exists" in r.stderr              # never silently overwrites an existing `vame` package

@@ -12,6 +12,12 @@ def project(tmp_path_factory, hip):
     return dc.make_project(tmp_path_factory)
 
 
+def test_reference_import_names_resolve_to_the_build(hip):
+    """`import vame`, `from vame.model.rnn_vae import RNN_VAE`, ... through the opt-in alias (vame_amd/compat.py).
+    Every test below drives the build through `import vame` in the reference's call order (examples/demo.py:48-56)."""
+    dc.check_alias_surface()
+
+
 def test_train_model_files_and_losses(project):
     dc.check_train_model_files_and_losses(project)
 

@@ -73,7 +73,7 @@ def embedd_latent_vectors(cfg, files, model, fixed):
         print('Embedding of latent vector for file %s' % file)
         data = np.load(os.path.join(project_path, 'data', file, file + '-PE-seq-clean.npy'))
         shard, (lo, hi) = embed_series(model, data, rank=rank, world=world)
-        if world > 1:
+        if dist.is_available() and dist.is_initialized():
             n = data.shape[1] - cfg['time_window']
             per = -(-n // world)
             padded = torch.zeros(per, shard.shape[1], device=shard.device)
@@ -277,6 +277,6 @@ def pose_segmentation(config):
                 np.save(os.path.join(save_data, 'cluster_center_' + f), cluster_center[idx])
             np.save(os.path.join(save_data, 'latent_vector_' + f), latent_vectors[idx])
             np.save(os.path.join(save_data, 'motif_usage_' + f), motif_usages[idx])
-        if world > 1:
+        if dist.is_available() and dist.is_initialized():
             dist.barrier()
         print("You succesfully extracted motifs with VAME! From here, you can proceed running vame.motif_videos() ")

@@ -385,6 +385,22 @@ extern "C" int vame_adam_amsgrad_f32(float* p, const float* g, float* m, float* 
     return VAME_OK;
 }
 
+// --------------------------------------------------------------------------------- indexed copy (padded parameter images)
+// dst[dst_idx[i]] = src[src_idx[i]]: moves the model's parameters into the zero-padded image the kernels run on when a hidden
+// size is not a multiple of 32 (and the padded gradients back); both index lists are ascending, so accesses stay nearly coalesced.
+__global__ __launch_bounds__(256) void index_copy_kernel(float* __restrict__ dst, const int64_t* __restrict__ dst_idx,
+                                                         const float* __restrict__ src, const int64_t* __restrict__ src_idx, int64_t n) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        dst[dst_idx[i]] = src[src_idx[i]];
+}
+extern "C" int vame_index_copy_f32(float* dst, const int64_t* dst_idx, const float* src, const int64_t* src_idx, int64_t n, void* stream) {
+    VAME_CHECK_ARG(dst && dst_idx && src && src_idx && n >= 0, VAME_E_BADARG, "index_copy: bad argument");
+    if (n == 0) return VAME_OK;
+    hipLaunchKernelGGL(index_copy_kernel, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, dst, dst_idx, src, src_idx, n);
+    VAME_LAUNCH_CHECK("index_copy");
+    return VAME_OK;
+}
+
 __global__ __launch_bounds__(256) void axpy_kernel(const float* __restrict__ x, float a, float* __restrict__ y, int64_t n) {
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
         y[i] += a * x[i];

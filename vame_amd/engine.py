@@ -541,7 +541,7 @@ class VAEEngine:
         ops.latent_fwd(mu, lvr, eps, B, Z, s.softplus, training, logvar, z, losses[LOSS_KLSUM:] if want_kl else None)
         return z, mu, logvar
 
-    def _decode_one(self, tag, name, dirs, steps, z, B, training, rows, jobs):
+    def _decode_one(self, tag, name, dirs, steps, z, B, training, rows, jobs, inputs=None):
         H, Z = dirs[0].H, self.spec.Z
         hid = None
         if self.h0_from_z:
@@ -550,23 +550,33 @@ class VAEEngine:
                                          bias=self._pv(f"{name}.latent_to_hidden.bias")))
         Y = self.buf(f"Y_{tag}", B, steps + 2, 2 * H)
         for dirn, d in enumerate(dirs):
-            gi = self.buf(f"gi_{tag}_{dirn}", B, 3 * H)
-            jobs.append(lambda d=d, gi=gi: ops.gemm(B, 3 * H, Z, Operand(z, Z), 0, self.P(d.w_ih, Z), 0, gi, 3 * H, bias=d.bias_gi))
             st = self.buf(f"st_{tag}_{dirn}", ops.gru_stash_floats(B, steps, H)) if training else None
-            # hidden.view(2,B,H) (rnn_model.py:104,137): direction d, row b lives at flat offset (d*B+b)*H
-            rows.append(self._gru_fwd_stream(d, gi, 3 * H, 0, hid, dirn * B * H, Y, 2 * H, steps, dirn, None, 0, 0, st, steps))
+            h0_off = dirn * B * H          # hidden.view(2,B,H) (rnn_model.py:104,137): direction d, row b lives at flat offset (d*B+b)*H
+            if inputs is None:             # z at every step (rnn_model.py:169-170): one projection, constant in time
+                gi = self.buf(f"gi_{tag}_{dirn}", B, 3 * H)
+                jobs.append(lambda d=d, gi=gi: ops.gemm(B, 3 * H, Z, Operand(z, Z), 0, self.P(d.w_ih, Z), 0, gi, 3 * H, bias=d.bias_gi))
+                rows.append(self._gru_fwd_stream(d, gi, 3 * H, 0, hid, h0_off, Y, 2 * H, steps, dirn, None, 0, 0, st, steps))
+            else:                          # the caller's own sequence (B, L >= steps, Z): a projection per step, like encoder layer 1
+                ins, L = inputs
+                gi = self.buf(f"gi_seq_{tag}_{dirn}", B, steps, 3 * H)
+                jobs.append(lambda d=d, gi=gi: ops.gemm(B * steps, 3 * H, Z, Operand(ins, Z, seg=steps, seg_stride=L * Z), 0,
+                                                        self.P(d.w_ih, Z), 0, gi, 3 * H, bias=d.bias_gi))
+                rows.append(self._gru_fwd_stream(d, gi, steps * 3 * H, 3 * H, hid, h0_off, Y, 2 * H, steps, dirn, None, 0, 0, st, steps))
         return Y
 
-    def decode(self, z, B, training, which="both", heads=True):
+    def decode(self, z, B, training, which="both", heads=True, inputs=None):
         """Decoder (+ Decoder_Future) from z.  which = "dec" / "fut" runs only that one (the sub-module call patterns
-        model.decoder(ins, z) / model.decoder_future(ins, z) of generative_functions.py:39)."""
+        model.decoder(ins, z) / model.decoder_future(ins, z) of generative_functions.py:39).  inputs = (tensor (B, L, Z) contiguous, L):
+        the GRUs run over this sequence instead of z tiled over time (inference only; rnn_model.py:99-109 accepts any `inputs`)."""
+        if inputs is not None and training:
+            raise ValueError("decode(inputs=...) is an inference path; training builds the decoder input from z (rnn_model.py:169-170)")
         s, H, F, T, FS = self.spec, self.spec.H, self.spec.F, self.spec.T, self.spec.FS
         self.repack()
         self.serial += 1
         rows, jobs = [], []
         want_d, want_f = which in ("both", "dec"), s.future and which in ("both", "fut")
-        Yd = self._decode_one("dec", "decoder", self.dec, T, z, B, training, rows, jobs) if want_d else None
-        Yf = self._decode_one("fut", "decoder_future", self.fut, FS, z, B, training, rows, jobs) if want_f else None
+        Yd = self._decode_one("dec", "decoder", self.dec, T, z, B, training, rows, jobs, inputs) if want_d else None
+        Yf = self._decode_one("fut", "decoder_future", self.fut, FS, z, B, training, rows, jobs, inputs) if want_f else None
         self._parallel(jobs, self.small_streams)      # <= 6 independent (B x 3H|2H x Z) projections of z
         self._gru_fwd(rows, B)
         H, Hf = s.Hd, s.Hf

@@ -19,8 +19,12 @@ import numpy as np
 import torch
 
 from .. import ops
-from ..analysis.pose_segmentation import _device
+from .. import _lib
 from ..util.auxiliary import read_config
+
+
+def _device():
+    return _lib.device()          # looked up at call time (raises without an MI355X)
 
 
 def _iqr(z):

@@ -19,7 +19,7 @@ from pathlib import Path
 import numpy as np
 import torch
 
-from ..analysis.pose_segmentation import _device
+from .. import _lib
 from ..util.auxiliary import read_config
 from .dataloader import SEQUENCE_DATASET, DeviceWindowLoader
 from .rnn_model import RNN_VAE
@@ -28,6 +28,10 @@ TEST_BATCH_SIZE = 64
 _LOSS_CURVES = (('train_losses_', 'Train-Loss'), ('test_losses_', 'Test-Loss'), ('mse_train_losses_', 'MSE-Train-Loss'),
                 ('mse_test_losses_', 'MSE-Test-Loss'), ('kmeans_losses_', 'KMeans-Loss'), ('kl_losses_', 'KL-Loss'),
                 ('fut_losses_', 'Prediction-Loss'))
+
+
+def _device():
+    return _lib.device()          # looked up at call time (raises without an MI355X)
 
 
 def _pyplot():

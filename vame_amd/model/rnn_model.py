@@ -15,6 +15,7 @@ from torch import nn
 
 from .. import _lib
 from ..engine import ParamTable, Spec, VAEEngine
+from ..padding import PadMap, needs_padding
 
 
 class _EngineOwner:
@@ -45,6 +46,9 @@ class Encoder(nn.Module, _EngineOwner):
         with torch.no_grad():
             hn = eng.encode(x, T * F, B, training=False)
             out = hn[:B * 4 * eng.spec.H].view(B, 4 * eng.spec.H).clone()
+            pad = self._owner[0]._pad
+            if pad is not None:                      # hidden size not a multiple of 32: drop the padded units (vame_amd/padding.py)
+                out = pad.unpad_cols(out, 4, pad.true_spec.H)
         eng.check_async_errors()
         return out
 
@@ -64,6 +68,9 @@ class Lambda(nn.Module, _EngineOwner):
         """(B,4H) -> (z, mean, logvar); eval mode returns (mean, mean, logvar) (rnn_model.py:63-76)."""
         eng = self._eng()
         h = _as_f32(hidden, eng.dev)
+        pad = self._owner[0]._pad
+        if pad is not None:
+            h = pad.pad_cols(h, 4, pad.true_spec.H)
         B, Z = h.shape[0], eng.spec.Z
         with torch.no_grad():
             if self.training and eps is None:
@@ -79,18 +86,23 @@ class _DecoderBase(nn.Module, _EngineOwner):
         eng = self._eng()
         zt = _as_f32(z, eng.dev)
         B = zt.shape[0]
-        # `inputs` is z tiled over time in every reference caller (rnn_model.py:169-170, generative_functions.py:36-39); the kernels
-        # read z once.  A caller that passes something else gets an error instead of silently different numbers.
+        # `inputs` is z tiled over time in every reference caller (rnn_model.py:169-170, generative_functions.py:36-39): then the
+        # kernels read z once.  Any other sequence (the modules run their GRU over whatever they are given, rnn_model.py:106,139-140)
+        # takes the per-step input projection the encoder's second layer uses.
+        seq = None
         if inputs is not None and torch.is_tensor(inputs):
             steps = eng.spec.T if which == "dec" else eng.spec.FS
-            _check(inputs.dim() == 3 and inputs.shape[0] == B and inputs.shape[1] >= steps and inputs.shape[2] == eng.spec.Z,
-                   f"decoder inputs {tuple(inputs.shape)}: expected z tiled over time (B, >={steps}, {eng.spec.Z})")
-            it = inputs.detach().to(device=eng.dev, dtype=torch.float32)
-            _check(bool(torch.equal(it[:, 0, :], zt) and torch.equal(it[:, steps - 1, :], zt)),
-                   "vame_amd decoders take the latent tiled over time as `inputs` (as RNN_VAE.forward builds it); other inputs are "
-                   "not supported by the fused kernels")
+            # Decoder returns one output per input step (rnn_model.py:106-109) and the model is built for seq_len steps;
+            # Decoder_Future reads inputs[:, :future_steps] (rnn_model.py:139)
+            ok_len = inputs.dim() == 3 and (inputs.shape[1] == steps if which == "dec" else inputs.shape[1] >= steps)
+            _check(ok_len and inputs.shape[0] == B and inputs.shape[2] == eng.spec.Z,
+                   f"decoder inputs {tuple(inputs.shape)}: expected (B, {'' if which == 'dec' else '>='}{steps}, {eng.spec.Z})")
+            it = _as_f32(inputs, eng.dev)
+            tiled = bool(torch.equal(it[:, :steps, :], zt[:, None, :].expand(B, steps, eng.spec.Z)))
+            if not tiled:
+                seq = (it, it.shape[1])
         with torch.no_grad():
-            pred, fut = eng.decode(zt, B, training=False, which=which)
+            pred, fut = eng.decode(zt, B, training=False, which=which, inputs=seq)
             s = eng.spec
             out = pred[:B * s.T * s.F].view(B, s.T, s.F).clone() if which == "dec" else fut[:B * s.FS * s.F].view(B, s.FS, s.F).clone()
         eng.check_async_errors()
@@ -172,11 +184,15 @@ class _VAEFunction(torch.autograd.Function):
         if s.future:
             seed("dfut", dfut, B * s.FS * s.F)
         c = lambda g: None if g is None else g.contiguous()
-        eng.g = model._flat_gtmp
-        try:
+        if model._pad is not None:                   # the engine writes the padded gradient image; the real entries go to the temp bucket
             eng.backward(B, 0.0, 0.0, dz_ext=c(dz), dmu_ext=c(dmu), dlv_ext=c(dlv), use_minv=False)
-        finally:
-            eng.g = model._flat_g
+            model._pad.pull_grads(model._flat_gtmp)
+        else:
+            eng.g = model._flat_gtmp
+            try:
+                eng.backward(B, 0.0, 0.0, dz_ext=c(dz), dmu_ext=c(dmu), dlv_ext=c(dlv), use_minv=False)
+            finally:
+                eng.g = model._flat_g
         model._accumulate_tmp_grads()
         return (None, None, None, None) + (None,) * len(model._param_list)
 
@@ -207,6 +223,7 @@ class RNN_VAE(nn.Module):
                 object.__setattr__(m, "_owner", (self,))       # tuple: not registered as a sub-module
         self._flat_p = self._flat_g = self._flat_gtmp = None
         self._engine = None
+        self._pad = None
         self._register_state_dict_hook(_clone_state_dict)
 
     def _build_modules(self, ZDIMS, NUM_FEATURES, FUTURE_DECODER, FUTURE_STEPS, h1, h2, h_rec, h_pred, d_enc, d_rec, d_pred, softplus):
@@ -239,7 +256,16 @@ class RNN_VAE(nn.Module):
             self._flat_p, self._flat_g = flat_p, flat_g
             self._flat_gtmp = torch.zeros_like(flat_g)
             self._param_list = [p for _, p in plist]
-            self._engine = VAEEngine(self.spec, self._table, flat_p, flat_g)
+            if needs_padding(self.spec):
+                # a hidden size that is not a multiple of 32 (torch.nn.GRU takes any): the kernels run on a zero-padded image of
+                # the parameters; the model, its state_dict, the optimizer and the all-reduce keep the reference's shapes
+                self._pad = PadMap(self.spec, self._table, [(n, tuple(p.shape)) for n, p in plist], dev)
+                self._engine = VAEEngine(self._pad.spec, self._pad.table, self._pad.p, self._pad.g)
+            else:
+                self._pad = None
+                self._engine = VAEEngine(self.spec, self._table, flat_p, flat_g)
+        if self._pad is not None:
+            self._pad.push_params(self._flat_p)
         self._engine.version += 1          # weights may have changed since the last call: repack (a few tiny kernels)
         return self._engine
 
@@ -267,10 +293,16 @@ class RNN_VAE(nn.Module):
         if not (self.training and s.dropout > 0):
             return None
         if drop_mask is None:
-            return torch.bernoulli(torch.full((B, s.T, 2 * s.H), 1.0 - s.dropout, device=dev))
+            drop_mask = torch.bernoulli(torch.full((B, s.T, 2 * s.H), 1.0 - s.dropout, device=dev))
         drop_mask = drop_mask.to(device=dev, dtype=torch.float32).contiguous()
         _check(tuple(drop_mask.shape) == (B, s.T, 2 * s.H), f"drop_mask {tuple(drop_mask.shape)} != {(B, s.T, 2 * s.H)}")
         return drop_mask
+
+    def _engine_mask(self, mask):
+        """The keep-mask in the engine's (possibly padded) hidden-unit layout."""
+        if mask is None or self._pad is None:
+            return mask
+        return self._pad.pad_cols(mask, 2, self.spec.H, fill=1.0).contiguous()
 
     def forward(self, seq, eps=None, drop_mask=None):
         """rnn_model.py:162-179.  Returns (prediction, future, z, mu, logvar) or, without the
@@ -286,7 +318,7 @@ class RNN_VAE(nn.Module):
             if eps is None:
                 eps = torch.randn(B, s.Z, device=eng.dev)
             eps = eps.to(device=eng.dev, dtype=torch.float32).contiguous()
-        drop_mask = self._dropout_mask(B, drop_mask, eng.dev)
+        drop_mask = self._engine_mask(self._dropout_mask(B, drop_mask, eng.dev))
         if self.training and torch.is_grad_enabled():
             pred, fut, z, mu, lv = _VAEFunction.apply(self, x, eps, drop_mask, *self._param_list)
         else:
@@ -324,12 +356,14 @@ class RNN_VAE(nn.Module):
                 enc_in = enc_in.to(device=eng.dev, dtype=torch.float32).contiguous()
                 _check(tuple(enc_in.shape) == (B, s.T, F), f"enc_in {tuple(enc_in.shape)} != {(B, s.T, F)}")
             eng.forward(win, L * F, B, eps, training, cluster=(kl_weight, kloss, klmbda, bsize), enc_in=enc_in,
-                        drop_mask=self._dropout_mask(B, drop_mask, eng.dev), defer_heads=True)
+                        drop_mask=self._engine_mask(self._dropout_mask(B, drop_mask, eng.dev)), defer_heads=True)
             # test(): no future term (rnn_vae.py:183-198)
             losses = eng.loss(B, win, L * F, s.T * F, kl_weight, kloss, klmbda, bsize, mse_red, mse_pred,
                               with_future=training and s.future)
             if backward and training:
                 eng.backward(B, kl_weight, beta)
+                if self._pad is not None:
+                    self._pad.pull_grads(self._flat_g)
             out = losses[:4].clone()
             out[2] = out[2] * (-0.5 / (B * s.Z))
             if mse_red != "sum":

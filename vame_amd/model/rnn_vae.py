@@ -136,10 +136,16 @@ def _world():
     return 0, 1
 
 
+def _dist_active():
+    """True when this package runs under a process group (several ranks, or one rank with VAME_AMD_FORCE_DIST=1 -- the
+    single-GPU way to execute the RCCL path: init, collectives, barriers, shutdown)."""
+    return dist.is_available() and dist.is_initialized()
+
+
 def _rank_mean(t):
     """Average a small statistics tensor over ranks so every rank takes the same scheduler / checkpoint decisions."""
     _, world = _world()
-    if world > 1:
+    if _dist_active():
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
         t = t / world
     return t
@@ -149,7 +155,7 @@ def allreduce_gradients(model):
     """One RCCL all-reduce (SUM) of the flat fp32 gradient bucket over xGMI; the 1/world factor is folded
     into the Adam kernel.  2,618,476 floats = 10.5 MB at the default model size."""
     _, world = _world()
-    if world > 1:
+    if _dist_active():
         n = model.flat_parameters()[1].numel()
         bucket, eng = model._flat_g_comm, model._engine
         # the status word of this rank's cooperative launches rides the same all-reduce (slot n): afterwards it is non-zero on
@@ -231,8 +237,10 @@ def test(test_loader, epoch, model, optimizer, BETA, kl_weight, seq_len, mse_red
 
 # ------------------------------------------------------------------------------------ driver
 def _maybe_init_distributed():
-    """One process per GPU under torchrun (RANK/WORLD_SIZE/LOCAL_RANK in the env): RCCL over xGMI."""
-    if int(os.environ.get("WORLD_SIZE", "1")) > 1 and not dist.is_initialized():
+    """One process per GPU under torchrun (RANK/WORLD_SIZE/LOCAL_RANK in the env): RCCL over xGMI.  VAME_AMD_FORCE_DIST=1 creates
+    the group for WORLD_SIZE=1 as well (RANK / MASTER_ADDR / MASTER_PORT must be set): the whole collective path then runs on one GPU."""
+    forced = os.environ.get("VAME_AMD_FORCE_DIST", "0") not in ("", "0")
+    if (int(os.environ.get("WORLD_SIZE", "1")) > 1 or forced) and not dist.is_initialized():
         local = int(os.environ.get("LOCAL_RANK", "0"))
         if torch.cuda.is_available():
             torch.cuda.set_device(local)
@@ -331,10 +339,10 @@ def train_model(config):
             print("Could not load pretrained model. Check file path in config.yaml.")
 
     data_dir = os.path.join(pp, "data", "train", "")
-    if world > 1 and not is_main:
+    if _dist_active() and not is_main:
         dist.barrier()                      # let rank 0 create seq_mean/std first
     trainset = SEQUENCE_DATASET(data_dir, data='train_seq.npy', train=True, temporal_window=TEMPORAL_WINDOW)
-    if world > 1 and is_main:
+    if _dist_active() and is_main:
         dist.barrier()
     testset = SEQUENCE_DATASET(data_dir, data='test_seq.npy', train=False, temporal_window=TEMPORAL_WINDOW)
     keep = TEMPORAL_WINDOW // 2 + (FUTURE_STEPS if FUTURE_DECODER else 0)
@@ -392,7 +400,7 @@ def train_model(config):
                 np.save(os.path.join(loss_dir, nm + model_name), arr)
         print("\n")
 
-    if world > 1:
+    if _dist_active():
         dist.barrier()                      # rank 0's checkpoint / loss files are complete before any rank goes on (pose_segmentation)
     if convergence < cfg['model_convergence']:
         print('Finished training...')

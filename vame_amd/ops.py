@@ -394,6 +394,12 @@ def mask_scale(x, off, ld, seg, seg_stride, mask, scale, out, R, C):
     _lib.check(rc, "vame_mask_scale_f32")
 
 
+def index_copy(dst, dst_idx, src, src_idx):
+    """dst[dst_idx[i]] = src[src_idx[i]] (int64 element indices)."""
+    rc = _lib.lib().vame_index_copy_f32(_ptr(dst), _ptr(dst_idx), _ptr(src), _ptr(src_idx), dst_idx.numel(), _stream())
+    _lib.check(rc, "vame_index_copy_f32")
+
+
 def axpy(x, a, y, n, x_off=0, y_off=0):
     rc = _lib.lib().vame_axpy_f32(_ptr(x, x_off), float(a), _ptr(y, y_off), n, _stream())
     _lib.check(rc, "vame_axpy_f32")
