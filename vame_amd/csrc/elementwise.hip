@@ -761,7 +761,9 @@ __global__ __launch_bounds__(256) void nuclear_kernel(const float* __restrict__ 
             const double wj = A[j * n + j];
             rank += (wj > w) || (wj == w && j < tid);
         }
-        wsel[tid] = (rank < keff && w > 0.0) ? sqrt(w) : 0.0;
+        const double sv = (rank < keff && w > 0.0) ? sqrt(w) : 0.0;
+        wsel[tid] = sv;
+        cs[tid] = sv > 0.0 ? 1.0 / sv : 0.0;                 // one division per eigenvalue, not one per term of the Minv sums below
     }
     __syncthreads();
     if (tid == 0) {
@@ -770,14 +772,12 @@ __global__ __launch_bounds__(256) void nuclear_kernel(const float* __restrict__ 
         loss_out[0] = (float)(lmbda * s);
     }
     if (Minv) {
+        const double scale = (double)gscale * (double)lmbda / (double)bsize;
         for (int i = tid; i < Z * Z; i += 256) {
             const int a = i / Z, b = i % Z;
             double s = 0.0;
-            for (int j = 0; j < Z; ++j) {
-                const double sv = wsel[j];
-                if (sv > 0.0) s += V[a * n + j] * V[b * n + j] / sv;
-            }
-            Minv[i] = (float)((double)gscale * (double)lmbda / (double)bsize * s);
+            for (int j = 0; j < Z; ++j) s += V[a * n + j] * V[b * n + j] * cs[j];
+            Minv[i] = (float)(scale * s);
         }
     }
 }

@@ -140,6 +140,18 @@ class VAEEngine:
         self.wide_bwd = os.environ.get("VAME_AMD_WIDE_BWD", "1") != "0"      # 0: BPTT step by step (per-step GEMM + gate kernel)
         self._coop_state = None
         self._nuc_state = None
+        # nuclear-norm solve (one workgroup, ~0.2 ms, nothing else on the chip) on a side stream NEXT TO THE OUTPUT HEADS: it starts
+        # when the decoders' GRU launch has finished and runs beside the HBM-bound head / MSE / dY kernels, which leave most of a
+        # CU's registers and LDS free -- unlike the GRU launches, which need whole CUs (a solve beside them was measured to cost
+        # as much as it saves).  Joined before dz reads Minv and before the loss terms are handed out.
+        self.nuc_side = os.environ.get("VAME_AMD_NUC_SIDE", "1") != "0"
+        # the future decoder's two dW_hh contractions beside the small-kernel chain that follows the decoders' BPTT launch (_early_wgrads)
+        self.bwd_overlap = os.environ.get("VAME_AMD_BWD_OVERLAP", "1") != "0"
+        self.skinny_side = os.environ.get("VAME_AMD_SKINNY_SIDE", "1") != "0"
+        self._early_stream, self._early_pending = None, False
+        self._nuc_stream = None
+        self._nuc_pending = None          # arguments of a deferred cluster_terms()
+        self._nuc_event = None            # recorded on the side stream after the solve
         self._drop_mask = None
         self.packed_version = -1
         self.version = 0          # bumped by the owner whenever flat_p changes
@@ -190,7 +202,29 @@ class VAEEngine:
             n *= s
         return self.ws.get(name, n, self.dev, zero=zero)
 
-    def _group_wgrads(self, jobs):
+    def _early_wgrads(self, after_event, pick):
+        """Issue the queued weight-gradient GEMMs selected by `pick(job)` NOW, on a side stream that starts at `after_event`
+        (recorded behind the BPTT launch that produced their operands).  Used for ONE MFMA-bound contraction next to the chain of
+        small / HBM-bound kernels between the decoders' BPTT launch and the encoder's (time sums, dz, Lambda backward: ~0.4 ms in
+        which most CUs idle); the caller joins the stream before the next GRU launch, which wants every CU for itself."""
+        mine = [j for j in self._wgrad_queue if pick(j)]
+        if len(mine) < 1:
+            return
+        self._wgrad_queue = [j for j in self._wgrad_queue if not pick(j)]
+        if self._early_stream is None:
+            self._early_stream = torch.cuda.Stream(device=self.dev)
+        self._early_stream.wait_event(after_event)
+        with torch.cuda.stream(self._early_stream):
+            for j in self._group_wgrads(mine, ws_name="splitk_early"):
+                self._gemm_wgrad_now(*j, lane="_early")
+        self._early_pending = True
+
+    def _join_early(self):
+        if self._early_pending:
+            torch.cuda.current_stream(self.dev).wait_stream(self._early_stream)
+            self._early_pending = False
+
+    def _group_wgrads(self, jobs, ws_name="splitk_group", after_first=None):
         """Weight-gradient GEMMs of one shape and operand layout -- the dW_hh of the six
         T-step (layer, direction) streams, the two layer-1 dW_ih, the future decoder's two dW_hh -- go out as ONE grouped launch
         each (vame_gemm_group_f32): all their k-slabs are dealt to the XCDs together, so nothing idles at the boundary between
@@ -205,10 +239,16 @@ class VAEEngine:
                 groups.setdefault(key, []).append(j)
             else:
                 rest.append(j)
-        for key, members in groups.items():
+        launched = 0
+        # largest group first (the six T-step dW_hh contractions: the step's dominant launch); `after_first` runs behind it
+        for key, members in sorted(groups.items(), key=lambda kv: -kv[0][0] * kv[0][1] * kv[0][2] * len(kv[1])):
             if len(members) < 2:
                 rest += members
                 continue
+            if launched == 1 and after_first is not None:
+                after_first()
+                after_first = None
+            launched += 1
             M, N, K = key[:3]
             for i in range(0, len(members), 8):
                 part = members[i:i + 8]
@@ -221,7 +261,7 @@ class VAEEngine:
                 cands = [k for k in range(8, 129, 8) if k * 8 * 32 <= K]
                 full = [k for k in cands if tiles * k >= 2 * 768 and (tiles * k) % 768 == 0]
                 sk = full[0] if full else next((k for k in cands if tiles * k >= 2 * 768), cands[-1] if cands else 8)
-                ws = self.ws.get("splitk_group", len(part) * sk * M * N, self.dev)
+                ws = self.ws.get(ws_name, len(part) * sk * M * N, self.dev)
                 ops.gemm_group(M, N, K, [m[3] for m in part], 1, [m[4] for m in part], 1, self.g, [self.table.off(m[5]) for m in part],
                                N, sk, ws, a_gap_at=key[9], a_gap=key[10])
         return rest
@@ -260,6 +300,9 @@ class VAEEngine:
         if self._wgrad_queue is not None:
             self._wgrad_queue.append((M, N, K, A, B, gname, row_off, gap_at, gap))
             return
+        self._gemm_wgrad_now(M, N, K, A, B, gname, row_off, gap_at, gap, lane)
+
+    def _gemm_wgrad_now(self, M, N, K, A, B, gname, row_off=0, gap_at=0, gap=0, lane=0):
         sk = self._splitk(M, N, K)
         ws = self.ws.get(f"splitk{lane}", max(sk * M * N, 1), self.dev) if sk > 1 else None
         ops.gemm(M, N, K, A, 1, B, 1, self.g, N, c_off=self.table.off(gname) + row_off * N, splitk=sk, ws=ws,
@@ -298,7 +341,33 @@ class VAEEngine:
         if not jobs:
             return
         n = (self.wgrad_streams or (4 if (self._B_bwd or 0) <= 1024 else 1)) if self.dev.type == "cuda" else 1
-        jobs = self._group_wgrads(jobs)                  # same-shape contractions leave as grouped launches first
+        skinny = []
+        if self.skinny_side and n == 1 and self.dev.type == "cuda":
+            # large batches: the narrow contractions (an output dimension <= 32: the layer-0 / decoder dW_ih, the output heads', Lambda's)
+            # stream their K = batch x time operand at HBM speed with the matrix pipes nearly idle, the wide ones are MFMA-bound with
+            # HBM nearly idle -> the narrow ones run on a side stream beside the wide ones, starting BEHIND the dominant grouped launch
+            # (which keeps the chip to itself, so its duration stays a statement about that kernel)
+            skinny = [j for j in jobs if min(j[0], j[1]) <= 32]
+            jobs = [j for j in jobs if min(j[0], j[1]) > 32]
+
+        def start_skinny():
+            if not skinny:
+                return
+            if self._early_stream is None:
+                self._early_stream = torch.cuda.Stream(device=self.dev)
+            self._early_stream.wait_stream(torch.cuda.current_stream(self.dev))
+            with torch.cuda.stream(self._early_stream):
+                for j in self._group_wgrads(skinny, ws_name="splitk_skinny"):
+                    self._gemm_wgrad_now(*j, lane="_sk")
+            self._early_pending = True
+        jobs = self._group_wgrads(jobs, after_first=start_skinny)                  # same-shape contractions leave as grouped launches first
+        if skinny and not self._early_pending:
+            start_skinny()
+        if skinny:
+            for j in jobs:
+                self._gemm_wgrad(*j)
+            self._join_early()
+            return
         if n < 2 or len(jobs) < 2:
             for j in jobs:
                 self._gemm_wgrad(*j)
@@ -579,6 +648,7 @@ class VAEEngine:
         Yf = self._decode_one("fut", "decoder_future", self.fut, FS, z, B, training, rows, jobs, inputs) if want_f else None
         self._parallel(jobs, self.small_streams)      # <= 6 independent (B x 3H|2H x Z) projections of z
         self._gru_fwd(rows, B)
+        self._issue_pending_cluster()                 # the solve runs beside the output heads below
         H, Hf = s.Hd, s.Hf
         pred = None
         self._heads_deferred = not heads
@@ -610,6 +680,33 @@ class VAEEngine:
         ops.nuclear(G, Z, kloss, B, klmbda, bsize, self.buf("losses", 8), LOSS_KMEANS, self.buf("Minv", Z, Z), gscale=kl_weight,
                     vstate=self._nuc_state)
 
+    def set_overlap(self, on):
+        """Turn the three side-stream overlaps (nuclear-norm solve, early future-decoder dW_hh, narrow weight gradients) on / off
+        together; bench.py's per-kernel pass runs with them off so that a kernel's duration is its own."""
+        prev = (self.nuc_side, self.bwd_overlap, self.skinny_side)
+        self.nuc_side, self.bwd_overlap, self.skinny_side = (on, on, on) if isinstance(on, bool) else on
+        return prev
+
+    def _issue_pending_cluster(self):
+        """Launch the deferred nuclear-norm solve on the side stream, ordered after everything issued so far on the caller's."""
+        if self._nuc_pending is None:
+            return
+        args, self._nuc_pending = self._nuc_pending, None
+        if self._nuc_stream is None:
+            self._nuc_stream = torch.cuda.Stream(device=self.dev)
+        main = torch.cuda.current_stream(self.dev)
+        self._nuc_stream.wait_stream(main)
+        with torch.cuda.stream(self._nuc_stream):
+            self.cluster_terms(*args)
+            self._nuc_event = torch.cuda.Event()
+            self._nuc_event.record(self._nuc_stream)
+
+    def join_cluster(self):
+        """Before Minv / losses[KMEANS] are read on the caller's stream."""
+        if self._nuc_event is not None:
+            torch.cuda.current_stream(self.dev).wait_event(self._nuc_event)
+            self._nuc_event = None
+
     def forward(self, win, win_row, B, eps, training, cluster=None, enc_in=None, drop_mask=None, defer_heads=False):
         """Full RNN_VAE.forward (rnn_model.py:162-179).  Returns workspace views pred, fut, z, mu, logvar.
         cluster = (kl_weight, kloss, klmbda, bsize) also evaluates the nuclear-norm loss as soon as z exists.
@@ -619,9 +716,13 @@ class VAEEngine:
         hn = self.encode(xin, xin_row, B, training, drop_mask=drop_mask)
         z, mu, logvar = self.latent(hn, B, eps, training)
         if cluster is not None:
-            self.cluster_terms(B, *cluster)
+            if self.nuc_side and training and self.dev.type == "cuda":
+                self._nuc_pending = (B,) + tuple(cluster)             # issued by decode() right behind the decoders' GRU launch
+            else:
+                self.cluster_terms(B, *cluster)
         self._cluster_done = cluster is not None
         pred, fut = self.decode(z, B, training, heads=not (defer_heads and training and self._heads_fusable()))
+        self._issue_pending_cluster()                                 # (decode() did it unless it returned early)
         self._B = B
         self._win, self._win_row, self._eps = xin, xin_row, eps
         sh = lambda t, *shape: t[:_numel(shape)].view(*shape)
@@ -738,6 +839,10 @@ class VAEEngine:
             rows += rows_f
             groups.append(("decoder_future", per_f, Yf, dhid_f, FS))
         self._gru_bwd(rows, B)
+        ev_dec = None
+        if self.bwd_overlap and self.dev.type == "cuda" and s.future:
+            ev_dec = torch.cuda.Event()
+            ev_dec.record()
         He = H
         dz_jobs = []                                                # dz = sum of (B x K) @ (K x Z) products: issued together below
         for name, per, Y, dhid, steps in groups:
@@ -751,8 +856,12 @@ class VAEEngine:
                 self._gemm_wgrad(2 * H, Z, B, Operand(dhid, 2 * H), Operand(z, Z), wl)
                 ops.colsum(dhid, 0, B, 2 * H, 2 * H, self.g, t.off(f"{name}.latent_to_hidden.bias"))
                 dz_jobs.append((2 * H, Operand(dhid, 2 * H), self.P(wl, Z)))
+        if ev_dec is not None:
+            Hf_, Kf = s.Hf, B * FS
+            self._early_wgrads(ev_dec, lambda j: j[0] == 3 * Hf_ and j[1] == Hf_ and j[2] == Kf and j[5].startswith("decoder_future."))
         self._sum_into(dz, B, Z, dz_jobs)
         H = He
+        self.join_cluster()
         if use_minv and kl_weight != 0:
             ops.gemm(B, Z, Z, Operand(z, Z), 0, Operand(self.buf("Minv", Z, Z), Z), 1, dz, Z, accumulate=True)
         if dz_ext is not None:
@@ -781,6 +890,7 @@ class VAEEngine:
             st = self.buf(f"st_e1_{dirn}", ops.gru_stash_floats(B, T, H))
             rows.append(self._gru_bwd_stream(d, st, Y1, T, dirn, None, T, dhn, (2 + dirn) * H, 4 * H, dG, None, 0, dbias, T))
             per.append((d, dG, dbias))
+        self._join_early()                                           # the GRU launch wants every CU
         self._gru_bwd(rows, B)
         dY0 = self.buf("dY0", B, T, 2 * H)
         y0rows = Operand(Y0, 2 * H, off=2 * H, seg=T, seg_stride=(T + 2) * 2 * H)

@@ -364,6 +364,7 @@ class RNN_VAE(nn.Module):
                 eng.backward(B, kl_weight, beta)
                 if self._pad is not None:
                     self._pad.pull_grads(self._flat_g)
+            eng.join_cluster()
             out = losses[:4].clone()
             out[2] = out[2] * (-0.5 / (B * s.Z))
             if mse_red != "sum":
