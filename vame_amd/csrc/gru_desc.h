@@ -26,7 +26,7 @@ struct GruBwdStream {
     float* dbias;
     int64_t T, reverse, pad;
 };
-struct GruBwdParams { GruBwdStream s[8]; int nstreams; int B; int ntiles; int tile_off = 0; };
+struct GruBwdParams { GruBwdStream s[8]; int nstreams; int B; int ntiles; int tile_off = 0; int pace_cp = 0, pace_ld = 0; };   // pace_*: see gru_ws_bwd_kernel
 
 // In the 32x32 accumulator layout register r of lane l holds row CR(r) + 4*(l>>5), column l&31.
 #define CR(r) (((r) & 3) + 8 * ((r) >> 2))

@@ -610,10 +610,302 @@ __global__ __launch_bounds__(H / 32 * 64) void gru_seq_bwd_kernel(GruBwdParams P
     GRU_PROBE_END();
 }
 
+
+// ------------------------------------------------------------------------------------------- backward, wave-specialised (round 3)
+// Same tile (32 batch rows of one stream, all T steps), same stash / dG / dbias formats and the same arithmetic order as
+// gru_seq_bwd_kernel -- but the two waves of every SIMD no longer do the same thing in lock step:
+//   * waves 0 .. NW/2-1 ("MFMA waves", one per SIMD) own 64 hidden columns each and do nothing but the contraction
+//     dh_{t-1} = dh*u + [da_r | da_z | dgh_n] W_hh (K = 3H): their vector-memory queue holds ONLY the L2 weight ring, so no HBM
+//     round trip ever sits in front of a weight fragment (the coupling that capped the old kernel, profiles/r02_gru_ablation.txt);
+//   * waves NW/2 .. NW-1 ("memory waves", the other wave of each SIMD) own every HBM stream: during the MFMA loop of step s they
+//     copy dG of step s out and fetch the coefficient stash + dy of step s+1 into registers -- a whole contraction (~50 k cycles)
+//     of cover instead of one barrier's worth -- and between two loops they do the coefficient math for their 64 columns and write
+//     the A operand tile.
+// Hand-offs: dh (MFMA -> memory) and the update-gate carry dh*u (memory -> MFMA) go through `xd`, an LDS image in accumulator-
+// fragment order (each lane re-reads exactly the 16-byte slots its partner lane wrote); the A tile through `gs`.  Two barriers per
+// step, as before.  dgi_n no longer passes through LDS (the tile is 3H wide): the memory waves store it from registers.
+// LDS: 32 x (3H + 4) + 32 x H floats = 131,584 B at H = 256.
+// ABL (timing only, wrong results): 1 no dG copy-out, 2 no next-step loads, 4 no MFMA loop, 8 no dgi_n stores
+template <int H, int ABL = 0>
+__global__ __launch_bounds__(H / 32 * 64) void gru_ws_bwd_kernel(GruBwdParams P) {
+    constexpr int NW = H / 32, MW = NW / 2, K3 = 3 * H, LDG = K3 + 4, KC = K3 / 8;
+    static_assert(NW % 2 == 0 && 32 % MW == 0, "wave-specialised BPTT: H must be 64 * {1, 2, 4, 8}");
+    __shared__ float gs[32 * LDG];                          // per row [da_r | da_z | dgh_n]: the MFMA A operand
+    __shared__ float4 xd[NW * 4 * 64];                      // [col-block][q][lane]: dh (after barrier 2) / carry (after barrier 1)
+    int sidx, tile;
+    if (!map_block(P.nstreams, P.ntiles, sidx, tile)) return;
+    GRU_PROBE_BEGIN();
+    const GruBwdStream& S = P.s[sidx];
+    const int B = P.B, T = (int)S.T;
+    const int tid = threadIdx.x, lane = tid & 63, li = lane & 31, hh = lane >> 5;
+    const int w = UNIFORM(tid >> 6);
+    const int row0 = tile * 32, lrow = 4 * hh;
+    const int nvalid = B - row0;
+    const bool full = nvalid >= 32;
+    const bool skip_last = S.dh0 == nullptr;               // dh before the first step is not asked for: the last contraction is skipped
+
+    if (w < MW) {
+        // ================================================================ MFMA waves: columns [64 w, 64 w + 64)
+        const int cbA = 2 * w, cbB = 2 * w + 1;
+        const float4* __restrict__ wpA = reinterpret_cast<const float4*>(S.wpt) + (int64_t)cbA * KC * 64 + lane;
+        const float4* __restrict__ wpB = wpA + (int64_t)KC * 64;
+        const float* grow_a = &gs[li * LDG + 4 * hh];
+        constexpr int PD = 3;                               // ring depth in chunk pairs ((KC / 2) % PD == 0 for every H % 64 == 0)
+        f32x4 wq[PD][4];
+#pragma unroll
+        for (int c = 0; c < PD; ++c) {
+            RING_LOAD(wq[c][0], wpA, (2 * c) * 64); RING_LOAD(wq[c][1], wpA, (2 * c + 1) * 64);
+            RING_LOAD(wq[c][2], wpB, (2 * c) * 64); RING_LOAD(wq[c][3], wpB, (2 * c + 1) * 64);
+        }
+        f32x16 a0, b0;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { a0[r] = 0.f; b0[r] = 0.f; }
+        // dy of the NEXT step rides in this role's spare registers (the memory waves' 160 stash registers leave no room for it): it
+        // is requested behind the last ring wait of a contraction -- nothing in the weight ring ever waits behind it -- and added to
+        // dh when dh goes to xd one step later, so what the memory waves read is d = dh + dy, summed in the lock-step kernel's order
+        const BufRange r_dy = buf_range(S.dy ? S.dy + (int64_t)row0 * S.dy_row : nullptr, (uint64_t)(full ? 32 : nvalid) * (uint64_t)S.dy_row * 4);
+        const uint32_t v_dy = ((uint32_t)lrow * (uint32_t)S.dy_row + (uint32_t)li) * 4u;
+        const uint32_t dy_row_b = UNIFORM((uint32_t)S.dy_row * 4u), dy_t_b = UNIFORM((uint32_t)S.dy_t * 4u);
+        f32x16 dyA, dyB;
+        auto load_dy = [&](int step) {
+            const int fstep = T - 1 - step;
+            const uint32_t t = (uint32_t)(S.reverse ? T - 1 - fstep : fstep);
+            const uint32_t s_dy = UNIFORM(t * dy_t_b + (uint32_t)cbA * 128u);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                dyA[r] = buf_load_f32(r_dy, v_dy, s_dy + (uint32_t)CR(r) * dy_row_b);
+                dyB[r] = buf_load_f32(r_dy, v_dy, s_dy + 128u + (uint32_t)CR(r) * dy_row_b);
+            }
+        };
+        load_dy(T > 1 ? 1 : 0);
+        __syncthreads();                                    // prologue: xd holds dh_T + dy_{T-1} (the memory waves' loads)
+        GRU_PHASE_DECL();
+        for (int step = 0; step < T; ++step) {
+            __syncthreads();                                // barrier 1: A tile and carry of this step are in LDS
+            GRU_PHASE(2);                 // (probe build) MFMA waves: wait for the memory waves' coefficient phase
+            if (step + 1 == T && skip_last) break;
+            f32x16 a1, b1;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 va = xd[(cbA * 4 + q) * 64 + lane], vb = xd[(cbB * 4 + q) * 64 + lane];
+                a0[4 * q] = va.x; a0[4 * q + 1] = va.y; a0[4 * q + 2] = va.z; a0[4 * q + 3] = va.w;
+                b0[4 * q] = vb.x; b0[4 * q + 1] = vb.y; b0[4 * q + 2] = vb.z; b0[4 * q + 3] = vb.w;
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { a1[r] = 0.f; b1[r] = 0.f; }
+            float4 fa0 = *reinterpret_cast<const float4*>(grow_a), fa1 = *reinterpret_cast<const float4*>(grow_a + 8);
+            GRU_PHASE(1);                 // carry read, accumulator init
+#pragma unroll 1
+            for (int c0 = 0; c0 < ((ABL & 4) ? PD : KC / 2); c0 += PD)
+#pragma unroll
+            for (int j = 0; j < PD; ++j) {
+                const int c = 2 * (c0 + j);
+                const int cnx = (c + 2 < KC) ? c + 2 : 0;   // A fragments of the next chunk pair, requested before this pair's MFMAs
+                const float4 na0 = *reinterpret_cast<const float4*>(grow_a + 8 * cnx);
+                const float4 na1 = *reinterpret_cast<const float4*>(grow_a + 8 * cnx + 8);
+                RING_WAIT4(4 * (PD - 1), wq[j][0], wq[j][1], wq[j][2], wq[j][3]);
+                const f32x4 wa0 = wq[j][0], wa1 = wq[j][1], wb0 = wq[j][2], wb1 = wq[j][3];
+                a0 = MFMA_32x32x2(fa0.x, wa0[0], a0); a1 = MFMA_32x32x2(fa1.x, wa1[0], a1);
+                b0 = MFMA_32x32x2(fa0.x, wb0[0], b0); b1 = MFMA_32x32x2(fa1.x, wb1[0], b1);
+                a0 = MFMA_32x32x2(fa0.y, wa0[1], a0); a1 = MFMA_32x32x2(fa1.y, wa1[1], a1);
+                b0 = MFMA_32x32x2(fa0.y, wb0[1], b0); b1 = MFMA_32x32x2(fa1.y, wb1[1], b1);
+                a0 = MFMA_32x32x2(fa0.z, wa0[2], a0); a1 = MFMA_32x32x2(fa1.z, wa1[2], a1);
+                b0 = MFMA_32x32x2(fa0.z, wb0[2], b0); b1 = MFMA_32x32x2(fa1.z, wb1[2], b1);
+                a0 = MFMA_32x32x2(fa0.w, wa0[3], a0); a1 = MFMA_32x32x2(fa1.w, wa1[3], a1);
+                b0 = MFMA_32x32x2(fa0.w, wb0[3], b0); b1 = MFMA_32x32x2(fa1.w, wb1[3], b1);
+                RING_FENCE();
+                {   // refill behind the slot's last use; wraps into the next step's first chunks
+                    const int cn = (c0 + j + PD == KC / 2 + j) ? 2 * j : c + 2 * PD;
+                    RING_LOAD(wq[j][0], wpA, cn * 64); RING_LOAD(wq[j][1], wpA, (cn + 1) * 64);
+                    RING_LOAD(wq[j][2], wpB, cn * 64); RING_LOAD(wq[j][3], wpB, (cn + 1) * 64);
+                }
+                fa0 = na0; fa1 = na1;
+            }
+            GRU_PHASE(5);                 // contraction
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { a0[r] = a0[r] + a1[r]; b0[r] = b0[r] + b1[r]; }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {       // xd <- d of the next step = dh + dy (the last step's dh leaves without: it is dh0)
+                const bool more = step + 1 < T;
+                xd[(cbA * 4 + q) * 64 + lane] = make_float4(a0[4 * q] + (more ? dyA[4 * q] : 0.f), a0[4 * q + 1] + (more ? dyA[4 * q + 1] : 0.f),
+                                                            a0[4 * q + 2] + (more ? dyA[4 * q + 2] : 0.f), a0[4 * q + 3] + (more ? dyA[4 * q + 3] : 0.f));
+                xd[(cbB * 4 + q) * 64 + lane] = make_float4(b0[4 * q] + (more ? dyB[4 * q] : 0.f), b0[4 * q + 1] + (more ? dyB[4 * q + 1] : 0.f),
+                                                            b0[4 * q + 2] + (more ? dyB[4 * q + 2] : 0.f), b0[4 * q + 3] + (more ? dyB[4 * q + 3] : 0.f));
+            }
+            SCHED_FENCE();
+            load_dy(step + 2 < T ? step + 2 : step);        // (unconditional, see the memory waves' load_step)
+            GRU_PHASE(4);                 // d -> xd, dy request
+            __syncthreads();                                // barrier 2: d of the next step is in xd, the A tile may be overwritten
+            GRU_PHASE(6);
+        }
+        GRU_PHASE_END();
+        if (S.dh0) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int grow = row0 + CR(r) + lrow;
+                if (grow < B) {
+                    S.dh0[(int64_t)grow * S.dh0_row + 32 * cbA + li] = a0[r];
+                    S.dh0[(int64_t)grow * S.dh0_row + 32 * cbB + li] = b0[r];
+                }
+            }
+        }
+    } else {
+        // ================================================================ memory waves: all HBM streams + coefficient math
+        // Every stream is addressed as a tile-relative BUFFER RANGE (uniform base + scalar offset + one 32-bit lane offset): the flat
+        // form costs a 64-bit address pair per row and access, which hipcc keeps live across the step loop (1800 spilled registers
+        // in the first version of this kernel).  Rows past the batch fall outside the ranges: their loads return 0, their stores are
+        // dropped; an absent dy is a 0-byte range.
+        const int k = w - MW;
+        const int rows_here = full ? 32 : nvalid;
+        const BufRange r_st = buf_range(S.stash + (int64_t)tile * T * NW * 20 * 64 * 4, (uint64_t)T * NW * 20 * 64 * 16);
+        const BufRange r_dg = buf_range(S.dg + (int64_t)row0 * T * 4 * H, (uint64_t)rows_here * T * 4 * H * 4);
+        const uint32_t v_st = (uint32_t)lane * 16u;                                              // stash: float4 per lane
+        const uint32_t v_dn = ((uint32_t)lrow * (uint32_t)T * 4u * H + (uint32_t)li) * 4u;
+        const uint32_t dg_row_b = UNIFORM((uint32_t)T * 4u * H * 4u);
+        float4 st[2][20];                                    // [col-block][coefficient * 4 + q]: cA, cB, u, r, gh_n
+        // PACING: the memory waves have a whole contraction (~50 k cycles) for 40 loads and 24 + stores per lane.  Issued as one burst
+        // they fill the CU's vector-memory FIFO and the LDS queues, and the MFMA waves' weight-ring loads and A-fragment reads wait
+        // behind them (measured: contraction 60.7 k cycles per step instead of 49.2 k, profiles/r03_ws_probe.txt); so they go out in
+        // small groups with s_sleep in between (pace_* x 256 cycles after each group; 0 in the first call, where nothing overlaps).
+        const int pace_cp = P.pace_cp;
+        auto load_step = [&](int step, int pace) {
+            const int fstep = T - 1 - step;
+            const uint32_t t = (uint32_t)(S.reverse ? T - 1 - fstep : fstep);
+#pragma unroll
+            for (int c2 = 0; c2 < 2; ++c2) {
+                const uint32_t cb = 2 * k + c2;
+                const uint32_t s_st = UNIFORM((t * NW + cb) * 20u * 1024u);
+#pragma unroll
+                for (int i = 0; i < 20; ++i) {
+                    st[c2][i] = buf_load_f32x4(r_st, v_st, s_st + i * 1024u);
+                    if (i % 4 == 3) { SCHED_FENCE(); for (int z = 0; z < pace; ++z) VAME_SLEEP4(); }
+                }
+            }
+        };
+        // d of the first step = dh_T + dy -> xd
+        {
+            const int t0 = S.reverse ? 0 : T - 1;
+#pragma unroll
+            for (int c2 = 0; c2 < 2; ++c2) {
+                const int cb = 2 * k + c2;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    float v[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int row = CR(4 * q + j) + lrow, grow = row0 + row;
+                        const float dhv = (S.dhn && grow < B) ? S.dhn[(int64_t)grow * S.dhn_row + 32 * cb + li] : 0.0f;
+                        const float dy0 = (S.dy && grow < B) ? S.dy[(int64_t)grow * S.dy_row + (int64_t)t0 * S.dy_t + 32 * cb + li] : 0.0f;
+                        v[j] = dhv + dy0;
+                    }
+                    xd[(cb * 4 + q) * 64 + lane] = make_float4(v[0], v[1], v[2], v[3]);
+                }
+            }
+        }
+        load_step(0, 0);
+        float dbs[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+        // LDS -> global copy of the three tile blocks: this wave's rows are k, k + MW, ...; a lane moves float4 number i = lane + 64 it
+        // of a row (3H / 4 per row), which lands in global block (0, 1, 3)[i / (H/4)]
+        uint32_t v_cp[(K3 / 4 + 63) / 64];
+#pragma unroll
+        for (int it = 0; it < (K3 / 4 + 63) / 64; ++it) {
+            const int col = 4 * (lane + 64 * it), blk = col / H;
+            v_cp[it] = col < K3 ? (uint32_t)((blk == 2 ? 3 * H : blk * H) + col % H) * 4u : 0xffffffffu;      // (poisoned: dropped)
+        }
+        __syncthreads();                                    // prologue
+        GRU_PHASE_DECL();
+        for (int step = 0; step < T; ++step) {
+            const int fstep = T - 1 - step;
+            const uint32_t t = (uint32_t)(S.reverse ? T - 1 - fstep : fstep);
+            const uint32_t s_t = UNIFORM(t * 4u * H * 4u);
+            // ---- coefficient math of this wave's 64 columns: A tile -> gs, carry -> xd, dgi_n straight to dG (the A tile has no
+            // room for it and 32 more live registers do not fit next to the 192 of the prefetched operands)
+            float4 dnext = xd[((2 * k) * 4 + 0) * 64 + lane];       // d of the first row group; each group requests the next one's
+#pragma unroll
+            for (int c2 = 0; c2 < 2; ++c2) {
+                const int cb = 2 * k + c2;
+                const uint32_t s_dn = UNIFORM(s_t + (2u * H + 32u * (2 * k + c2)) * 4u);
+                float* gw_lo = &gs[lrow * LDG + 32 * cb + li];
+                float* gw_hi = gw_lo + 16 * LDG;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float4 dhq = dnext;
+                    if (c2 * 4 + q < 7) dnext = xd[((2 * k + (c2 * 4 + q + 1) / 4) * 4 + (q + 1) % 4) * 64 + lane];
+                    const float dhv[4] = {dhq.x, dhq.y, dhq.z, dhq.w};
+                    const float4 sa = st[c2][0 * 4 + q], sb = st[c2][1 * 4 + q], su = st[c2][2 * 4 + q], sr = st[c2][3 * 4 + q], sg = st[c2][4 * 4 + q];
+                    const float av[4] = {sa.x, sa.y, sa.z, sa.w}, bv[4] = {sb.x, sb.y, sb.z, sb.w}, uv[4] = {su.x, su.y, su.z, su.w},
+                                rv[4] = {sr.x, sr.y, sr.z, sr.w}, gv[4] = {sg.x, sg.y, sg.z, sg.w};
+                    float cy[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int r = 4 * q + j;
+                        const float d = dhv[j];                    // = dh + dy (see the MFMA waves)
+                        const float dan = d * av[j];
+                        const float dau = d * bv[j];
+                        const float dgh = dan * rv[j];
+                        const float dar = dgh * gv[j] * (1.0f - rv[j]);
+                        cy[j] = d * uv[j];                         // dh carried through the update gate
+                        float* gw = (r < 8 ? gw_lo : gw_hi) + (CR(r) & 15) * LDG;
+                        gw[0] = dar; gw[H] = dau; gw[2 * H] = dgh;
+                        if (!(ABL & 8)) buf_store_f32(r_dg, v_dn, s_dn + (uint32_t)CR(r) * dg_row_b, dan);
+                        dbs[c2][0] += dar; dbs[c2][1] += dau; dbs[c2][2] += dan; dbs[c2][3] += dgh;
+                    }
+                    xd[(cb * 4 + q) * 64 + lane] = make_float4(cy[0], cy[1], cy[2], cy[3]);
+                    SCHED_FENCE();                          // one row group at a time: its five stash registers die here
+                }
+            }
+            GRU_PHASE(1);                 // (probe build) memory waves: coefficient phase
+            __syncthreads();                                // barrier 1
+            GRU_PHASE(2);
+            // ---- beside the MFMA loop: the three tile blocks of dG out of LDS ...
+            if (!(ABL & 1)) {
+#pragma unroll 2
+                for (int g = 0; g < 32 / MW; ++g) {
+                    const int row = MW * g + k;
+                    const uint32_t s_row = UNIFORM(s_t + (uint32_t)row * dg_row_b);
+#pragma unroll
+                    for (int it = 0; it < (K3 / 4 + 63) / 64; ++it)
+                        buf_store_f32x4(r_dg, v_cp[it], s_row, *reinterpret_cast<const float4*>(&gs[row * LDG + (4 * (lane + 64 * it)) % K3]));
+                    SCHED_FENCE();
+                    for (int z = 0; z < pace_cp; ++z) VAME_SLEEP4();      // pacing: see below
+                }
+            }
+            GRU_PHASE(3);                 // dG copy-out
+            if (step + 1 == T && skip_last) break;
+            // ---- ... and the stash / dy of the next step in: a whole contraction of cover
+            SCHED_FENCE();
+            // (unconditional: a conditional load makes every stash register a loop-carried phi of old and new value -- both sets live
+            // during the loads, 384 registers; the last step re-reads its own operands instead)
+            if (!(ABL & 2)) load_step(step + 1 < T ? step + 1 : step, P.pace_ld);
+            GRU_PHASE(4);                 // next step's stash request (issue)
+            __syncthreads();                                // barrier 2
+            GRU_PHASE(6);
+        }
+        GRU_PHASE_END();
+        if (S.dbias) {
+#pragma unroll
+            for (int c2 = 0; c2 < 2; ++c2) {
+                float d0 = dbs[c2][0], d1 = dbs[c2][1], d2 = dbs[c2][2], d3 = dbs[c2][3];
+                d0 += __shfl_xor(d0, 32); d1 += __shfl_xor(d1, 32); d2 += __shfl_xor(d2, 32); d3 += __shfl_xor(d3, 32);
+                if (hh == 0) {
+                    float* o = S.dbias + (int64_t)tile * 4 * H + 32 * (2 * k + c2) + li;
+                    o[0] = d0; o[H] = d1; o[2 * H] = d2; o[3 * H] = d3;
+                }
+            }
+        }
+    }
+    GRU_PROBE_END();
+}
+
 // ------------------------------------------------------------------------------------------- host
 #include <stdlib.h>
 [[maybe_unused]] static int abl_env(const char* name) { const char* e = getenv(name); return e ? atoi(e) : 0; }
 #define ABL_CASE(K, H, A, P, st) case A: hipLaunchKernelGGL((K<H, A>), dim3(grid_blocks(P.nstreams, P.ntiles)), dim3(H / 32 * 64), 0, st, P); return;
+
+static bool gru_ws_enabled() {
+    const char* e = getenv("VAME_GRU_WS");
+    return e ? atoi(e) != 0 : true;
+}
 
 template <int H>
 static void launch_fwd(const GruFwdParams& P, hipStream_t st) {
@@ -638,6 +930,26 @@ static void launch_bwd(const GruBwdParams& P, hipStream_t st) {
         default: break;
     }
 #endif
+    if constexpr (H == 256 || H == 128) {
+        // wave-specialised BPTT (gru_ws_bwd_kernel) for the hidden sizes it is instantiated for; VAME_GRU_WS=0 keeps the lock-step kernel
+        if (gru_ws_enabled()) {
+            GruBwdParams Q = P;
+            // pacing of the memory waves (units of 256 cycles per request group), sized so that their 8 + 10 groups span about two
+            // thirds of one contraction (2 x 48 x 16 MFMAs at H = 256, a quarter of that at H = 128): measured optimum 2 / 12 at H = 256
+            { const char* e = getenv("VAME_WS_PACE_CP"); Q.pace_cp = e ? atoi(e) : 2 * H * H / 65536; }
+            { const char* e = getenv("VAME_WS_PACE_LD"); Q.pace_ld = e ? atoi(e) : 12 * H * H / 65536; }
+            const GruBwdParams& P = Q;
+#if !defined(VAME_EMU) && defined(VAME_GEMM_AB)
+            if (H == 256) switch (abl_env("VAME_WS_ABL")) {
+                ABL_CASE(gru_ws_bwd_kernel, 256, 1, P, st) ABL_CASE(gru_ws_bwd_kernel, 256, 2, P, st) ABL_CASE(gru_ws_bwd_kernel, 256, 3, P, st)
+                ABL_CASE(gru_ws_bwd_kernel, 256, 4, P, st) ABL_CASE(gru_ws_bwd_kernel, 256, 8, P, st) ABL_CASE(gru_ws_bwd_kernel, 256, 11, P, st) ABL_CASE(gru_ws_bwd_kernel, 256, 7, P, st)
+                default: break;
+            }
+#endif
+            hipLaunchKernelGGL((gru_ws_bwd_kernel<H, 0>), dim3(grid_blocks(P.nstreams, P.ntiles)), dim3(H / 32 * 64), 0, st, P);
+            return;
+        }
+    }
     hipLaunchKernelGGL((gru_seq_bwd_kernel<H, 0>), dim3(grid_blocks(P.nstreams, P.ntiles)), dim3(H / 32 * 64), 0, st, P);
 }
 

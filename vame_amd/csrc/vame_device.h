@@ -10,12 +10,14 @@ typedef f32x4_emu f32x4;
 #define MFMA_16x16x4(a, b, c) emu_mfma_16x16x4((a), (b), (c))
 #define VAME_DYN_SMEM(name) char* name = emu::dyn_smem()
 #define SETPRIO(n)
+#define VAME_SLEEP4()
 #define WAVE_SYNC() emu::wave_sync()      /* lanes are fibers on the host: a wave-private LDS exchange needs an explicit rendezvous */
 #define SCHED_FENCE()
 #define RING_FENCE()
 #define RING_LOAD(dst, ptr, idx) (dst) = *reinterpret_cast<const f32x4*>((ptr) + (idx))
 #define RING_WAIT2(n, a, b)
 #define RING_WAIT3(n, a, b, c)
+#define RING_WAIT4(n, a, b, c, d)
 #define VAME_EXPF(x) expf(x)
 #define VAME_RCP(x) (1.0f / (x))
 #else
@@ -27,6 +29,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define MFMA_16x16x4(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
 #define VAME_DYN_SMEM(name) extern __shared__ __attribute__((aligned(16))) char name[]
 #define SETPRIO(n) __builtin_amdgcn_s_setprio(n)
+#define VAME_SLEEP4() __builtin_amdgcn_s_sleep(4)      /* ~256 cycles off the issue ports */
 #define WAVE_SYNC() __builtin_amdgcn_wave_barrier()   /* lanes of a wave run in lock step and its LDS accesses complete in order: ordering hint only */
 #define SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)   /* keep the scheduler from merging phases (register pressure) */
 #define RING_FENCE() __builtin_amdgcn_sched_barrier(0)    /* prefetch-ring refills stay behind the MFMAs that read the slot */
@@ -39,6 +42,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define RING_LOAD(dst, ptr, idx) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"((ptr) + (idx)))
 #define RING_WAIT2(n, a, b) asm volatile("s_waitcnt vmcnt(%2)" : "+v"(a), "+v"(b) : "n"(n))
 #define RING_WAIT3(n, a, b, c) asm volatile("s_waitcnt vmcnt(%3)" : "+v"(a), "+v"(b), "+v"(c) : "n"(n))
+#define RING_WAIT4(n, a, b, c, d) asm volatile("s_waitcnt vmcnt(%4)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "n"(n))
 #define VAME_EXPF(x) __expf(x)
 #define VAME_RCP(x) __builtin_amdgcn_rcpf(x)   /* v_rcp_f32, 1 ulp */
 #endif
@@ -68,6 +72,10 @@ static inline void buf_store_f32(BufRange r, uint32_t voff, uint32_t soff, float
     const uint64_t o = (uint64_t)voff + soff;
     if (o + 4 <= r.bytes) *reinterpret_cast<float*>(const_cast<char*>(r.base) + o) = v;
 }
+static inline void buf_store_f32x4(BufRange r, uint32_t voff, uint32_t soff, float4 v) {
+    const uint64_t o = (uint64_t)voff + soff;
+    if (o + 16 <= r.bytes) *reinterpret_cast<float4*>(const_cast<char*>(r.base) + o) = v;
+}
 #else
 typedef __amdgpu_buffer_rsrc_t BufRange;
 __device__ __forceinline__ BufRange buf_range(const void* base, uint64_t bytes) {
@@ -82,6 +90,10 @@ __device__ __forceinline__ float4 buf_load_f32x4(BufRange r, uint32_t voff, uint
 }
 __device__ __forceinline__ void buf_store_f32(BufRange r, uint32_t voff, uint32_t soff, float v) {
     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, (int)voff, (int)soff, 0);
+}
+typedef unsigned vame_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void buf_store_f32x4(BufRange r, uint32_t voff, uint32_t soff, float4 v) {
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(vame_u32x4, v), r, (int)voff, (int)soff, 0);
 }
 #endif
 
