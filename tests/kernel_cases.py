@@ -332,6 +332,31 @@ def check_gru_coop_bwd(dev, H, B, T, launches=2):
     assert int(state.status.item()) == 0
 
 
+def check_gru_ws_bwd(dev, H, B, T):
+    """The wave-specialised BPTT kernel (gru_seq.hip: gru_ws_bwd_kernel; MFMA waves / memory waves) against the numpy oracle AND
+    bit for bit against the lock-step kernel it replaces at H = 256 (same stash, same arithmetic order): dG, dh0, bias partials.
+    VAME_GRU_WS picks the kernel per launch (2 = wave-specialised wherever it is instantiated, 0 = lock-step)."""
+    import os
+    prev = os.environ.get("VAME_GRU_WS")
+    try:
+        os.environ["VAME_GRU_WS"] = "2"
+        check_gru_bwd(dev, H, B, T)
+        x, st, Y, hN = run_gru_fwd(dev, H, B, T, seed=1)
+        rng = np.random.default_rng(5)
+        dYt = T_(rng.standard_normal((B, T, 2 * H)).astype(np.float32), dev)
+        dhNt = T_(rng.standard_normal((B, 2 * H)).astype(np.float32), dev)
+        ws = _run_gru_bwd(dev, H, B, T, st, Y, dYt, dhNt)
+        os.environ["VAME_GRU_WS"] = "0"
+        ls = _run_gru_bwd(dev, H, B, T, st, Y, dYt, dhNt)
+        for (dG, dh0, dbias, _), (dG2, dh02, dbias2, _) in zip(ws, ls):
+            assert torch.equal(dG, dG2) and torch.equal(dh0, dh02) and torch.equal(dbias, dbias2)
+    finally:
+        if prev is None:
+            os.environ.pop("VAME_GRU_WS", None)
+        else:
+            os.environ["VAME_GRU_WS"] = prev
+
+
 def check_gru_bwd(dev, H, B, T):
     x, st, Y, hN = run_gru_fwd(dev, H, B, T, seed=1)
     rng = np.random.default_rng(5)

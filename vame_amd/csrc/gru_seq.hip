@@ -902,9 +902,13 @@ __global__ __launch_bounds__(H / 32 * 64) void gru_ws_bwd_kernel(GruBwdParams P)
 [[maybe_unused]] static int abl_env(const char* name) { const char* e = getenv(name); return e ? atoi(e) : 0; }
 #define ABL_CASE(K, H, A, P, st) case A: hipLaunchKernelGGL((K<H, A>), dim3(grid_blocks(P.nstreams, P.ntiles)), dim3(H / 32 * 64), 0, st, P); return;
 
-static bool gru_ws_enabled() {
+// VAME_GRU_WS: 0 = lock-step BPTT kernel everywhere; unset / 1 = wave-specialised kernel at H = 256 (measured: 102 -> 114 TF at batch
+// 4096, faster down to batch 100); 2 = also at H = 128, where a step's contraction is four times shorter and the serial coefficient
+// phase weighs more (measured slower at small batches; kept for the tests)
+static bool gru_ws_enabled(int H) {
     const char* e = getenv("VAME_GRU_WS");
-    return e ? atoi(e) != 0 : true;
+    const int v = e ? atoi(e) : 1;
+    return v >= 2 ? true : (v == 1 && H == 256);
 }
 
 template <int H>
@@ -932,7 +936,7 @@ static void launch_bwd(const GruBwdParams& P, hipStream_t st) {
 #endif
     if constexpr (H == 256 || H == 128) {
         // wave-specialised BPTT (gru_ws_bwd_kernel) for the hidden sizes it is instantiated for; VAME_GRU_WS=0 keeps the lock-step kernel
-        if (gru_ws_enabled()) {
+        if (gru_ws_enabled(H)) {
             GruBwdParams Q = P;
             // pacing of the memory waves (units of 256 cycles per request group), sized so that their 8 + 10 groups span about two
             // thirds of one contraction (2 x 48 x 16 MFMAs at H = 256, a quarter of that at H = 128): measured optimum 2 / 12 at H = 256
