@@ -334,7 +334,7 @@ def check_gru_coop_bwd(dev, H, B, T, launches=2):
 
 def check_gru_ws_bwd(dev, H, B, T):
     """The wave-specialised BPTT kernel (gru_seq.hip: gru_ws_bwd_kernel; MFMA waves / memory waves) against the numpy oracle AND
-    bit for bit against the lock-step kernel it replaces at H = 256 (same stash, same arithmetic order): dG, dh0, bias partials.
+    bit for bit against the lock-step kernel it replaces at H = 256 (same stash, same arithmetic order): dG, dh0; bias partials to rounding.
     VAME_GRU_WS picks the kernel per launch (2 = wave-specialised wherever it is instantiated, 0 = lock-step)."""
     import os
     prev = os.environ.get("VAME_GRU_WS")
@@ -349,7 +349,9 @@ def check_gru_ws_bwd(dev, H, B, T):
         os.environ["VAME_GRU_WS"] = "0"
         ls = _run_gru_bwd(dev, H, B, T, st, Y, dYt, dhNt)
         for (dG, dh0, dbias, _), (dG2, dh02, dbias2, _) in zip(ws, ls):
-            assert torch.equal(dG, dG2) and torch.equal(dh0, dh02) and torch.equal(dbias, dbias2)
+            assert torch.equal(dG, dG2) and torch.equal(dh0, dh02)
+            # bias partials: the same 16 x T terms per lane, summed pairwise (packed fp32 adds) instead of one by one
+            np.testing.assert_allclose(N_(dbias), N_(dbias2), rtol=2e-5, atol=2e-5 * float(np.abs(N_(dbias2)).max()))
     finally:
         if prev is None:
             os.environ.pop("VAME_GRU_WS", None)

@@ -623,7 +623,12 @@ __global__ __launch_bounds__(H / 32 * 64) void gru_seq_bwd_kernel(GruBwdParams P
 //     the A operand tile.
 // Hand-offs: dh (MFMA -> memory) and the update-gate carry dh*u (memory -> MFMA) go through `xd`, an LDS image in accumulator-
 // fragment order (each lane re-reads exactly the 16-byte slots its partner lane wrote); the A tile through `gs`.  Two barriers per
-// step, as before.  dgi_n no longer passes through LDS (the tile is 3H wide): the memory waves store it from registers.
+// step, as before.  dgi_n no longer passes through LDS (the tile is 3H wide): the memory waves keep it in registers across barrier 1
+// and store it beside the contraction.  The coefficient phase is written on packed fp32 pairs (v_pk_mul_f32 / v_pk_add_f32): it
+// runs on ONE wave per SIMD while the MFMA waves wait, so its instruction count is step time.  The memory waves' requests are paced
+// (s_sleep between small groups): issued as a burst they fill the CU's vector-memory FIFO and the contraction stalls behind them.
+// Cycles per step at H = 256 (profiles/r03_ws_probe.txt): coefficient phase 3.4 k, contraction 54.5 k (floor 49.2 k), hand-offs 1 k
+// = 58.9 k, against 72 k for the lock-step kernel.
 // LDS: 32 x (3H + 4) + 32 x H floats = 131,584 B at H = 256.
 // ABL (timing only, wrong results): 1 no dG copy-out, 2 no next-step loads, 4 no MFMA loop, 8 no dgi_n stores
 template <int H, int ABL = 0>
@@ -660,25 +665,7 @@ __global__ __launch_bounds__(H / 32 * 64) void gru_ws_bwd_kernel(GruBwdParams P)
         f32x16 a0, b0;
 #pragma unroll
         for (int r = 0; r < 16; ++r) { a0[r] = 0.f; b0[r] = 0.f; }
-        // dy of the NEXT step rides in this role's spare registers (the memory waves' 160 stash registers leave no room for it): it
-        // is requested behind the last ring wait of a contraction -- nothing in the weight ring ever waits behind it -- and added to
-        // dh when dh goes to xd one step later, so what the memory waves read is d = dh + dy, summed in the lock-step kernel's order
-        const BufRange r_dy = buf_range(S.dy ? S.dy + (int64_t)row0 * S.dy_row : nullptr, (uint64_t)(full ? 32 : nvalid) * (uint64_t)S.dy_row * 4);
-        const uint32_t v_dy = ((uint32_t)lrow * (uint32_t)S.dy_row + (uint32_t)li) * 4u;
-        const uint32_t dy_row_b = UNIFORM((uint32_t)S.dy_row * 4u), dy_t_b = UNIFORM((uint32_t)S.dy_t * 4u);
-        f32x16 dyA, dyB;
-        auto load_dy = [&](int step) {
-            const int fstep = T - 1 - step;
-            const uint32_t t = (uint32_t)(S.reverse ? T - 1 - fstep : fstep);
-            const uint32_t s_dy = UNIFORM(t * dy_t_b + (uint32_t)cbA * 128u);
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                dyA[r] = buf_load_f32(r_dy, v_dy, s_dy + (uint32_t)CR(r) * dy_row_b);
-                dyB[r] = buf_load_f32(r_dy, v_dy, s_dy + 128u + (uint32_t)CR(r) * dy_row_b);
-            }
-        };
-        load_dy(T > 1 ? 1 : 0);
-        __syncthreads();                                    // prologue: xd holds dh_T + dy_{T-1} (the memory waves' loads)
+        __syncthreads();                                    // prologue: xd holds dh_T (the memory waves' load of dhn)
         GRU_PHASE_DECL();
         for (int step = 0; step < T; ++step) {
             __syncthreads();                                // barrier 1: A tile and carry of this step are in LDS
@@ -725,17 +712,12 @@ __global__ __launch_bounds__(H / 32 * 64) void gru_ws_bwd_kernel(GruBwdParams P)
 #pragma unroll
             for (int r = 0; r < 16; ++r) { a0[r] = a0[r] + a1[r]; b0[r] = b0[r] + b1[r]; }
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {       // xd <- d of the next step = dh + dy (the last step's dh leaves without: it is dh0)
-                const bool more = step + 1 < T;
-                xd[(cbA * 4 + q) * 64 + lane] = make_float4(a0[4 * q] + (more ? dyA[4 * q] : 0.f), a0[4 * q + 1] + (more ? dyA[4 * q + 1] : 0.f),
-                                                            a0[4 * q + 2] + (more ? dyA[4 * q + 2] : 0.f), a0[4 * q + 3] + (more ? dyA[4 * q + 3] : 0.f));
-                xd[(cbB * 4 + q) * 64 + lane] = make_float4(b0[4 * q] + (more ? dyB[4 * q] : 0.f), b0[4 * q + 1] + (more ? dyB[4 * q + 1] : 0.f),
-                                                            b0[4 * q + 2] + (more ? dyB[4 * q + 2] : 0.f), b0[4 * q + 3] + (more ? dyB[4 * q + 3] : 0.f));
+            for (int q = 0; q < 4; ++q) {
+                xd[(cbA * 4 + q) * 64 + lane] = make_float4(a0[4 * q], a0[4 * q + 1], a0[4 * q + 2], a0[4 * q + 3]);
+                xd[(cbB * 4 + q) * 64 + lane] = make_float4(b0[4 * q], b0[4 * q + 1], b0[4 * q + 2], b0[4 * q + 3]);
             }
-            SCHED_FENCE();
-            load_dy(step + 2 < T ? step + 2 : step);        // (unconditional, see the memory waves' load_step)
-            GRU_PHASE(4);                 // d -> xd, dy request
-            __syncthreads();                                // barrier 2: d of the next step is in xd, the A tile may be overwritten
+            GRU_PHASE(4);                 // dh -> xd
+            __syncthreads();                                // barrier 2: dh_{t-1} is in xd, the A tile may be overwritten
             GRU_PHASE(6);
         }
         GRU_PHASE_END();
@@ -758,11 +740,15 @@ __global__ __launch_bounds__(H / 32 * 64) void gru_ws_bwd_kernel(GruBwdParams P)
         const int k = w - MW;
         const int rows_here = full ? 32 : nvalid;
         const BufRange r_st = buf_range(S.stash + (int64_t)tile * T * NW * 20 * 64 * 4, (uint64_t)T * NW * 20 * 64 * 16);
+        const BufRange r_dy = buf_range(S.dy ? S.dy + (int64_t)row0 * S.dy_row : nullptr, (uint64_t)rows_here * (uint64_t)S.dy_row * 4);
         const BufRange r_dg = buf_range(S.dg + (int64_t)row0 * T * 4 * H, (uint64_t)rows_here * T * 4 * H * 4);
+        const uint32_t v_dy = ((uint32_t)lrow * (uint32_t)S.dy_row + (uint32_t)li) * 4u;         // dy / dgi_n: accumulator layout
+        const uint32_t dy_row_b = UNIFORM((uint32_t)S.dy_row * 4u), dy_t_b = UNIFORM((uint32_t)S.dy_t * 4u);
         const uint32_t v_st = (uint32_t)lane * 16u;                                              // stash: float4 per lane
         const uint32_t v_dn = ((uint32_t)lrow * (uint32_t)T * 4u * H + (uint32_t)li) * 4u;
         const uint32_t dg_row_b = UNIFORM((uint32_t)T * 4u * H * 4u);
         float4 st[2][20];                                    // [col-block][coefficient * 4 + q]: cA, cB, u, r, gh_n
+        f32x16 dyv[2];
         // PACING: the memory waves have a whole contraction (~50 k cycles) for 40 loads and 24 + stores per lane.  Issued as one burst
         // they fill the CU's vector-memory FIFO and the LDS queues, and the MFMA waves' weight-ring loads and A-fragment reads wait
         // behind them (measured: contraction 60.7 k cycles per step instead of 49.2 k, profiles/r03_ws_probe.txt); so they go out in
@@ -780,26 +766,27 @@ __global__ __launch_bounds__(H / 32 * 64) void gru_ws_bwd_kernel(GruBwdParams P)
                     st[c2][i] = buf_load_f32x4(r_st, v_st, s_st + i * 1024u);
                     if (i % 4 == 3) { SCHED_FENCE(); for (int z = 0; z < pace; ++z) VAME_SLEEP4(); }
                 }
+                const uint32_t s_dy = UNIFORM(t * dy_t_b + cb * 128u);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    dyv[c2][r] = buf_load_f32(r_dy, v_dy, s_dy + (uint32_t)CR(r) * dy_row_b);
+                    if (r % 8 == 7) { SCHED_FENCE(); for (int z = 0; z < pace; ++z) VAME_SLEEP4(); }
+                }
             }
         };
-        // d of the first step = dh_T + dy -> xd
-        {
-            const int t0 = S.reverse ? 0 : T - 1;
+        // dh_T -> xd
 #pragma unroll
-            for (int c2 = 0; c2 < 2; ++c2) {
-                const int cb = 2 * k + c2;
+        for (int c2 = 0; c2 < 2; ++c2) {
+            const int cb = 2 * k + c2;
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    float v[4];
+            for (int q = 0; q < 4; ++q) {
+                float v[4];
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const int row = CR(4 * q + j) + lrow, grow = row0 + row;
-                        const float dhv = (S.dhn && grow < B) ? S.dhn[(int64_t)grow * S.dhn_row + 32 * cb + li] : 0.0f;
-                        const float dy0 = (S.dy && grow < B) ? S.dy[(int64_t)grow * S.dy_row + (int64_t)t0 * S.dy_t + 32 * cb + li] : 0.0f;
-                        v[j] = dhv + dy0;
-                    }
-                    xd[(cb * 4 + q) * 64 + lane] = make_float4(v[0], v[1], v[2], v[3]);
+                for (int j = 0; j < 4; ++j) {
+                    const int grow = row0 + CR(4 * q + j) + lrow;
+                    v[j] = (S.dhn && grow < B) ? S.dhn[(int64_t)grow * S.dhn_row + 32 * cb + li] : 0.0f;
                 }
+                xd[(cb * 4 + q) * 64 + lane] = make_float4(v[0], v[1], v[2], v[3]);
             }
         }
         load_step(0, 0);
@@ -820,44 +807,64 @@ __global__ __launch_bounds__(H / 32 * 64) void gru_ws_bwd_kernel(GruBwdParams P)
             const uint32_t s_t = UNIFORM(t * 4u * H * 4u);
             // ---- coefficient math of this wave's 64 columns: A tile -> gs, carry -> xd, dgi_n straight to dG (the A tile has no
             // room for it and 32 more live registers do not fit next to the 192 of the prefetched operands)
-            float4 dnext = xd[((2 * k) * 4 + 0) * 64 + lane];       // d of the first row group; each group requests the next one's
+            // Packed fp32 pairs (v_pk_mul_f32 / v_pk_add_f32: two IEEE operations per instruction, same results): the phase is bound by
+            // the instruction issue of ONE wave per SIMD while the MFMA waves wait, so halving its VALU count shortens the step.
+            float dan_keep[2][16];
 #pragma unroll
             for (int c2 = 0; c2 < 2; ++c2) {
                 const int cb = 2 * k + c2;
-                const uint32_t s_dn = UNIFORM(s_t + (2u * H + 32u * (2 * k + c2)) * 4u);
                 float* gw_lo = &gs[lrow * LDG + 32 * cb + li];
                 float* gw_hi = gw_lo + 16 * LDG;
+                f32x2 bs_ar = {0.f, 0.f}, bs_au = {0.f, 0.f}, bs_an = {0.f, 0.f}, bs_gh = {0.f, 0.f};
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    const float4 dhq = dnext;
-                    if (c2 * 4 + q < 7) dnext = xd[((2 * k + (c2 * 4 + q + 1) / 4) * 4 + (q + 1) % 4) * 64 + lane];
-                    const float dhv[4] = {dhq.x, dhq.y, dhq.z, dhq.w};
+                    const float4 dhq = xd[(cb * 4 + q) * 64 + lane];
                     const float4 sa = st[c2][0 * 4 + q], sb = st[c2][1 * 4 + q], su = st[c2][2 * 4 + q], sr = st[c2][3 * 4 + q], sg = st[c2][4 * 4 + q];
-                    const float av[4] = {sa.x, sa.y, sa.z, sa.w}, bv[4] = {sb.x, sb.y, sb.z, sb.w}, uv[4] = {su.x, su.y, su.z, su.w},
-                                rv[4] = {sr.x, sr.y, sr.z, sr.w}, gv[4] = {sg.x, sg.y, sg.z, sg.w};
                     float cy[4];
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const int r = 4 * q + j;
-                        const float d = dhv[j];                    // = dh + dy (see the MFMA waves)
-                        const float dan = d * av[j];
-                        const float dau = d * bv[j];
-                        const float dgh = dan * rv[j];
-                        const float dar = dgh * gv[j] * (1.0f - rv[j]);
-                        cy[j] = d * uv[j];                         // dh carried through the update gate
-                        float* gw = (r < 8 ? gw_lo : gw_hi) + (CR(r) & 15) * LDG;
-                        gw[0] = dar; gw[H] = dau; gw[2 * H] = dgh;
-                        if (!(ABL & 8)) buf_store_f32(r_dg, v_dn, s_dn + (uint32_t)CR(r) * dg_row_b, dan);
-                        dbs[c2][0] += dar; dbs[c2][1] += dau; dbs[c2][2] += dan; dbs[c2][3] += dgh;
+                    for (int h2 = 0; h2 < 2; ++h2) {
+                        const f32x2 d = (h2 ? f32x2{dhq.z, dhq.w} : f32x2{dhq.x, dhq.y})
+                                        + f32x2{dyv[c2][4 * q + 2 * h2], dyv[c2][4 * q + 2 * h2 + 1]};
+                        const f32x2 av = h2 ? f32x2{sa.z, sa.w} : f32x2{sa.x, sa.y}, bv = h2 ? f32x2{sb.z, sb.w} : f32x2{sb.x, sb.y};
+                        const f32x2 uv = h2 ? f32x2{su.z, su.w} : f32x2{su.x, su.y}, rv = h2 ? f32x2{sr.z, sr.w} : f32x2{sr.x, sr.y};
+                        const f32x2 gv = h2 ? f32x2{sg.z, sg.w} : f32x2{sg.x, sg.y};
+                        const f32x2 one = {1.0f, 1.0f};
+                        const f32x2 dan = d * av;
+                        const f32x2 dau = d * bv;
+                        const f32x2 dgh = dan * rv;
+                        const f32x2 dar = dgh * gv * (one - rv);
+                        const f32x2 c = d * uv;                    // dh carried through the update gate
+                        bs_ar += dar; bs_au += dau; bs_an += dan; bs_gh += dgh;
+#pragma unroll
+                        for (int e = 0; e < 2; ++e) {
+                            const int r = 4 * q + 2 * h2 + e;
+                            float* gw = (r < 8 ? gw_lo : gw_hi) + (CR(r) & 15) * LDG;
+                            gw[0] = dar[e]; gw[H] = dau[e]; gw[2 * H] = dgh[e];
+                            dan_keep[c2][r] = dan[e];
+                            cy[2 * h2 + e] = c[e];
+                        }
                     }
                     xd[(cb * 4 + q) * 64 + lane] = make_float4(cy[0], cy[1], cy[2], cy[3]);
                     SCHED_FENCE();                          // one row group at a time: its five stash registers die here
+                    if (c2 == 0 && q == 0) GRU_PHASE(0);    // (probe build) the first row group, i.e. the wait for the prefetched operands
                 }
+                // bias partials: the lock-step kernel adds element by element in register order; pairs first and then the two halves is a
+                // different (equally valid) fp32 summation order of the same 16 x T terms -> dbias agrees to rounding, not bit for bit
+                dbs[c2][0] += bs_ar[0] + bs_ar[1]; dbs[c2][1] += bs_au[0] + bs_au[1]; dbs[c2][2] += bs_an[0] + bs_an[1]; dbs[c2][3] += bs_gh[0] + bs_gh[1];
             }
             GRU_PHASE(1);                 // (probe build) memory waves: coefficient phase
             __syncthreads();                                // barrier 1
             GRU_PHASE(2);
-            // ---- beside the MFMA loop: the three tile blocks of dG out of LDS ...
+            // ---- beside the MFMA loop: dgi_n out of the registers, the three tile blocks of dG out of LDS ...
+            if (!(ABL & 8)) {
+#pragma unroll
+                for (int c2 = 0; c2 < 2; ++c2) {
+                    const uint32_t s_dn = UNIFORM(s_t + (2u * H + 32u * (2 * k + c2)) * 4u);
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) buf_store_f32(r_dg, v_dn, s_dn + (uint32_t)CR(r) * dg_row_b, dan_keep[c2][r]);
+                }
+                SCHED_FENCE();
+            }
             if (!(ABL & 1)) {
 #pragma unroll 2
                 for (int g = 0; g < 32 / MW; ++g) {
@@ -938,10 +945,11 @@ static void launch_bwd(const GruBwdParams& P, hipStream_t st) {
         // wave-specialised BPTT (gru_ws_bwd_kernel) for the hidden sizes it is instantiated for; VAME_GRU_WS=0 keeps the lock-step kernel
         if (gru_ws_enabled(H)) {
             GruBwdParams Q = P;
-            // pacing of the memory waves (units of 256 cycles per request group), sized so that their 8 + 10 groups span about two
-            // thirds of one contraction (2 x 48 x 16 MFMAs at H = 256, a quarter of that at H = 128): measured optimum 2 / 12 at H = 256
+            // pacing of the memory waves (units of 256 cycles per request group), sized so that their 8 copy + 14 load groups span
+            // about 90 % of one contraction (54 k cycles at H = 256, a quarter of that at H = 128) and never outlast it: measured
+            // optimum 2 / 8 at H = 256 (profiles/r03_ws_probe.txt: 7 .. 9 within noise, 10 and more make the MFMA waves wait)
             { const char* e = getenv("VAME_WS_PACE_CP"); Q.pace_cp = e ? atoi(e) : 2 * H * H / 65536; }
-            { const char* e = getenv("VAME_WS_PACE_LD"); Q.pace_ld = e ? atoi(e) : 12 * H * H / 65536; }
+            { const char* e = getenv("VAME_WS_PACE_LD"); Q.pace_ld = e ? atoi(e) : 8 * H * H / 65536; }
             const GruBwdParams& P = Q;
 #if !defined(VAME_EMU) && defined(VAME_GEMM_AB)
             if (H == 256) switch (abl_env("VAME_WS_ABL")) {

@@ -6,6 +6,7 @@
 #include "hip_emu.h"
 typedef f32x16_emu f32x16;
 typedef f32x4_emu f32x4;
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 #define MFMA_32x32x2(a, b, c) emu_mfma_32x32x2((a), (b), (c))
 #define MFMA_16x16x4(a, b, c) emu_mfma_16x16x4((a), (b), (c))
 #define VAME_DYN_SMEM(name) char* name = emu::dyn_smem()
@@ -24,6 +25,7 @@ typedef f32x4_emu f32x4;
 #include <hip/hip_runtime.h>
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));      /* pairs for the packed fp32 VALU ops (v_pk_mul_f32, v_pk_add_f32) */
 // f32-in/f32-acc matrix FMA: exact f32 (k-ordered fmaf chain) at the 157 TF rate on gfx950
 #define MFMA_32x32x2(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
 #define MFMA_16x16x4(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
