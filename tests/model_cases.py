@@ -168,6 +168,33 @@ def check_padded_hidden_sizes(dev):
         assert_grad_close(prm.grad.cpu().numpy(), grads[k], TINY_REL, k, step_scale_of(grads.values()))
 
 
+def check_legacy_padded_hidden(dev):
+    """RNN_VAE_LEGACY with a hidden size that is not a multiple of 32 (the padded parameter image under the legacy parameter names:
+    encoder.rnn_1 / rnn_2, lmbda.hidden_to_linear, uni-directional decoder) against the stock-torch restatement of the legacy model
+    (oracle/torch_ref.py, itself pinned by step_legacy.npz): loss terms and every gradient."""
+    from oracle.torch_ref import TorchRefLegacy, reference_loss
+    from vame_amd.model.rnn_model import RNN_VAE_LEGACY
+    T, F, Z, H, FS, B = 6, 12, 10, 40, 3, 7
+    torch.manual_seed(4)
+    m = RNN_VAE_LEGACY(2 * T, Z, F, 1, FS, H, H, H, H, 0, 0, 0, False)
+    ref = TorchRefLegacy(T, F, Z, H, FS)
+    ref.load_state_dict({k: v.clone() for k, v in m.state_dict().items()})
+    ref.train()
+    gen = torch.Generator().manual_seed(1)
+    win, eps = torch.randn(B, T + FS, F, generator=gen), torch.randn(B, Z, generator=gen)
+    loss, terms = reference_loss(ref(win[:, :T], eps), win[:, :T], win[:, T:], 0.7, kloss=Z, bsize=B)
+    loss.backward()
+    m = m.to(dev).train()
+    got = m.loss_step(win.to(dev).contiguous(), 0.7, beta=1.0, kloss=Z, klmbda=0.1, bsize=B, eps=eps.to(dev)).cpu().numpy()
+    for i, t in enumerate(terms):
+        assert_loss_close(got[i], float(t.detach()), name=str(i))
+    rg = {k: p.grad for k, p in ref.named_parameters()}
+    sc = step_scale_of(v.numpy() for v in rg.values() if v is not None)
+    for k, p in m.named_parameters():
+        r = rg[k].numpy() if rg.get(k) is not None else np.zeros(tuple(p.shape), np.float32)     # hidden_to_linear: unused, no gradient
+        assert_grad_close(p.grad.cpu().numpy(), r, TINY_REL, k, sc)
+
+
 def check_noise_input(dev):
     """cfg['noise']: the encoder sees a perturbed input while the reconstruction target stays clean (rnn_vae.py:116-124)."""
     from oracle import vame_oracle as vo

@@ -2,7 +2,7 @@
 reference's golden vectors (tiny model).  The same bodies run on the GPU in test_model_gpu.py."""
 import pytest
 
-from model_cases import check_decoder_inputs, check_padded_hidden_sizes, check_fused_heads_match, check_adam_trajectory, check_coop_failure_is_contained, check_odd_dims_vs_oracle, check_eval_and_submodules, check_evaluate_and_generative_cores, check_h0_view, check_device_window_loader, check_legacy_step, check_model_options, check_noise_input, check_stale_backward_guard, check_step
+from model_cases import check_legacy_padded_hidden, check_decoder_inputs, check_padded_hidden_sizes, check_fused_heads_match, check_adam_trajectory, check_coop_failure_is_contained, check_odd_dims_vs_oracle, check_eval_and_submodules, check_evaluate_and_generative_cores, check_h0_view, check_device_window_loader, check_legacy_step, check_model_options, check_noise_input, check_stale_backward_guard, check_step
 
 
 @pytest.mark.parametrize("name,kw,mse", [("step_tiny", 1.0, "sum"), ("step_tiny", 0.25, "sum"), ("step_tiny_oddB", 1.0, "sum"),
@@ -20,6 +20,10 @@ def test_autograd_path_matches_reference(emu):
 def test_hidden_sizes_not_multiple_of_32(emu):
     """VERDICT r2 #8: nn.GRU takes any hidden_size; the kernels run on a zero-padded parameter image (vame_amd/padding.py)."""
     check_padded_hidden_sizes("cpu")
+
+
+def test_legacy_topology_with_padded_hidden_size(emu):
+    check_legacy_padded_hidden("cpu")
 
 
 def test_decoders_over_arbitrary_inputs(emu):

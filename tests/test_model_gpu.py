@@ -6,7 +6,7 @@ import torch
 
 from conftest import load_golden
 from tolerances import BIG_REL, assert_grad_close, assert_loss_close, step_scale_of
-from model_cases import check_decoder_inputs, check_padded_hidden_sizes, check_fused_heads_match, check_adam_trajectory, check_coop_failure_is_contained, check_odd_dims_vs_oracle, check_eval_and_submodules, check_evaluate_and_generative_cores, check_h0_view, check_device_window_loader, check_legacy_step, check_model_options, check_noise_input, check_stale_backward_guard, check_step
+from model_cases import check_legacy_padded_hidden, check_decoder_inputs, check_padded_hidden_sizes, check_fused_heads_match, check_adam_trajectory, check_coop_failure_is_contained, check_odd_dims_vs_oracle, check_eval_and_submodules, check_evaluate_and_generative_cores, check_h0_view, check_device_window_loader, check_legacy_step, check_model_options, check_noise_input, check_stale_backward_guard, check_step
 from oracle import vame_oracle as vo
 from vame_amd.model.rnn_model import RNN_VAE
 
@@ -28,6 +28,10 @@ def test_autograd_path_matches_reference(hip):
 def test_hidden_sizes_not_multiple_of_32(hip):
     """VERDICT r2 #8: nn.GRU takes any hidden_size; the kernels run on a zero-padded parameter image (vame_amd/padding.py)."""
     check_padded_hidden_sizes("cuda")
+
+
+def test_legacy_topology_with_padded_hidden_size(hip):
+    check_legacy_padded_hidden("cuda")
 
 
 def test_decoders_over_arbitrary_inputs(hip):
