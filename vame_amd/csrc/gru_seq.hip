@@ -845,7 +845,7 @@ __global__ __launch_bounds__(H / 32 * 64) void gru_ws_bwd_kernel(GruBwdParams P)
                         }
                     }
                     xd[(cb * 4 + q) * 64 + lane] = make_float4(cy[0], cy[1], cy[2], cy[3]);
-                    SCHED_FENCE();                          // one row group at a time: its five stash registers die here
+                    if (q & 1) SCHED_FENCE();               // two row groups at a time (their LDS round trips overlap); their stash registers die here
                     if (c2 == 0 && q == 0) GRU_PHASE(0);    // (probe build) the first row group, i.e. the wait for the prefetched operands
                 }
                 // bias partials: the lock-step kernel adds element by element in register order; pairs first and then the two halves is a
