@@ -201,6 +201,32 @@ def test_model_options_dropout_and_hidden_sizes(name):
     np.testing.assert_allclose(ep, g["eval_pred"], atol=2e-5)
 
 
+def test_hmm_oracle_vs_sklearn_mixture_in_the_iid_limit():
+    """A second, third-party anchor at a realistic length (hmmlearn itself cannot be obtained here): an HMM whose
+    transition rows all equal its start distribution w emits i.i.d. draws from the mixture sum_k w_k N(mu_k, S_k), so its
+    log-likelihood and state posteriors over 3000 frames must equal scikit-learn's GaussianMixture with the same parameters --
+    which exercises the log-domain forward / backward recursions, the density and the posterior normalisation far beyond the
+    chain lengths brute-force enumeration can reach."""
+    from sklearn.mixture import GaussianMixture
+    from oracle import hmm_oracle as ho
+    rng = np.random.default_rng(11)
+    K, D, N = 4, 5, 3000
+    X = rng.standard_normal((N, D)) * rng.uniform(0.5, 2.0, D) + rng.standard_normal(D)
+    w = rng.dirichlet(np.ones(K) * 3)
+    means = rng.standard_normal((K, D))
+    A = rng.standard_normal((K, D, D))
+    covars = A @ A.transpose(0, 2, 1) / D + 0.3 * np.eye(D)
+    o = ho.GaussianHMMOracle(K)
+    o.startprob_, o.transmat_, o.means_, o.covars_ = w, np.tile(w, (K, 1)), means, covars
+    gm = GaussianMixture(K, covariance_type="full")
+    gm.weights_, gm.means_, gm.covariances_ = w, means, covars
+    gm.precisions_cholesky_ = np.stack([np.linalg.cholesky(np.linalg.inv(c)) for c in covars])        # sklearn's internal form: P = L L^T
+    logprob, stats, post = o.e_step(X)
+    np.testing.assert_allclose(logprob, gm.score_samples(X).sum(), rtol=1e-11)
+    np.testing.assert_allclose(post, gm.predict_proba(X), atol=1e-10)
+    np.testing.assert_allclose(stats["trans"].sum(0), post[1:].sum(0), atol=1e-8)                        # expected transition counts into each state
+
+
 @pytest.mark.parametrize("K,N,D,seed", [(2, 6, 2, 0), (3, 5, 1, 1), (2, 7, 3, 2)])
 def test_hmm_oracle_vs_exhaustive_enumeration(K, N, D, seed):
     """hmmlearn is not available to pin oracle/hmm_oracle.py against, so its recursions are pinned against the definition instead: on a
