@@ -51,13 +51,16 @@ def embed_series(model, data, batch=EMBED_BATCH, rank=0, world=1):
         raise ValueError(f"series has {F} features, model expects {s.F}")
     n = N - s.T
     lo, hi = (n * rank) // world, (n * (rank + 1)) // world
-    X = torch.from_numpy(np.ascontiguousarray(data, dtype=np.float32)).to(dev)     # .type(FloatTensor) of :91-94
+    # this rank's frames only: windows [lo, hi) read frames [lo, hi + T - 1) (a T-1 frame halo); nothing else crosses PCIe
+    seg = np.ascontiguousarray(data[:, lo:max(hi + s.T - 1, lo)], dtype=np.float32)      # .type(FloatTensor) of :91-94
+    Ns = seg.shape[1]
+    X = torch.from_numpy(seg).to(dev)
     out = torch.empty(max(hi - lo, 0), s.Z, device=dev)
     win = torch.empty(min(batch, max(hi - lo, 1)), s.T, F, device=dev)
     with torch.no_grad():
         for i0 in range(lo, hi, batch):
             b = min(batch, hi - i0)
-            ops.window_gather(X, N, F, None, i0, b, s.T, win)
+            ops.window_gather(X, Ns, F, None, i0 - lo, b, s.T, win)
             hn = eng.encode(win, s.T * F, b, training=False)
             _, mu, _ = eng.latent(hn, b, None, False, want_kl=False)
             out[i0 - lo:i0 - lo + b].copy_(mu[:b * s.Z].view(b, s.Z))
