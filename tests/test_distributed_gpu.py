@@ -38,3 +38,29 @@ def test_bench_refuses_more_ranks_than_gpus(hip):
     assert r.returncode != 0
     assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert "only 1 GPU" in r.stderr
+
+
+def test_bench_line_contract(hip):
+    """`python bench.py` on the MI355X (short: 3 timed steps, no CPU baseline): ONE JSON line with the contract's fields, the roofline
+    block measured live (dominant kernel, MFMA classes, the HBM-bound kernels of the step) and the three-region spread."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "2", "--no-cpu-baseline"], capture_output=True,
+                       text=True, timeout=600, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    j = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline"):
+        assert k in j, k
+    assert j["n_gpus"] == 1 and j["steps"] == 3 and j["warmup"] == 2 and j["dtype"] == "f32" and j["unit"] == "windows/s" and j["vs_baseline"] is None
+    assert j["value"] > 50_000 and abs(j["value"] - 4096 * 3 / (j["ms_per_step"] * 3e-3)) / j["value"] < 1e-3
+    roof = j["roofline"]
+    assert roof["bound"] == "mfma" and roof["peak"] == 157.3 and 0.3 < roof["frac"] < 1.0 and 0.3 < roof["step_frac"] < 1.0
+    assert abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-3
+    for c in ("gru_seq_fwd_kernel<256>", "gru_seq_bwd_kernel<256>", "gemm_kernel TN", "gemm_kernel NT", "gemm_kernel NN"):
+        assert roof["by_class"][c]["tflops"] > 20, c
+    for c in ("window_gather_kernel", "mse_kernel", "timesum_kernel"):
+        assert roof["by_class"][c]["bound"] == "hbm" and 0 < roof["by_class"][c]["frac"] < 1, c
+    assert j["repeat_spread"]["regions"] == 3 and j["repeat_spread"]["min"] <= j["value"] <= j["repeat_spread"]["max"] * 1.0001
+    also = j["also"]
+    assert also["configs3_h512_t60_b8192"]["value"] > 5_000 and also["configs4_embed_1gpu"]["value"] > 100_000
