@@ -289,3 +289,28 @@ def test_cfg4_full_batch_properties(hip):
 
 def test_fused_output_heads_match_the_default_path(hip):
     check_fused_heads_match("cuda")
+
+
+def test_side_stream_overlaps_do_not_change_results(hip):
+    """The three side-stream overlaps of a train step (nuclear-norm solve beside the output heads, future-decoder dW_hh beside the
+    post-BPTT chain, narrow weight gradients beside the wide ones) only reorder independent work: losses and every gradient must be
+    bit-identical with them on and off, launch after launch (a missing join would show up as a race here)."""
+    T, F, Z, H, FS, B = 30, 24, 30, 256, 15, 2048
+    torch.manual_seed(19)
+    model = RNN_VAE(2 * T, Z, F, 1, FS, H, H, H, H, 0, 0, 0, False).cuda().train()
+    gen = torch.Generator().manual_seed(3)
+    win = torch.randn(B, T + FS, F, generator=gen).cuda()
+    eps = torch.randn(B, Z, generator=gen).cuda()
+    eng = model._ensure_engine()
+    ref = None
+    for it in range(6):
+        prev = eng.set_overlap(it % 2 == 1)
+        terms = model.loss_step(win, 0.7, beta=1.0, kloss=Z, klmbda=0.1, bsize=B, eps=eps)
+        torch.cuda.synchronize()
+        got = (terms.clone(), model.flat_parameters()[1].clone())
+        eng.set_overlap(prev)
+        if ref is None:
+            ref = got
+        else:
+            assert torch.equal(got[0], ref[0]), (it, got[0], ref[0])
+            assert torch.equal(got[1], ref[1]), it
