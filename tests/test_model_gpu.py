@@ -293,8 +293,10 @@ def test_fused_output_heads_match_the_default_path(hip):
 
 def test_side_stream_overlaps_do_not_change_results(hip):
     """The three side-stream overlaps of a train step (nuclear-norm solve beside the output heads, future-decoder dW_hh beside the
-    post-BPTT chain, narrow weight gradients beside the wide ones) only reorder independent work: losses and every gradient must be
-    bit-identical with them on and off, launch after launch (a missing join would show up as a race here)."""
+    post-BPTT chain, narrow weight gradients beside the wide ones) only reorder independent work: every gradient must be
+    bit-identical with them on and off, launch after launch (a missing join would show up as a race here).  The eigen-solver's warm
+    start is reset before each step (its result depends on the previous call's eigenvectors at the 1e-7 level otherwise); the
+    rec / fut / KL scalars are sums of per-workgroup float atomics (logging only, no gradient reads them) and are compared to 1e-6."""
     T, F, Z, H, FS, B = 30, 24, 30, 256, 15, 2048
     torch.manual_seed(19)
     model = RNN_VAE(2 * T, Z, F, 1, FS, H, H, H, H, 0, 0, 0, False).cuda().train()
@@ -303,8 +305,10 @@ def test_side_stream_overlaps_do_not_change_results(hip):
     eps = torch.randn(B, Z, generator=gen).cuda()
     eng = model._ensure_engine()
     ref = None
-    for it in range(6):
+    for it in range(8):
         prev = eng.set_overlap(it % 2 == 1)
+        if eng._nuc_state is not None:
+            eng._nuc_state.zero_()
         terms = model.loss_step(win, 0.7, beta=1.0, kloss=Z, klmbda=0.1, bsize=B, eps=eps)
         torch.cuda.synchronize()
         got = (terms.clone(), model.flat_parameters()[1].clone())
@@ -312,5 +316,6 @@ def test_side_stream_overlaps_do_not_change_results(hip):
         if ref is None:
             ref = got
         else:
-            assert torch.equal(got[0], ref[0]), (it, got[0], ref[0])
-            assert torch.equal(got[1], ref[1]), it
+            assert torch.equal(got[0][3], ref[0][3]), (it, got[0], ref[0])                       # nuclear-norm term: one thread's sum
+            np.testing.assert_allclose(got[0][:3].cpu().numpy(), ref[0][:3].cpu().numpy(), rtol=1e-6)
+            assert torch.equal(got[1], ref[1]), (it, float((got[1] - ref[1]).abs().max()))
