@@ -296,7 +296,7 @@ def test_side_stream_overlaps_do_not_change_results(hip):
     post-BPTT chain, narrow weight gradients beside the wide ones) only reorder independent work: every gradient must be
     bit-identical with them on and off, launch after launch (a missing join would show up as a race here).  The eigen-solver's warm
     start is reset before each step (its result depends on the previous call's eigenvectors at the 1e-7 level otherwise); the
-    rec / fut / KL scalars are sums of per-workgroup float atomics (logging only, no gradient reads them) and are compared to 1e-6."""
+    rec / fut / KL scalars are sums of per-workgroup float atomics (logging only, no gradient reads them) and are compared to 2e-5 (measured run-to-run spread of the atomics: ~2e-6)."""
     T, F, Z, H, FS, B = 30, 24, 30, 256, 15, 2048
     torch.manual_seed(19)
     model = RNN_VAE(2 * T, Z, F, 1, FS, H, H, H, H, 0, 0, 0, False).cuda().train()
@@ -317,5 +317,5 @@ def test_side_stream_overlaps_do_not_change_results(hip):
             ref = got
         else:
             assert torch.equal(got[0][3], ref[0][3]), (it, got[0], ref[0])                       # nuclear-norm term: one thread's sum
-            np.testing.assert_allclose(got[0][:3].cpu().numpy(), ref[0][:3].cpu().numpy(), rtol=1e-6)
+            np.testing.assert_allclose(got[0][:3].cpu().numpy(), ref[0][:3].cpu().numpy(), rtol=2e-5)
             assert torch.equal(got[1], ref[1]), (it, float((got[1] - ref[1]).abs().max()))
