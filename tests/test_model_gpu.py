@@ -296,7 +296,7 @@ def test_side_stream_overlaps_do_not_change_results(hip):
     post-BPTT chain, narrow weight gradients beside the wide ones) only reorder independent work: every gradient must be
     bit-identical with them on and off, launch after launch (a missing join would show up as a race here).  The eigen-solver's warm
     start is reset before each step (its result depends on the previous call's eigenvectors at the 1e-7 level otherwise); the
-    rec / fut / KL scalars are sums of per-workgroup float atomics (logging only, no gradient reads them) and are compared to 2e-5 (measured run-to-run spread of the atomics: ~2e-6)."""
+    rec / fut / KL scalars are sums of per-workgroup float atomics (logging only, no gradient reads them) and are compared to 2e-5 (their summation order varies from launch to launch)."""
     T, F, Z, H, FS, B = 30, 24, 30, 256, 15, 2048
     torch.manual_seed(19)
     model = RNN_VAE(2 * T, Z, F, 1, FS, H, H, H, H, 0, 0, 0, False).cuda().train()
