@@ -706,8 +706,14 @@ extern "C" int vame_gemm_group_f32(int count, int M, int N, int K, const float* 
     hipStream_t st = (hipStream_t)stream;
     // same tile choice as vame_gemm_f32 for the output width (narrow outputs: the dW_ih of GRUs fed by the latent vector -- tiny
     // problems that are grouped for their launch count, not for occupancy)
-    const int rc = N > 64 ? launch_gemm<128, 128, 2, 2>(p, a_kmajor, b_kmajor, st)
-                 : N > 32 ? launch_gemm<128, 64, 4, 1>(p, a_kmajor, b_kmajor, st) : launch_gemm<128, 32, 4, 1>(p, a_kmajor, b_kmajor, st);
+    int rc;
+#if !defined(VAME_EMU) && defined(VAME_GEMM_AB)      // tuning build: 256 x 128 tiles for the grouped form (tools/gemm_group_ab.py; measured 15-30 % slower)
+    if (N > 64 && M >= 256 && getenv("VAME_GEMM_TILE") && atoi(getenv("VAME_GEMM_TILE")) == 1) rc = launch_gemm<256, 128, 2, 2>(p, a_kmajor, b_kmajor, st);
+    else if (N > 64 && M >= 256 && getenv("VAME_GEMM_TILE") && atoi(getenv("VAME_GEMM_TILE")) == 2) rc = launch_gemm<256, 128, 4, 2>(p, a_kmajor, b_kmajor, st);
+    else
+#endif
+    rc = N > 64 ? launch_gemm<128, 128, 2, 2>(p, a_kmajor, b_kmajor, st)
+       : N > 32 ? launch_gemm<128, 64, 4, 1>(p, a_kmajor, b_kmajor, st) : launch_gemm<128, 32, 4, 1>(p, a_kmajor, b_kmajor, st);
     VAME_CHECK_ARG(rc == VAME_OK, rc, "gemm_group: unsupported layout");
     VAME_LAUNCH_CHECK("gemm_group");
     GemmGroupOut out;
