@@ -52,9 +52,14 @@ def embed_series(model, data, batch=EMBED_BATCH, rank=0, world=1):
     n = N - s.T
     lo, hi = (n * rank) // world, (n * (rank + 1)) // world
     # this rank's frames only: windows [lo, hi) read frames [lo, hi + T - 1) (a T-1 frame halo); nothing else crosses PCIe
-    seg = np.ascontiguousarray(data[:, lo:max(hi + s.T - 1, lo)], dtype=np.float32)      # .type(FloatTensor) of :91-94
-    Ns = seg.shape[1]
-    X = torch.from_numpy(seg).to(dev)
+    view = data[:, lo:max(hi + s.T - 1, lo)]
+    Ns = view.shape[1]
+    if view.dtype == np.float32 and (Ns == 0 or view.strides[1] == 4):
+        X = torch.empty((F, Ns), device=dev)              # float32 rows go up as they lie (no host-side copy of the slice)
+        for f in range(F):
+            X[f].copy_(torch.from_numpy(view[f]))
+    else:
+        X = torch.from_numpy(np.ascontiguousarray(view, dtype=np.float32)).to(dev)     # .type(FloatTensor) of :91-94
     out = torch.empty(max(hi - lo, 0), s.Z, device=dev)
     win = torch.empty(min(batch, max(hi - lo, 1)), s.T, F, device=dev)
     with torch.no_grad():
