@@ -426,11 +426,14 @@ def embed_leg(dev, n_win_per_rank, rank, world, H=256, T=30):
         dt = float(tt.item())
     assert torch.isfinite(out).all()
     value = n_win / dt
-    tf = value / world * MFLOP_PER_WINDOW_EMBED * 1e6 / 1e12
+    # encoder (two bi-GRU layers) + both Lambda heads, matmul flops, 2 / MAC: 96.707 MFLOP per window at H = 256, T = 30
+    mflop = (2 * T * 2 * 3 * H * (F + H) + 2 * T * 2 * 3 * H * (2 * H + H) + 2 * 2 * 4 * H * Z) / 1e6
+    assert (H, T) != (256, 30) or abs(mflop - MFLOP_PER_WINDOW_EMBED) < 1e-3
+    tf = value / world * mflop * 1e6 / 1e12
     del model, out
     if dev.type == "cuda":
         torch.cuda.empty_cache()
-    return dict(metric="latent-embedding windows/sec (encoder + Lambda mean) T=30,F=24,h=256", value=round(value, 1), unit="windows/s",
+    return dict(metric=f"latent-embedding windows/sec (encoder + Lambda mean) T={T},F={F},h={H}", value=round(value, 1), unit="windows/s",
                 n_gpus=world, seconds=round(dt, 3), windows=n_win,
                 includes="host->device upload of the series + window gather + encoder + mean",
                 config=dict(workload=f"BASELINE.json configs[4] shape: {n_win_per_rank} stride-1 windows per GPU, batch 16384",

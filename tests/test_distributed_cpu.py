@@ -187,6 +187,15 @@ def test_bench_script_under_torchrun_two_ranks(emu):
     _check_two_rank_line(_bench_line(cmd))
 
 
+def test_bench_embed_mode_two_ranks(emu):
+    """`bench.py --mode embed --gpus 2` (BASELINE configs[4]: the window index range sharded over ranks, no collective on the data
+    path): self-launch, one JSON line, whole-job windows = 2 x per-rank windows."""
+    out = _bench_line([sys.executable, os.path.join(ROOT, "tests", "emu", "harness.py"), os.path.join(ROOT, "bench.py"), "--mode", "embed", "--gpus", "2",
+                       "--embed-windows", "300", "--hidden", "32", "--time-window", "4"])
+    assert out["n_gpus"] == 2 and out["windows"] == 600 and out["value"] > 0 and out["config"]["parallelism"] == "shard2"
+    assert out["metric"].endswith("T=4,F=24,h=32") and out["roofline"]["traffic"] is None
+
+
 def test_bench_script_launches_its_own_ranks(emu):
     """`python bench.py --gpus 2` with no torchrun environment must start the two ranks itself (never a silent 1-rank run), and a
     WORLD_SIZE that contradicts --gpus is an error."""
