@@ -417,6 +417,10 @@ class VAEEngine:
             return None
         return self._coop_state.status if self._coop_state.shared is None else self._coop_state.shared
 
+    def unshare_status(self):
+        if self._coop_state is not None and self._coop_state.shared is not None:
+            self._coop_state.shared = None
+
     def share_status(self, word):
         """Several ranks: copy this rank's status into `word` (one float behind the gradient bucket) so that the gradient all-reduce
         carries it; from then on `word` is the abort flag and the snapshot source on every rank (ops.CoopState)."""

@@ -164,6 +164,8 @@ def allreduce_gradients(model):
         eng.share_status(bucket[n:n + 1])
         dist.all_reduce(bucket, op=dist.ReduceOp.SUM)
         eng.snapshot_async_errors(reduced=True)
+    elif getattr(model, "_engine", None) is not None:
+        model._engine.unshare_status()          # (a process group that has been shut down since: back to the rank-local status word)
     return 1.0 / world
 
 
