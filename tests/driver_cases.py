@@ -173,6 +173,92 @@ def check_generative_model_modes(project):
     plt.close("all")
 
 
+def check_train_model_options(project, tmp_path, capsys):
+    """Config keys of the train driver beyond the stock values (SURVEY 8(b) list): `pretrained_weights` (loads best_model/<pretrained_model>_<Project>.pkl
+    and forces KL_START = 0, ANNEALTIME = 1: rnn_vae.py:306-323), `noise` (rnn_vae.py:116-119), `scheduler: 0` (StepLR, :339), a non-'sum' reduction, a
+    second `model_name`; then the failure branches: a missing pretrained file prints the reference's hint and trains from scratch, an unknown anneal
+    function raises NotImplementedError (:75)."""
+    import shutil
+    vame = _vame()
+    root, cfg, g = project
+    oroot = tmp_path / "opts"
+    shutil.copytree(root / "data", oroot / "data")
+    shutil.copytree(root / "model", oroot / "model")                      # best_model/VAME_demo.pkl from the first driver test
+    ocfg = dict(cfg, project_path=str(oroot), pretrained_weights=True, pretrained_model="VAME", model_name="VAME2", noise=True, scheduler=0,
+                mse_prediction_reduction="mean", max_epochs=4, model_snapshot=2, batch_size=96)
+    with open(oroot / "config.yaml", "w") as f:
+        yaml.safe_dump(ocfg, f)
+    np.random.seed(2)
+    vame.train_model(str(oroot / "config.yaml"))
+    out = capsys.readouterr().out
+    assert "Loading pretrained weights from" in out and "Could not load pretrained model" not in out
+    ld = oroot / "model" / "model_losses"
+    np.testing.assert_allclose(np.load(ld / "weight_values_VAME2.npy"), [1.0, 1.0, 1.0])          # KL_START = 0, ANNEALTIME = 1 from epoch 1 on
+    first = np.load(ld / "mse_train_losses_VAME2.npy")[0]
+    assert os.path.exists(oroot / "model" / "best_model" / "VAME2_demo.pkl")                       # weight > 0.99 from the first epoch: saved
+    assert sorted(os.listdir(oroot / "model" / "best_model" / "snapshots")) == sorted(list(g["files_snap"]) + ["VAME2_demo_epoch_2.pkl"])
+    fut = np.load(ld / "fut_losses_VAME2.npy")
+    assert fut[0] < 10.0                                                                           # 'mean' reduction of the future term (sum: ~1e3)
+    # a pretrained model that does not exist: the reference prints a hint and goes on with the fresh initialisation
+    bad = dict(ocfg, pretrained_model="nope", model_name="VAME3", max_epochs=3)
+    with open(oroot / "config_bad.yaml", "w") as f:
+        yaml.safe_dump(bad, f)
+    os.replace(oroot / "config_bad.yaml", oroot / "config.yaml")
+    vame.train_model(str(oroot / "config.yaml"))
+    assert "Could not load pretrained model" in capsys.readouterr().out
+    np.testing.assert_allclose(np.load(ld / "weight_values_VAME3.npy"), [0.0, 0.0])               # stock kl_start = 2
+    assert first < 0.99 * np.load(ld / "mse_train_losses_VAME3.npy")[0]                            # the first run DID start from the trained weights
+    with open(oroot / "config.yaml", "w") as f:
+        yaml.safe_dump(dict(bad, pretrained_weights=False, anneal_function="cosine", kl_start=0), f)
+    with pytest.raises(NotImplementedError):
+        vame.train_model(str(oroot / "config.yaml"))
+
+
+def check_pose_segmentation_prompts(project, tmp_path, monkeypatch):
+    """The interactive branches of pose_segmentation() (pose_segmentation.py:218-236,267-277): `all_data: 'No'` asks which files to
+    quantify, an existing parameterization asks before recomputing it from the saved latents; `individual_parameterization: True`
+    clusters every file on its own with `random_state_kmeans` / `n_init_kmeans`."""
+    import builtins
+    import shutil
+    vame = _vame()
+    root, cfg, g = project
+    proot = tmp_path / "prompts"
+    shutil.copytree(root / "data", proot / "data")
+    shutil.copytree(root / "model", proot / "model")
+    os.makedirs(proot / "data" / "vid2")
+    np.save(proot / "data" / "vid2" / "vid2-PE-seq-clean.npy", g["train_seq"][:, 50:150])
+    pcfg = dict(cfg, project_path=str(proot), video_sets=["vid1", "vid2"], all_data="No", individual_parameterization=True, n_cluster=3)
+    with open(proot / "config.yaml", "w") as f:
+        yaml.safe_dump(pcfg, f)
+    asked = []
+
+    def answers(seq):
+        it = iter(seq)
+
+        def fake(prompt=""):
+            asked.append(prompt)
+            return next(it)
+        return fake
+    monkeypatch.setattr(builtins, "input", answers(["no", "no", "yes"]))        # not everything; vid1: no, vid2: yes
+    vame.pose_segmentation(str(proot / "config.yaml"))
+    assert len(asked) == 3 and "entire dataset" in asked[0] and "vid1" in asked[1] and "vid2" in asked[2]
+    out2 = proot / "results" / "vid2" / "VAME" / "kmeans-3"
+    lat = np.load(out2 / "latent_vector_vid2.npy")
+    assert lat.shape == (100 - cfg["time_window"], cfg["zdims"]) and np.load(out2 / "cluster_center_vid2.npy").shape == (3, cfg["zdims"])
+    assert not os.path.exists(proot / "results" / "vid1" / "VAME" / "kmeans-3")
+    lab_first = np.load(out2 / "3_km_label_vid2.npy")
+    # second call: the parameterization exists -> asks; 'no' leaves the files alone, 'yes' recomputes from the SAVED latents
+    stamp = os.path.getmtime(out2 / "3_km_label_vid2.npy")
+    asked.clear()
+    monkeypatch.setattr(builtins, "input", answers(["vid2", "no"]))             # a file name instead of yes / no
+    vame.pose_segmentation(str(proot / "config.yaml"))
+    assert len(asked) == 2 and "already exists" in asked[1] and os.path.getmtime(out2 / "3_km_label_vid2.npy") == stamp
+    monkeypatch.setattr(builtins, "input", answers(["vid2", "yes"]))
+    vame.pose_segmentation(str(proot / "config.yaml"))
+    np.testing.assert_array_equal(np.load(out2 / "latent_vector_vid2.npy"), lat)
+    np.testing.assert_array_equal(np.load(out2 / "3_km_label_vid2.npy"), lab_first)               # same latents, same random_state
+
+
 def check_train_model_legacy_topology(project, tmp_path):
     """cfg['legacy'] = True trains RNN_VAE_LEGACY (rnn_vae.py:294-297): checkpoint keys / shapes of the legacy model."""
     import shutil

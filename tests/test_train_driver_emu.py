@@ -36,6 +36,14 @@ def test_generative_model_modes(project):
     dc.check_generative_model_modes(project)
 
 
+def test_train_model_options(project, tmp_path, capsys):
+    dc.check_train_model_options(project, tmp_path, capsys)
+
+
+def test_pose_segmentation_prompts(project, tmp_path, monkeypatch):
+    dc.check_pose_segmentation_prompts(project, tmp_path, monkeypatch)
+
+
 def test_train_model_legacy_topology(project, tmp_path):
     dc.check_train_model_legacy_topology(project, tmp_path)
 
