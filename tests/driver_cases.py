@@ -212,6 +212,15 @@ def check_train_model_options(project, tmp_path, capsys):
         yaml.safe_dump(dict(bad, pretrained_weights=False, anneal_function="cosine", kl_start=0), f)
     with pytest.raises(NotImplementedError):
         vame.train_model(str(oroot / "config.yaml"))
+    # model_convergence (rnn_vae.py:375-394): the counter grows while no best model is saved (weight <= 0.99 in the first epochs) and the
+    # loop breaks BEFORE that epoch's loss arrays are written, exactly as in the reference
+    with open(oroot / "config.yaml", "w") as f:
+        yaml.safe_dump(dict(bad, pretrained_weights=False, model_name="VAME4", model_convergence=0, max_epochs=6), f)
+    capsys.readouterr()
+    vame.train_model(str(oroot / "config.yaml"))
+    out = capsys.readouterr().out
+    assert "Model converged" in out and out.count("Epoch:") == 1
+    assert not os.path.exists(ld / "train_losses_VAME4.npy")
 
 
 def check_pose_segmentation_prompts(project, tmp_path, monkeypatch):
