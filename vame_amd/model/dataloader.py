@@ -16,22 +16,28 @@ from torch.utils.data.dataset import Dataset
 from .. import ops
 
 
+def _series_statistics(folder, series, compute):
+    """Global scalar mean / std of the TRAIN series, kept next to it as seq_mean.npy / seq_std.npy (the on-disk contract of
+    dataloader.py:27-35): computed and written by the first training run, read by every later run and by the test split."""
+    files = [folder + name for name in ("seq_mean.npy", "seq_std.npy")]
+    if compute and not os.path.exists(os.path.join(folder, "seq_mean.npy")):
+        print("Compute mean and std for temporal dataset.")
+        stats = (np.mean(series), np.std(series))
+        for f, v in zip(files, stats):
+            np.save(f, v)
+        return stats
+    return tuple(np.load(f) for f in files)
+
+
 class SEQUENCE_DATASET(Dataset):
+    """Same constructor, attributes (`X` (F, N), `mean`, `std`, `data_points`, `temporal_window`) and item semantics as the reference's class."""
+
     def __init__(self, path_to_file, data, train, temporal_window):
+        series = np.load(path_to_file + data)
+        self.X = series.T if series.shape[0] > series.shape[1] else series        # stored feature-major whatever the file's orientation (:22-23)
         self.temporal_window = temporal_window
-        self.X = np.load(path_to_file + data)
-        if self.X.shape[0] > self.X.shape[1]:
-            self.X = self.X.T
-        self.data_points = len(self.X[0, :])
-        if train and not os.path.exists(os.path.join(path_to_file, 'seq_mean.npy')):
-            print("Compute mean and std for temporal dataset.")
-            self.mean = np.mean(self.X)
-            self.std = np.std(self.X)
-            np.save(path_to_file + 'seq_mean.npy', self.mean)
-            np.save(path_to_file + 'seq_std.npy', self.std)
-        else:
-            self.mean = np.load(path_to_file + 'seq_mean.npy')
-            self.std = np.load(path_to_file + 'seq_std.npy')
+        self.data_points = self.X.shape[1]
+        self.mean, self.std = _series_statistics(path_to_file, self.X, train)
         print('Initialize %s data. Datapoints %d' % ('train' if train else 'test', self.data_points))
 
     def __len__(self):
