@@ -75,20 +75,28 @@ def self_launch(args):
 
 # ------------------------------------------------------------------------------------------------ per-kernel timing (HIP events)
 class KernelTimer:
-    """HIP-event timing of each C-ABI launch group on the stream it is launched on (torch's current stream)."""
+    """HIP-event timing of each C-ABI launch group on the stream it is launched on (torch's current stream).  MFMA-bound groups
+    are also bracketed by clock stamps (vame_clock_stamp, OUTSIDE the event pair): the average shader clock while that kernel ran."""
 
-    def __init__(self):
+    def __init__(self, clocked=()):
         self.records = []
+        self.clocked = set(clocked)
 
     def wrap(self, ops_mod, name, work_fn):
         inner = getattr(ops_mod, name)
+        from vame_amd import ops as _ops
 
         def timed(*a, **k):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            probe = _ops.ClockProbe(torch.device("cuda", torch.cuda.current_device())) if name in self.clocked else None
+            if probe is not None:
+                probe.start()
             e0.record()
             r = inner(*a, **k)
             e1.record()
-            self.records.append((name, work_fn(*a, **k), e0, e1))
+            if probe is not None:
+                probe.stop()
+            self.records.append((name, work_fn(*a, **k), e0, e1, probe))
             return r
         setattr(ops_mod, name, timed)
         return inner
@@ -96,11 +104,18 @@ class KernelTimer:
     def summary(self):
         torch.cuda.synchronize()
         agg = {}
-        for name, (key, work), e0, e1 in self.records:
-            d = agg.setdefault(key, dict(api=name, launches=0, ms=0.0, work=0.0))
+        for name, (key, work), e0, e1, probe in self.records:
+            d = agg.setdefault(key, dict(api=name, launches=0, ms=0.0, work=0.0, clk_ms=0.0, clk_w=0.0))
+            ms = e0.elapsed_time(e1)
             d["launches"] += 1
-            d["ms"] += e0.elapsed_time(e1)
+            d["ms"] += ms
             d["work"] += work
+            mhz = probe.mhz() if probe is not None else None
+            if mhz:                                   # time-weighted mean clock of the group's launches
+                d["clk_ms"] += ms
+                d["clk_w"] += ms * mhz
+        for d in agg.values():
+            d["mhz"] = d["clk_w"] / d["clk_ms"] if d["clk_ms"] > 0 else None
         return agg
 
 
@@ -108,7 +123,8 @@ def profile_kernels(model, loader, B, steps=3):
     """Per-kernel-class time + algorithmic flops (MFMA classes) or algorithmic HBM bytes (gather / mse / timesum) over `steps` train
     steps, separate from the timed region."""
     from vame_amd import ops
-    kt = KernelTimer()
+    mfma_apis = ("gru_seq_fwd", "gru_seq_bwd", "gru_wide_fwd", "gru_wide_bwd", "gru_coop_fwd", "gru_coop_bwd", "gemm", "gemm_group")
+    kt = KernelTimer(clocked=mfma_apis)
 
     def gru_flops(tag):
         def f(streams, B_, Hh):
@@ -116,6 +132,13 @@ def profile_kernels(model, loader, B, steps=3):
             fl = sum(2.0 * 3 * Hh * Hh * B_ * int(s[key_t]) for s in streams)
             name = "gru_seq" if Hh <= 256 else "gru_wide"
             return (f"{name}_{tag}_kernel<{Hh}> x{len(streams)} streams", fl)
+        return f
+
+    def coop_flops(tag):       # column-split GRU launches of the small-batch path: rows = (row0, nrows) restricts the launch to a row range
+        def f(streams, B_, Hh, state, rows=(0, 0)):
+            key_t = ops.GF["T"] if tag == "fwd" else ops.GB["T"]
+            nrows = rows[1] or B_
+            return (f"gru_coop_{tag}_kernel<{Hh}> x{len(streams)} streams", sum(2.0 * 3 * Hh * Hh * nrows * int(s[key_t]) for s in streams))
         return f
 
     def gemm_flops(M, N, K, A, akm, Bm, bkm, *a, **k):
@@ -138,6 +161,7 @@ def profile_kernels(model, loader, B, steps=3):
 
     saved = {n: kt.wrap(ops, n, fn) for n, fn in (("gru_seq_fwd", gru_flops("fwd")), ("gru_seq_bwd", gru_flops("bwd")),
                                                   ("gru_wide_fwd", gru_flops("fwd")), ("gru_wide_bwd", gru_flops("bwd")),
+                                                  ("gru_coop_fwd", coop_flops("fwd")), ("gru_coop_bwd", coop_flops("bwd")),
                                                   ("gemm", gemm_flops), ("gemm_group", group_flops),
                                                   ("window_gather", gather_bytes), ("mse_fwd_bwd", mse_bytes), ("timesum", timesum_bytes))}
     # per-kernel durations are taken with the step's side-stream overlaps OFF (engine.set_overlap): a kernel that shares the chip with
@@ -159,7 +183,15 @@ def profile_kernels(model, loader, B, steps=3):
     return agg
 
 
-def roofline_block(agg, value_per_gpu, mflop_per_window, ms_per_step, dump=False):
+NOMINAL_MHZ = 2400.0                      # MI355X_MICROARCH.md: the clock the 157.3 TF peak is quoted at
+
+
+def at_clock(frac, mhz):
+    """A fraction of the nominal peak restated against what the box's sustained shader clock allows: frac / (clock / 2400 MHz)."""
+    return round(frac * NOMINAL_MHZ / mhz, 4) if mhz else None
+
+
+def roofline_block(agg, value_per_gpu, mflop_per_window, ms_per_step, dump=False, region_mhz=None):
     mf = {k: d for k, d in agg.items() if not k.startswith("hbm ")}
     hb = {k: d for k, d in agg.items() if k.startswith("hbm ")}
     mfma_ms = sum(d["ms"] for d in mf.values())
@@ -175,18 +207,30 @@ def roofline_block(agg, value_per_gpu, mflop_per_window, ms_per_step, dump=False
     classes = {}
     for k, d in mf.items():
         c = k.split(" ")[0] + (" " + k.split(" ")[1] if k.startswith("gemm") else "")
-        e = classes.setdefault(c, dict(ms=0.0, work=0.0))
+        e = classes.setdefault(c, dict(ms=0.0, work=0.0, clk_ms=0.0, clk_w=0.0))
         e["ms"] += d["ms"]
         e["work"] += d["work"]
-    by_class = {c: dict(ms_per_step=round(e["ms"], 3), tflops=round(e["work"] / (e["ms"] * 1e-3) / 1e12, 2)) for c, e in classes.items()}
+        e["clk_ms"] += d.get("clk_ms", 0.0)
+        e["clk_w"] += d.get("clk_w", 0.0)
+    by_class = {}
+    for c, e in classes.items():
+        tf = e["work"] / (e["ms"] * 1e-3) / 1e12
+        mhz = e["clk_w"] / e["clk_ms"] if e["clk_ms"] > 0 else None
+        by_class[c] = dict(ms_per_step=round(e["ms"], 3), tflops=round(tf, 2), clock_mhz=round(mhz, 0) if mhz else None,
+                           frac_at_clock=at_clock(tf / PEAK_F32_MFMA_TFLOPS, mhz))
     for k, d in hb.items():                       # the bandwidth-bound kernels of the step against the 8 TB/s HBM roofline
         gbs = d["work"] / (d["ms"] * 1e-3) / 1e9
         by_class[k[4:]] = dict(bound="hbm", ms_per_step=round(d["ms"], 4), launches_per_step=d["launches"],
                                algorithmic_mb_per_step=round(d["work"] / 1e6, 2), gbs=round(gbs, 1), frac=round(gbs / PEAK_HBM_GBS, 4))
+    step_frac = value_per_gpu * mflop_per_window * 1e6 / (PEAK_F32_MFMA_TFLOPS * 1e12)
     return dict(bound="mfma", kernel=dom_key, achieved=round(achieved, 3), peak=PEAK_F32_MFMA_TFLOPS, unit="TFLOP/s",
                 frac=round(achieved / PEAK_F32_MFMA_TFLOPS, 4), traffic=pmc_traffic(dom_key),
+                # the shader clock the box sustained WHILE the dominant kernel ran (vame_clock_stamp around each of its launches) and the
+                # fraction of what that clock allows: frac mixes kernel quality with the box's power state, frac_at_clock does not
+                clock_mhz=round(dom["mhz"], 0) if dom.get("mhz") else None, frac_at_clock=at_clock(achieved / PEAK_F32_MFMA_TFLOPS, dom.get("mhz")),
                 launch_ms=round(per_launch_ms, 4), launches_per_step=dom["launches"],
-                step_frac=round(value_per_gpu * mflop_per_window * 1e6 / (PEAK_F32_MFMA_TFLOPS * 1e12), 4),
+                step_frac=round(step_frac, 4),
+                clock_mhz_timed_region=round(region_mhz, 0) if region_mhz else None, step_frac_at_clock=at_clock(step_frac, region_mhz),
                 by_class=by_class, timed_kernel_ms_per_step=round(sum(d["ms"] for d in agg.values()), 3),
                 mfma_kernel_ms_per_step=round(mfma_ms, 3), non_mfma_ms_per_step=round(ms_per_step - mfma_ms, 3),
                 note="per-kernel times: 3 separate steps with the side-stream overlaps off (serial); ms_per_step: timed region with them on, "
@@ -233,14 +277,14 @@ def _cpu_subprocess(fn_call, threads, timeout):
     raise RuntimeError(r.stderr[-500:])
 
 
-def cpu_baseline():
+def cpu_baseline(sample_steps=32):
     """Reference-equivalent torch-CPU train step (oracle/torch_ref.py) on this box's host cores, in a
     subprocess with a hard time limit (a bounded sample: 32 steps of B=256, about 10 s of CPU work, at the better of two
     thread counts; the other count is only probed with 4 steps)."""
     import subprocess
     avail = len(os.sched_getaffinity(0))
     best, tried = None, []
-    for threads, steps in ((min(avail, 16), 32), (min(avail, 64), 4)):   # torch-CPU GRUs stop scaling early: report the better count
+    for threads, steps in ((min(avail, 16), sample_steps), (min(avail, 64), min(4, sample_steps))):   # torch-CPU GRUs stop scaling early: report the better count
         if any(t == threads for t, _ in tried):
             continue
         try:
@@ -297,15 +341,24 @@ class _SynthDataset:
         return synth_series(N_SERIES)
 
 
-def timed_region(step, steps, world, sync, dev):
-    """EXACTLY `steps` steps bracketed by barrier + device sync on both sides; the MAX over ranks."""
+def timed_region(step, steps, world, sync, dev, info=None):
+    """EXACTLY `steps` steps bracketed by barrier + device sync on both sides; the MAX over ranks.  `info` (dict) receives the
+    average shader clock over the region on this rank (`mhz`, GPU only: vame_clock_stamp right behind the opening sync and in
+    front of the closing one) and, with several ranks, every rank's own time before the closing barrier (`rank_dts`)."""
+    from vame_amd import ops
+    probe = ops.ClockProbe(dev) if dev.type == "cuda" else None
     if world > 1:
         dist.barrier()
     sync()
     t0 = time.perf_counter()
+    if probe is not None:
+        probe.start()
     for _ in range(steps):
         terms = step()
+    if probe is not None:
+        probe.stop()
     sync()
+    own = time.perf_counter() - t0
     if world > 1:
         dist.barrier()
     dt = time.perf_counter() - t0
@@ -313,6 +366,12 @@ def timed_region(step, steps, world, sync, dev):
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
+        each = [torch.zeros(1, device=dev, dtype=torch.float64) for _ in range(world)]
+        dist.all_gather(each, torch.tensor([own], device=dev, dtype=torch.float64))
+        if info is not None:
+            info["rank_dts"] = [float(e.item()) for e in each]
+    if info is not None:
+        info["mhz"] = probe.mhz() if probe is not None else None
     return dt, terms
 
 
@@ -339,18 +398,21 @@ def train_leg(dev, H, T, B, steps, warmup, rank, world, repeats=1, profile=True,
 
     for _ in range(warmup):
         terms = step()
-    dts = []
+    dts, infos = [], []
     for _ in range(repeats):
-        dt, terms = timed_region(step, steps, world, sync, dev)
+        info = {}
+        dt, terms = timed_region(step, steps, world, sync, dev, info)
         dts.append(dt)
+        infos.append(info)
     last = [float(v) for v in terms.cpu()]
     assert all(np.isfinite(last)), f"non-finite loss terms {last}"
-    res = dict(dts=dts, last=last, mflop=train_mflop_per_window(H, T), roofline=None, distributed=None)
+    res = dict(dts=dts, last=last, mflop=train_mflop_per_window(H, T), roofline=None, distributed=None, mhz=infos[0].get("mhz"),
+               rank_dts=infos[0].get("rank_dts"))
     if world > 1:
         res["distributed"] = collective_block(model, step, steps, rank, world, sync, dev, dts[0], one_rank_leg)
     if profile and on_gpu and rank == 0:
         agg = profile_kernels(model, loader, B)
-        res["roofline"] = roofline_block(agg, B * steps / dts[0], res["mflop"], dts[0] / steps * 1e3, dump)
+        res["roofline"] = roofline_block(agg, B * steps / dts[0], res["mflop"], dts[0] / steps * 1e3, dump, region_mhz=res["mhz"])
     del model, opt, loader
     if on_gpu:
         torch.cuda.empty_cache()
@@ -414,8 +476,14 @@ def embed_leg(dev, n_win_per_rank, rank, world, H=256, T=30):
     if dev.type == "cuda":
         torch.cuda.synchronize()
     t0 = time.perf_counter()
+    probe = None
+    if dev.type == "cuda":
+        from vame_amd import ops
+        probe = ops.ClockProbe(dev)
+        probe.start()
     out, (lo, hi) = embed_series(model, data, batch=16384, rank=rank, world=world)
     if dev.type == "cuda":
+        probe.stop()
         torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -430,6 +498,7 @@ def embed_leg(dev, n_win_per_rank, rank, world, H=256, T=30):
     mflop = (2 * T * 2 * 3 * H * (F + H) + 2 * T * 2 * 3 * H * (2 * H + H) + 2 * 2 * 4 * H * Z) / 1e6
     assert (H, T) != (256, 30) or abs(mflop - MFLOP_PER_WINDOW_EMBED) < 1e-3
     tf = value / world * mflop * 1e6 / 1e12
+    mhz = probe.mhz() if probe is not None else None
     del model, out
     if dev.type == "cuda":
         torch.cuda.empty_cache()
@@ -439,7 +508,8 @@ def embed_leg(dev, n_win_per_rank, rank, world, H=256, T=30):
                 config=dict(workload=f"BASELINE.json configs[4] shape: {n_win_per_rank} stride-1 windows per GPU, batch 16384",
                             parallelism=f"shard{world}"),
                 roofline=dict(bound="mfma", unit="TFLOP/s", peak=PEAK_F32_MFMA_TFLOPS, achieved=round(tf, 2),
-                              frac=round(tf / PEAK_F32_MFMA_TFLOPS, 4),
+                              frac=round(tf / PEAK_F32_MFMA_TFLOPS, 4), clock_mhz=round(mhz, 0) if mhz else None,
+                              frac_at_clock=at_clock(tf / PEAK_F32_MFMA_TFLOPS, mhz),
                               traffic=pmc_traffic("gru_seq_fwd_kernel<256> x2 streams embed") if dev.type == "cuda" else None))
 
 
@@ -450,6 +520,8 @@ def workload_name(H, T, B, world):
         head = "BASELINE.json configs[1]"
     elif (H, T, B) == (512, 60, 8192):
         head = "BASELINE.json configs[3]"
+    elif (H, T, B) == (256, 30, 256):
+        head = "BASELINE.json configs[0] shape on the GPU (the reference's stock config.yaml batch, vame/initialize_project/new.py:111)"
     else:
         head = "non-headline shape (BASELINE.json configs[3] is H=512,T=60,batch 8192)"
     return head + f": T={T},F={F},zdims={Z},hidden={H},FS={FS}, batch={B}/GPU fp32 train step (gather+fwd+loss+bwd+allreduce+Adam-amsgrad)"
@@ -461,6 +533,9 @@ def main():
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-steps", type=int, default=None,
+                    help="train steps (B=256) of the CPU baseline sample; default 32 on a GPU box.  Naming it also runs the baseline "
+                         "where nothing else is measured (the CPU test-suite's emulator harness)")
     ap.add_argument("--no-also", action="store_true", help="skip the configs[3] / configs[4] legs and the two extra timed regions")
     ap.add_argument("--batch", type=int, default=4096)
     ap.add_argument("--dump-kernels", action="store_true", help="per-launch-group table on stderr")
@@ -505,12 +580,18 @@ def main():
                         dump=args.dump_kernels, one_rank_leg=True)
         also = None
         if extras and world == 1 and on_gpu:
-            # the other two single-GPU configurations of BASELINE.json under the same clock, each with its own roofline
+            # the other two single-GPU configurations of BASELINE.json under the same clock, each with its own roofline, and the batch
+            # the reference's stock config.yaml trains at (256: vame/initialize_project/new.py:111 -- the configuration real users run)
             c4 = train_leg(dev, 512, 60, 8192, 5, 2, 0, 1)
             c4_line = dict(metric="temporal windows/sec (train) T=60,F=24,h=512", value=round(8192 * 5 / c4["dts"][0], 1), unit="windows/s",
                            steps=5, warmup=2, ms_per_step=round(c4["dts"][0] / 5 * 1e3, 3), config=dict(workload=workload_name(512, 60, 8192, 1)),
                            roofline=c4["roofline"])
-            also = dict(configs3_h512_t60_b8192=c4_line, configs4_embed_1gpu=embed_leg(dev, 2_000_000, 0, 1))
+            b256 = train_leg(dev, 256, 30, 256, 30, 10, 0, 1)
+            b256_line = dict(metric="temporal windows/sec (train) T=30,F=24,h=256", value=round(256 * 30 / b256["dts"][0], 1), unit="windows/s",
+                             steps=30, warmup=10, ms_per_step=round(b256["dts"][0] / 30 * 1e3, 3),
+                             config=dict(workload=workload_name(256, 30, 256, 1)), roofline=b256["roofline"])
+            also = dict(configs3_h512_t60_b8192=c4_line, configs4_embed_1gpu=embed_leg(dev, 2_000_000, 0, 1), batch256=b256_line)
+        out = None
         if rank == 0:
             dt = res["dts"][0]
             value = B * world * args.steps / dt
@@ -520,6 +601,9 @@ def main():
                        config=dict(workload=workload_name(H, T, B, world), global_batch=B * world, parallelism=f"dp{world}",
                                    last_loss_terms=res["last"]),
                        roofline=res["roofline"])
+            if res["rank_dts"] is not None:          # every rank's own time for the same region (before the closing barrier): `value` uses the MAX
+                per = [d / args.steps * 1e3 for d in res["rank_dts"]]
+                out["ms_per_step_by_rank"] = dict(min=round(min(per), 3), max=round(max(per), 3), ranks=[round(v, 3) for v in per])
             if len(res["dts"]) > 1:                  # `value` is the first region; the other two only show the spread
                 vals = sorted(B * world * args.steps / d for d in res["dts"])
                 out["repeat_spread"] = dict(regions=len(vals), steps_each=args.steps, min=round(vals[0], 1), median=round(vals[len(vals) // 2], 1),
@@ -528,9 +612,14 @@ def main():
                 out["distributed"] = res["distributed"]
             if also is not None:
                 out["also"] = also
-            if not args.no_cpu_baseline and world == 1 and on_gpu:
-                out["cpu_baseline"] = cpu_baseline()
+        if world > 1:                                # the ranks part here: the CPU baseline below is rank 0's alone, nobody waits in a collective for it
+            dist.barrier()
+            dist.destroy_process_group()
+        if rank == 0:
+            if not args.no_cpu_baseline and (on_gpu or args.cpu_baseline_steps is not None):
+                out["cpu_baseline"] = cpu_baseline(args.cpu_baseline_steps or 32)     # rank 0's host cores, N = 1 and N > 1 alike
             print(json.dumps(out))
+        return
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

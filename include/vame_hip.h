@@ -27,6 +27,11 @@ int vame_version(void);
  * binds committed rocprofv3 counter summaries to a build (profiles/, bench.py roofline.traffic). */
 const char* vame_source_id(void);
 const char* vame_last_error(void);
+/* Measurement aid (bench.py): nblocks workgroups each write {s_memtime (shader-clock ticks), s_memrealtime (100 MHz ticks), XCC id,
+ * HW_ID} to out[4 * block].  Two launches around a region give the average shader clock over it per XCD:
+ * (d memtime / d realtime) x 100 MHz -- the box's sustained clock under the measured kernels, reported next to every roofline
+ * fraction (`clock_mhz`, `frac_at_clock`). */
+int vame_clock_stamp(int64_t* out, int nblocks, void* stream);
 
 /* Sliding-window batcher: out[b,l,f] = X[f*N + start_b + l]  (B,L,F).
  * Replaces SEQUENCE_DATASET.__getitem__ + default collate + permute(0,2,1)
@@ -87,9 +92,19 @@ enum vame_gru_fwd_field {
     GF_T, GF_REVERSE, GF_PAD,
     GF_WPX, GF_BGI, GF_XF,                  /* fused input projection: packed W_ih (vame_gru_pack_x_f32), bias_gi (3H), F (0 = off);
                                                GF_GI/_ROW/_T then describe x (B,T,F) instead of gi */
-    GF_RESERVED,
+    GF_OPT,                                 /* launch options, read from stream 0 only (see VAME_GRU_OPT_*; 0 = defaults) */
     VAME_GRU_FWD_FIELDS
 };
+/* Launch options of the GRU sequence kernels: a bit field in GF_OPT / GB_OPT of stream 0.  Kernel selection and tuning are
+ * ARGUMENTS of a call -- the library reads no process-global state (no environment variables) outside its tuning builds, so two
+ * callers in one process cannot influence each other.
+ *   bits 0..3   kernel: VAME_GRU_KERNEL_AUTO (the measured default per hidden size), _LOCKSTEP (all waves of a workgroup do the
+ *               same thing per phase), _WS (wave-specialised: MFMA waves + memory waves; refused where not instantiated)
+ *   bits 8..15  pace_cp + 1, bits 16..23  pace_ld + 1: pacing of the wave-specialised kernels' memory waves in units of 256
+ *               cycles per request group (0 = the measured default for the hidden size) */
+enum vame_gru_kernel { VAME_GRU_KERNEL_AUTO = 0, VAME_GRU_KERNEL_LOCKSTEP = 1, VAME_GRU_KERNEL_WS = 2 };
+#define VAME_GRU_OPT(kernel, pace_cp, pace_ld) \
+    ((int64_t)(kernel) | ((int64_t)((pace_cp) < 0 ? 0 : (pace_cp) + 1) << 8) | ((int64_t)((pace_ld) < 0 ? 0 : (pace_ld) + 1) << 16))
 int64_t vame_gru_stash_floats(int B, int T, int H);
 /* W_ih (3H,F), F <= 32 -> wpx (3H*32): zero-padded K = 32 input projection in MFMA B-fragment order (encoder layer 0:
  * the projection x_t W_ih^T is then computed inside the sequence kernel instead of by vame_gemm_f32). */
@@ -107,11 +122,13 @@ enum vame_gru_bwd_field {
     GB_DG,                                  /* out (B,T,4H) contiguous */
     GB_DH0, GB_DH0_ROW,                     /* out grad wrt initial state (0 = none) */
     GB_DBIAS,                               /* out (ntiles,4H) per-tile column sums of dG over rows and time */
-    GB_RESERVED,
+    GB_OPT,                                 /* launch options, read from stream 0 only (VAME_GRU_OPT(...); 0 = defaults) */
     GB_T, GB_REVERSE, GB_PAD,
     VAME_GRU_BWD_FIELDS
 };
 int vame_gru_seq_bwd_f32(const int64_t* desc, int nstreams, int B, int H, void* stream);
+/* 1 if vame_gru_seq_bwd_f32 has `kernel` (enum vame_gru_kernel) for hidden size H; asking for one it has not is VAME_E_UNSUPPORTED */
+int vame_gru_seq_bwd_has_kernel(int H, int kernel);
 
 /* Per-step GRU cell for hidden sizes beyond the persistent sequence kernels (H > 256, BASELINE config 4): the gate GEMM
  * gh = h_{t-1} W_hh^T is a vame_gemm_f32 call (a real dense contraction at batch x hidden = 8192 x 512) and these

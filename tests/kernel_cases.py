@@ -1,5 +1,6 @@
 """Shared kernel test bodies: run on `cpu` tensors through the emulator or on `cuda` through libvame_hip.so."""
 import numpy as np
+import pytest
 import torch
 
 from oracle import vame_oracle as vo
@@ -153,7 +154,7 @@ def _pack(dev, W_hh, b_ih, b_hh, H):
 FORCE_WIDE = False           # set by check_gru_wide_small: the two-blocks-per-wave kernels at H <= 256
 
 
-def run_gru_fwd(dev, H, B, T, seed=0, coop=None, coop_chunks=None):
+def run_gru_fwd(dev, H, B, T, seed=0, coop=None, coop_chunks=None, want_rows=False):
     """Two streams (forward + reverse dir, with h0) in one launch; returns everything needed for bwd.
     coop: an ops.CoopState -> the column-split small-batch kernel instead of the batch-tile-persistent one."""
     rng = np.random.default_rng(seed)
@@ -176,14 +177,53 @@ def run_gru_fwd(dev, H, B, T, seed=0, coop=None, coop_chunks=None):
                      GF["HN"]: ops.addr(hN, d * H), GF["HN_ROW"]: 2 * H, GF["STASH"]: ops.addr(stash), GF["T"]: T,
                      GF["REVERSE"]: d, GF["PAD"]: 1})
         st.append(dict(W_ih=W_ih, W_hh=W_hh, b_ih=b_ih, b_hh=b_hh, h0=h0, wpb=wpb, stash=stash, keep=(gi, wpf, bhn, h0t)))
+    launch_gru_fwd(rows, B, H, coop, coop_chunks)
+    if want_rows:
+        return x, st, Y, hN, rows
+    return x, st, Y, hN
+
+
+FWD_KERNEL = ops.KERNEL_AUTO      # kernel argument of launch_gru_fwd's gru_seq_fwd launches (GF_OPT descriptor field)
+
+
+def launch_gru_fwd(rows, B, H, coop=None, coop_chunks=None):
     if coop is not None:
         for chunk in (coop_chunks or [(0, 0)]):
             ops.gru_coop_fwd(rows, B, H, coop, rows=chunk)
     elif H > 256 or FORCE_WIDE:
         ops.gru_wide_fwd(rows, B, H)
     else:
-        ops.gru_seq_fwd(rows, B, H)
-    return x, st, Y, hN
+        ops.gru_seq_fwd(rows, B, H, kernel=FWD_KERNEL)
+
+
+def check_gru_fwd_ring_stress(dev, H, B, T, launches=200):
+    """Repeat / stress guard of the forward kernels' weight ring (inline-asm loads with hand-counted vmcnt waits: exactly what the host
+    emulator cannot see, and a memory-ordering slip there shows only under load): the SAME launch `launches` times while a side
+    stream streams HBM at full rate, outputs compared bit for bit -- h sequence + final state after EVERY launch, the BPTT stash
+    every tenth -- against the first launch, which is itself checked against the oracle by check_gru_fwd at a small batch."""
+    x, st, Y, hN, rows = run_gru_fwd(dev, H, B, T, want_rows=True)
+    torch.cuda.synchronize()
+    Y0, hN0, st0 = Y.clone(), hN.clone(), [s["stash"].clone() for s in st]
+    side = torch.cuda.Stream()
+    big = [torch.empty(1 << 28, device=dev) for _ in range(2)]             # 2 x 1 GiB, copied back and forth beside the launches
+    stop = torch.cuda.Event()
+    with torch.cuda.stream(side):
+        for i in range(launches):
+            big[(i + 1) & 1].copy_(big[i & 1])
+        stop.record()
+    bad = torch.zeros(3, dtype=torch.int64, device=dev)
+    for it in range(launches):
+        Y.zero_()
+        launch_gru_fwd(rows, B, H)
+        bad[0] += (Y != Y0).any()
+        bad[1] += (hN != hN0).any()
+        if it % 10 == 9:
+            for s, s0 in zip(st, st0):
+                bad[2] += (s["stash"] != s0).any()
+    overlapped = not stop.query()                 # the background copies were still running when the last launch was enqueued
+    torch.cuda.synchronize()
+    assert bad.tolist() == [0, 0, 0], f"launch-to-launch differences (Y, hN, stash): {bad.tolist()}"
+    return overlapped
 
 
 def check_gru_coop_fwd(dev, H, B, T, launches=2):
@@ -309,7 +349,7 @@ def _run_gru_bwd(dev, H, B, T, st, Y, dYt, dhNt, coop=None, coop_chunks=None):
     elif H > 256 or FORCE_WIDE:
         ops.gru_wide_bwd(rows, B, H)
     else:
-        ops.gru_seq_bwd(rows, B, H)
+        ops.gru_seq_bwd(rows, B, H, kernel=BWD_KERNEL)
     return outs
 
 
@@ -332,24 +372,27 @@ def check_gru_coop_bwd(dev, H, B, T, launches=2):
     assert int(state.status.item()) == 0
 
 
+BWD_KERNEL = ops.KERNEL_AUTO      # kernel argument of _run_gru_bwd's gru_seq_bwd launches (ops.KERNEL_*: a descriptor field, not process state)
+
+
 def check_gru_ws_bwd(dev, H, B, T):
     """The wave-specialised BPTT kernel (gru_seq.hip: gru_ws_bwd_kernel; MFMA waves / memory waves) against the numpy oracle AND
     bit for bit against the lock-step kernel it replaces at H = 256 (same stash, same arithmetic order): dG, dh0; bias partials to rounding.
-    VAME_GRU_WS picks the kernel per launch (2 = wave-specialised wherever it is instantiated, 0 = lock-step)."""
-    import os
-    prev = os.environ.get("VAME_GRU_WS")
+    The kernel is picked per launch by the GB_OPT descriptor field (ops.gru_seq_bwd(kernel=...))."""
+    global BWD_KERNEL
+    assert ops.gru_seq_bwd_has_kernel(H, ops.KERNEL_WS)
     try:
-        os.environ["VAME_GRU_WS"] = "2"
+        BWD_KERNEL = ops.KERNEL_WS
         check_gru_bwd(dev, H, B, T)
         x, st, Y, hN = run_gru_fwd(dev, H, B, T, seed=1)
         rng = np.random.default_rng(5)
         dYt = T_(rng.standard_normal((B, T, 2 * H)).astype(np.float32), dev)
         dhNt = T_(rng.standard_normal((B, 2 * H)).astype(np.float32), dev)
         ws = _run_gru_bwd(dev, H, B, T, st, Y, dYt, dhNt)
-        os.environ["VAME_GRU_WS"] = "0"
+        BWD_KERNEL = ops.KERNEL_LOCKSTEP
         ls = _run_gru_bwd(dev, H, B, T, st, Y, dYt, dhNt)
         if dev != "cpu":                        # hand-off races between the two roles would show as launch-to-launch differences
-            os.environ["VAME_GRU_WS"] = "2"
+            BWD_KERNEL = ops.KERNEL_WS
             for _ in range(10):
                 again = _run_gru_bwd(dev, H, B, T, st, Y, dYt, dhNt)
                 assert all(torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2]) for a, b in zip(again, ws))
@@ -358,10 +401,28 @@ def check_gru_ws_bwd(dev, H, B, T):
             # bias partials: the same 16 x T terms per lane, summed pairwise (packed fp32 adds) instead of one by one
             np.testing.assert_allclose(N_(dbias), N_(dbias2), rtol=2e-5, atol=2e-5 * float(np.abs(N_(dbias2)).max()))
     finally:
-        if prev is None:
-            os.environ.pop("VAME_GRU_WS", None)
-        else:
-            os.environ["VAME_GRU_WS"] = prev
+        BWD_KERNEL = ops.KERNEL_AUTO
+
+
+def check_gru_kernel_option_is_an_argument(dev):
+    """The kernel choice is a field of the descriptor (GB_OPT), validated per call: an unknown value is refused, the wave-specialised
+    kernel is refused for a hidden size it is not instantiated for, and the library reads no environment variable for it."""
+    from vame_amd import _lib
+    H, B, T = 64, 32, 2
+    x, st, Y, hN = run_gru_fwd(dev, H, B, T, seed=1)
+    dYt, dhNt = torch.zeros(B, T, 2 * H, device=dev), torch.zeros(B, 2 * H, device=dev)
+    global BWD_KERNEL
+    try:
+        assert not ops.gru_seq_bwd_has_kernel(H, ops.KERNEL_WS) and ops.gru_seq_bwd_has_kernel(H, ops.KERNEL_LOCKSTEP)
+        assert ops.gru_seq_bwd_has_kernel(256, ops.KERNEL_WS) and not ops.gru_seq_bwd_has_kernel(512, ops.KERNEL_AUTO)
+        BWD_KERNEL = ops.KERNEL_WS
+        with pytest.raises(_lib.VameHipError, match="not instantiated"):
+            _run_gru_bwd(dev, H, B, T, st, Y, dYt, dhNt)
+        BWD_KERNEL = 7
+        with pytest.raises(_lib.VameHipError, match="unknown kernel option"):
+            _run_gru_bwd(dev, H, B, T, st, Y, dYt, dhNt)
+    finally:
+        BWD_KERNEL = ops.KERNEL_AUTO
 
 
 def check_gru_bwd(dev, H, B, T):

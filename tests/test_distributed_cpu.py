@@ -170,13 +170,18 @@ def _bench_line(cmd):
 def _check_two_rank_line(out):
     assert out["n_gpus"] == 2 and out["steps"] == 2 and out["warmup"] == 1 and out["value"] > 0
     assert all(np.isfinite(out["config"]["last_loss_terms"]))
-    assert out["roofline"] is None and "cpu_baseline" not in out           # nothing measured off the GPU
+    assert out["roofline"] is None                                          # nothing measured off the GPU
+    # an N-rank line is complete: rank 0's CPU baseline rides on it and every rank's own time is listed next to the MAX
+    cb = out["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["value"] > 0 and cb["cores"] >= 1 and "train steps of B=256" in cb["sample"]
+    pr = out["ms_per_step_by_rank"]
+    assert len(pr["ranks"]) == 2 and 0 < pr["min"] <= pr["max"] <= out["ms_per_step"] * 1.001
     d = out["distributed"]                                                   # proof that two ranks went through the collective
     assert d["world_size"] == 2 and d["backend"] == "gloo" and d["allreduce_us"] > 0 and d["allreduce_bucket_bytes"] > 0
     assert 0 < d["weak_scaling_eff"] and d["one_rank_leg_ms_per_step"] > 0
 
 
-BENCH_TINY = ["--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "8", "--hidden", "32", "--time-window", "4"]
+BENCH_TINY = ["--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "8", "--hidden", "32", "--time-window", "4", "--cpu-baseline-steps", "1"]
 
 
 def test_bench_script_under_torchrun_two_ranks(emu):

@@ -326,31 +326,25 @@ def test_round3_fast_path_matches_the_previous_path_over_an_adam_trajectory(hip)
     (lock-step BPTT kernel, everything on one stream) over ten optimizer steps at batch 2048, H = 256, same windows and eps:
     the final weights agree to 1e-5 of each tensor's scale (the two paths differ only in the summation order of the bias partials
     and in the eigen-solver's warm-start history)."""
-    import os
+    from vame_amd import ops
     from vame_amd.model.rnn_vae import FusedAdamAMSGrad
     T, F, Z, H, FS, B = 30, 24, 30, 256, 15, 2048
     gen = torch.Generator().manual_seed(5)
     wins = [torch.randn(B, T + FS, F, generator=gen).cuda() for _ in range(10)]
     epss = [torch.randn(B, Z, generator=gen).cuda() for _ in range(10)]
     finals = []
-    prev_env = os.environ.get("VAME_GRU_WS")
-    try:
-        for fast in (True, False):
-            os.environ["VAME_GRU_WS"] = "1" if fast else "0"
-            torch.manual_seed(19)
-            model = RNN_VAE(2 * T, Z, F, 1, FS, H, H, H, H, 0, 0, 0, False).cuda().train()
-            model._ensure_engine().set_overlap(fast)
-            opt = FusedAdamAMSGrad(model, lr=5e-4)
-            for w_, e_ in zip(wins, epss):
-                model.loss_step(w_, 1.0, beta=1.0, kloss=Z, klmbda=0.1, bsize=B, eps=e_)
-                opt.step()
-            torch.cuda.synchronize()
-            finals.append({k: v.detach().cpu().numpy().copy() for k, v in model.state_dict().items()})
-    finally:
-        if prev_env is None:
-            os.environ.pop("VAME_GRU_WS", None)
-        else:
-            os.environ["VAME_GRU_WS"] = prev_env
+    for fast in (True, False):
+        torch.manual_seed(19)
+        model = RNN_VAE(2 * T, Z, F, 1, FS, H, H, H, H, 0, 0, 0, False).cuda().train()
+        eng = model._ensure_engine()
+        eng.set_overlap(fast)
+        eng.gru_bwd_kernel = ops.KERNEL_AUTO if fast else ops.KERNEL_LOCKSTEP      # a launch argument (GB_OPT), not process state
+        opt = FusedAdamAMSGrad(model, lr=5e-4)
+        for w_, e_ in zip(wins, epss):
+            model.loss_step(w_, 1.0, beta=1.0, kloss=Z, klmbda=0.1, bsize=B, eps=e_)
+            opt.step()
+        torch.cuda.synchronize()
+        finals.append({k: v.detach().cpu().numpy().copy() for k, v in model.state_dict().items()})
     for k in finals[0]:
         a, b = finals[0][k], finals[1][k]
         assert np.abs(a - b).max() <= 1e-5 * np.abs(b).max(), (k, float(np.abs(a - b).max()), float(np.abs(b).max()))

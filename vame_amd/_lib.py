@@ -20,6 +20,7 @@ _SIGS = {
     "vame_source_id": (c_char_p, []),
     "vame_version": (c_int, []),
     "vame_last_error": (c_char_p, []),
+    "vame_clock_stamp": (c_int, [c_void_p, c_int, c_void_p]),
     "vame_window_gather_f32": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p]),
     "vame_gemm_f32": (c_int, [c_int, c_int, c_int, c_void_p, c_int64, c_int, c_int64, c_int64, c_void_p, c_int64, c_int,
                               c_int64, c_int64, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p, c_int, c_int, c_void_p]),
@@ -31,6 +32,7 @@ _SIGS = {
     "vame_gru_stash_floats": (c_int64, [c_int, c_int, c_int]),
     "vame_gru_seq_fwd_f32": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p]),
     "vame_gru_seq_bwd_f32": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p]),
+    "vame_gru_seq_bwd_has_kernel": (c_int, [c_int, c_int]),
     "vame_gru_cell_fwd_f32": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64,
                                       c_int, c_int, c_void_p]),
     "vame_gru_cell_bwd_f32": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int, c_int,

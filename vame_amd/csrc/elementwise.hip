@@ -17,6 +17,31 @@ extern "C" int vame_version(void) { return 100; }
 #endif
 extern "C" const char* vame_source_id(void) { return VAME_SRC_ID; }
 
+// ---- clock stamps (measurement only; bench.py): the shader clock moves with the power budget (2.0-2.3 GHz under the MFMA kernels of
+// this path, 2.4 GHz nominal), so a fraction of the nominal peak mixes kernel quality with the box.  One launch of this kernel before
+// and one after a region give (s_memtime = shader-clock counter, s_memrealtime = constant 100 MHz counter) pairs per XCD; the ratio of
+// the two differences x 100 MHz is the average shader clock over the region.
+__global__ __launch_bounds__(64) void clock_stamp_kernel(long long* __restrict__ out) {
+#ifdef VAME_EMU
+    if (threadIdx.x == 0) { out[blockIdx.x * 4 + 0] = 0; out[blockIdx.x * 4 + 1] = 0; out[blockIdx.x * 4 + 2] = blockIdx.x & 7; out[blockIdx.x * 4 + 3] = 0; }
+#else
+    const long long t = (long long)__builtin_amdgcn_s_memtime(), r = (long long)__builtin_amdgcn_s_memrealtime();
+    unsigned xcc, hwid;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+    if (threadIdx.x == 0) {
+        long long* o = out + (long long)blockIdx.x * 4;
+        o[0] = t; o[1] = r; o[2] = (long long)(xcc & 15u); o[3] = (long long)hwid;
+    }
+#endif
+}
+extern "C" int vame_clock_stamp(int64_t* out, int nblocks, void* stream) {
+    VAME_CHECK_ARG(out && nblocks >= 1 && nblocks <= 1024, VAME_E_BADARG, "clock_stamp: out null or nblocks=%d not in 1..1024", nblocks);
+    hipLaunchKernelGGL(clock_stamp_kernel, dim3(nblocks), dim3(64), 0, (hipStream_t)stream, reinterpret_cast<long long*>(out));
+    VAME_LAUNCH_CHECK("clock_stamp");
+    return VAME_OK;
+}
+
 static inline int ew_blocks(int64_t n, int per_block = 256) {
     int64_t b = cdiv64(n, per_block);
     return (int)(b < 1 ? 1 : (b > 2048 ? 2048 : b));   // <= 256 CUs x 8 blocks, grid-stride the rest

@@ -13,7 +13,7 @@ struct GruFwdStream {
     int64_t T, reverse, pad;
     const float* wpx; const float* bgi; int64_t xf;      // fused input projection (xf = features, 0 = gi is precomputed)
 };
-struct GruFwdParams { GruFwdStream s[8]; int nstreams; int B; int ntiles; int tile_off = 0; };   // tile_off: first 32-row tile of this launch (gru_coop)
+struct GruFwdParams { GruFwdStream s[8]; int nstreams; int B; int ntiles; int tile_off = 0; int kernel = 0, pace_cp = -1, pace_ld = -1; };   // tile_off: first 32-row tile of this launch (gru_coop)
 
 struct GruBwdStream {
     const float* stash; const float* y; int64_t y_row, y_t;
@@ -26,7 +26,7 @@ struct GruBwdStream {
     float* dbias;
     int64_t T, reverse, pad;
 };
-struct GruBwdParams { GruBwdStream s[8]; int nstreams; int B; int ntiles; int tile_off = 0; int pace_cp = 0, pace_ld = 0; };   // pace_*: see gru_ws_bwd_kernel
+struct GruBwdParams { GruBwdStream s[8]; int nstreams; int B; int ntiles; int tile_off = 0; int kernel = 0, pace_cp = -1, pace_ld = -1; };   // pace_*: see gru_ws_bwd_kernel
 
 // In the 32x32 accumulator layout register r of lane l holds row CR(r) + 4*(l>>5), column l&31.
 #define CR(r) (((r) & 3) + 8 * ((r) >> 2))
@@ -38,8 +38,17 @@ struct GruBwdParams { GruBwdStream s[8]; int nstreams; int B; int ntiles; int ti
 #endif
 
 
+// GF_OPT / GB_OPT of stream 0 (include/vame_hip.h, VAME_GRU_OPT): kernel choice and pacing are arguments, not process state
+static inline void gru_parse_opt(int64_t opt, int& kernel, int& pace_cp, int& pace_ld) {
+    kernel = (int)(opt & 15);
+    pace_cp = (int)((opt >> 8) & 255) - 1;          // -1 = default
+    pace_ld = (int)((opt >> 16) & 255) - 1;
+}
+
 static inline int gru_parse_fwd(const int64_t* desc, int nstreams, int B, GruFwdParams& P) {
     P.nstreams = nstreams; P.B = B; P.ntiles = (int)cdiv64(B, 32);
+    gru_parse_opt(desc[GF_OPT], P.kernel, P.pace_cp, P.pace_ld);
+    VAME_CHECK_ARG(P.kernel <= VAME_GRU_KERNEL_WS, VAME_E_BADARG, "gru_seq_fwd: unknown kernel option %d", P.kernel);
     for (int i = 0; i < nstreams; ++i) {
         const int64_t* d = desc + (int64_t)i * VAME_GRU_FWD_FIELDS;
         GruFwdStream& s = P.s[i];
@@ -63,6 +72,8 @@ static inline int gru_parse_fwd(const int64_t* desc, int nstreams, int B, GruFwd
 
 static inline int gru_parse_bwd(const int64_t* desc, int nstreams, int B, GruBwdParams& P) {
     P.nstreams = nstreams; P.B = B; P.ntiles = (int)cdiv64(B, 32);
+    gru_parse_opt(desc[GB_OPT], P.kernel, P.pace_cp, P.pace_ld);
+    VAME_CHECK_ARG(P.kernel <= VAME_GRU_KERNEL_WS, VAME_E_BADARG, "gru_seq_bwd: unknown kernel option %d", P.kernel);
     for (int i = 0; i < nstreams; ++i) {
         const int64_t* d = desc + (int64_t)i * VAME_GRU_BWD_FIELDS;
         GruBwdStream& s = P.s[i];

@@ -905,18 +905,27 @@ __global__ __launch_bounds__(H / 32 * 64) void gru_ws_bwd_kernel(GruBwdParams P)
 }
 
 // ------------------------------------------------------------------------------------------- host
+#if !defined(VAME_EMU) && (defined(VAME_GEMM_AB) || defined(VAME_PROBE))
+// TUNING BUILDS ONLY (make ab / make probe; never the shipped library): ablation masks and kernel / pacing overrides from the environment,
+// so that tools/ws_probe.py, ws_abl.py can sweep them under an unchanged Python layer
 #include <stdlib.h>
 [[maybe_unused]] static int abl_env(const char* name) { const char* e = getenv(name); return e ? atoi(e) : 0; }
+static void tuning_overrides(GruBwdParams& Q) {
+    if (const char* e = getenv("VAME_GRU_WS")) Q.kernel = atoi(e) == 0 ? VAME_GRU_KERNEL_LOCKSTEP : atoi(e) >= 2 ? VAME_GRU_KERNEL_WS : VAME_GRU_KERNEL_AUTO;
+    if (const char* e = getenv("VAME_WS_PACE_CP")) Q.pace_cp = atoi(e);
+    if (const char* e = getenv("VAME_WS_PACE_LD")) Q.pace_ld = atoi(e);
+}
+#define GRU_TUNING_OVERRIDES(Q) tuning_overrides(Q)
+#else
+#define GRU_TUNING_OVERRIDES(Q)
+#endif
 #define ABL_CASE(K, H, A, P, st) case A: hipLaunchKernelGGL((K<H, A>), dim3(grid_blocks(P.nstreams, P.ntiles)), dim3(H / 32 * 64), 0, st, P); return;
 
-// VAME_GRU_WS: 0 = lock-step BPTT kernel everywhere; unset / 1 = wave-specialised kernel at H = 256 (measured: 102 -> 114 TF at batch
-// 4096, faster down to batch 100); 2 = also at H = 128, where a step's contraction is four times shorter and the serial coefficient
-// phase weighs more (measured slower at small batches; kept for the tests)
-static bool gru_ws_enabled(int H) {
-    const char* e = getenv("VAME_GRU_WS");
-    const int v = e ? atoi(e) : 1;
-    return v >= 2 ? true : (v == 1 && H == 256);
-}
+// Kernel choice for BPTT (GB_OPT of stream 0, include/vame_hip.h): AUTO = the wave-specialised kernel at H = 256 (measured: 102 -> 120 TF
+// at batch 4096, faster down to batch 100) and the lock-step kernel elsewhere (at H = 128 a step's contraction is four times shorter and
+// the serial coefficient phase weighs more: measured slower, instantiated for the tests and for callers that ask for it).
+template <int H> static constexpr bool gru_ws_instantiated() { return H == 256 || H == 128; }
+static bool gru_ws_auto(int H) { return H == 256; }
 
 template <int H>
 static void launch_fwd(const GruFwdParams& P, hipStream_t st) {
@@ -932,7 +941,9 @@ static void launch_fwd(const GruFwdParams& P, hipStream_t st) {
     else hipLaunchKernelGGL((gru_seq_fwd_kernel<H, 0, false>), dim3(grid_blocks(P.nstreams, P.ntiles)), dim3(H / 32 * 64), 0, st, P);
 }
 template <int H>
-static void launch_bwd(const GruBwdParams& P, hipStream_t st) {
+static void launch_bwd(const GruBwdParams& P_, hipStream_t st) {
+    GruBwdParams P = P_;
+    GRU_TUNING_OVERRIDES(P);
 #if !defined(VAME_EMU) && defined(VAME_GEMM_AB)
     if (H == 256) switch (abl_env("VAME_ABL_BWD")) {
         ABL_CASE(gru_seq_bwd_kernel, 256, 1, P, st) ABL_CASE(gru_seq_bwd_kernel, 256, 2, P, st) ABL_CASE(gru_seq_bwd_kernel, 256, 3, P, st)
@@ -941,15 +952,15 @@ static void launch_bwd(const GruBwdParams& P, hipStream_t st) {
         default: break;
     }
 #endif
-    if constexpr (H == 256 || H == 128) {
-        // wave-specialised BPTT (gru_ws_bwd_kernel) for the hidden sizes it is instantiated for; VAME_GRU_WS=0 keeps the lock-step kernel
-        if (gru_ws_enabled(H)) {
+    if constexpr (gru_ws_instantiated<H>()) {
+        // wave-specialised BPTT (gru_ws_bwd_kernel) for the hidden sizes it is instantiated for
+        if (P.kernel == VAME_GRU_KERNEL_WS || (P.kernel == VAME_GRU_KERNEL_AUTO && gru_ws_auto(H))) {
             GruBwdParams Q = P;
             // pacing of the memory waves (units of 256 cycles per request group), sized so that their 8 copy + 14 load groups span
             // about 90 % of one contraction (54 k cycles at H = 256, a quarter of that at H = 128) and never outlast it: measured
             // optimum 2 / 8 at H = 256 (profiles/r03_ws_probe.txt: 7 .. 9 within noise, 10 and more make the MFMA waves wait)
-            { const char* e = getenv("VAME_WS_PACE_CP"); Q.pace_cp = e ? atoi(e) : 2 * H * H / 65536; }
-            { const char* e = getenv("VAME_WS_PACE_LD"); Q.pace_ld = e ? atoi(e) : 8 * H * H / 65536; }
+            if (Q.pace_cp < 0) Q.pace_cp = 2 * H * H / 65536;
+            if (Q.pace_ld < 0) Q.pace_ld = 8 * H * H / 65536;
             const GruBwdParams& P = Q;
 #if !defined(VAME_EMU) && defined(VAME_GEMM_AB)
             if (H == 256) switch (abl_env("VAME_WS_ABL")) {
@@ -986,11 +997,19 @@ extern "C" int vame_gru_seq_fwd_f32(const int64_t* desc, int nstreams, int B, in
     return VAME_OK;
 }
 
+extern "C" int vame_gru_seq_bwd_has_kernel(int H, int kernel) {
+    if (H < 32 || H > 256 || H % 32) return 0;
+    if (kernel == VAME_GRU_KERNEL_WS) return H == 256 || H == 128;
+    return kernel == VAME_GRU_KERNEL_AUTO || kernel == VAME_GRU_KERNEL_LOCKSTEP;
+}
+
 extern "C" int vame_gru_seq_bwd_f32(const int64_t* desc, int nstreams, int B, int H, void* stream) {
     VAME_CHECK_ARG(desc && nstreams >= 1 && nstreams <= 8, VAME_E_BADARG, "gru_seq_bwd: nstreams=%d not in 1..8", nstreams);
     VAME_CHECK_ARG(B >= 1, VAME_E_SHAPE, "gru_seq_bwd: empty batch");
     GruBwdParams P;
     if (int rc = gru_parse_bwd(desc, nstreams, B, P)) return rc;
+    VAME_CHECK_ARG(P.kernel != VAME_GRU_KERNEL_WS || vame_gru_seq_bwd_has_kernel(H, VAME_GRU_KERNEL_WS), VAME_E_UNSUPPORTED,
+                   "gru_seq_bwd: the wave-specialised kernel is not instantiated for H=%d", H);
     hipStream_t st = (hipStream_t)stream;
     switch (H) {
         case 32: launch_bwd<32>(P, st); break;

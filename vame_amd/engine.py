@@ -138,6 +138,10 @@ class VAEEngine:
         self.coop = os.environ.get("VAME_AMD_COOP", "1") != "0"
         self.wide = os.environ.get("VAME_AMD_WIDE", "1") != "0"
         self.wide_bwd = os.environ.get("VAME_AMD_WIDE_BWD", "1") != "0"      # 0: BPTT step by step (per-step GEMM + gate kernel)
+        # BPTT / forward kernel choice of the persistent H <= 256 launches (ops.KERNEL_*): an argument of every launch (descriptor field),
+        # AUTO = the library's measured default per hidden size; the A/B tests set these attributes
+        self.gru_bwd_kernel = ops.KERNEL_AUTO
+        self.gru_fwd_kernel = ops.KERNEL_AUTO
         self._coop_state = None
         self._nuc_state = None
         # nuclear-norm solve (one workgroup, ~0.2 ms, nothing else on the chip) on a side stream NEXT TO THE OUTPUT HEADS: it starts
@@ -393,11 +397,24 @@ class VAEEngine:
             main.wait_stream(side)
 
     # ------------------------------------------------------------------ GRU sequence dispatch
-    def check_async_errors(self):
+    def _multi_rank(self):
+        return torch.distributed.is_available() and torch.distributed.is_initialized()
+
+    def check_async_errors(self, all_ranks=False):
         """Called where the host synchronises anyway (end of an epoch, before a checkpoint, after an inference call whose result
-        goes to the host): surfaces device-side failures that cannot raise.  Free when no cooperative launch happened since."""
-        if self._coop_state is not None:
-            self._coop_state.check()
+        goes to the host): surfaces device-side failures that cannot raise.  Free when no cooperative launch happened since.
+        all_ranks (the epoch-end checks of train() / test(): every rank is at this program point): the status words are MAX-reduced
+        over the ranks first, so either every rank raises or none does -- a rank raising on its own would leave the others in
+        their next collective."""
+        if self._coop_state is None:
+            return
+        reduce = None
+        if all_ranks and self._multi_rank():
+            def reduce(n):
+                t = torch.tensor([int(n)], dtype=torch.int32, device=self.dev)
+                torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+                return int(t.item())
+        self._coop_state.check(reduce=reduce)
 
     def poll_async_errors(self):
         """Start of a step: raise if an earlier step's status snapshot has arrived non-zero (never blocks)."""
@@ -408,7 +425,9 @@ class VAEEngine:
         """End of a step: enqueue the 4-byte status copy that poll_async_errors() of the next steps looks at.  With several ranks
         the word to look at is the all-reduced one (share_status), so the copy is enqueued by allreduce_gradients (reduced=True) and
         the per-rank call at the end of loss_step does nothing."""
-        if self._coop_state is not None and (reduced or self._coop_state.shared is None):
+        # (under a process group the rank-local call does nothing from the very first step on -- `shared` is only set by the first
+        # all-reduce, and a rank-local word in the snapshot ring would let ONE rank raise a step later)
+        if self._coop_state is not None and (reduced or (self._coop_state.shared is None and not self._multi_rank())):
             self._coop_state.snapshot()
 
     def abort_flag(self):
@@ -466,7 +485,7 @@ class VAEEngine:
                     ops.gru_coop_fwd(part, B, H, self._coop_state, rows=chunk)
                 if parts:
                     continue
-            ops.gru_seq_fwd(part_rows, B, H)
+            ops.gru_seq_fwd(part_rows, B, H, kernel=self.gru_fwd_kernel)
 
     def _gru_bwd(self, rows, B):
         for H in sorted({r["_s"].d.H for r in rows}, reverse=True):
@@ -483,7 +502,10 @@ class VAEEngine:
             for part, chunk in parts:
                 ops.gru_coop_bwd(part, B, H, self._coop_state, rows=chunk)
             if not parts:
-                ops.gru_seq_bwd(part_rows, B, H)
+                k = self.gru_bwd_kernel
+                if k == ops.KERNEL_WS and not ops.gru_seq_bwd_has_kernel(H, k):
+                    k = ops.KERNEL_AUTO
+                ops.gru_seq_bwd(part_rows, B, H, kernel=k)
 
     def _stepwise_fwd(self, s, B):
         """One (layer,direction) stream step by step: gh = h_{t-1} W_hh^T (GEMM) then the gate kernel."""
@@ -842,6 +864,12 @@ class VAEEngine:
             rows_f, per_f, Yf, dhid_f = self._decoder_backward("fut", "decoder_future", self.fut, FS, self.buf("dfut", B, FS, F), B, dz, False)
             rows += rows_f
             groups.append(("decoder_future", per_f, Yf, dhid_f, FS))
+        if self._nuc_event is not None and any(self._coop_parts([r for r in rows if r["_s"].d.H == hh_], B, GB["T"], hh_)
+                                               for hh_ in {r["_s"].d.H for r in rows}):
+            # small batches: the BPTT launch is the cooperative column-split kernel (one co-resident workgroup per CU, members spin on
+            # each other) -- the side stream's single-workgroup solve must not hold a CU beside it (the heads / MSE kernels it was
+            # meant to overlap take microseconds at these sizes), so it is joined here instead of before dz
+            self.join_cluster()
         self._gru_bwd(rows, B)
         ev_dec = None
         if self.bwd_overlap and self.dev.type == "cuda" and s.future:
@@ -862,7 +890,10 @@ class VAEEngine:
                 dz_jobs.append((2 * H, Operand(dhid, 2 * H), self.P(wl, Z)))
         if ev_dec is not None:
             Hf_, Kf = s.Hf, B * FS
-            self._early_wgrads(ev_dec, lambda j: j[0] == 3 * Hf_ and j[1] == Hf_ and j[2] == Kf and j[5].startswith("decoder_future."))
+            # the two dW_hh jobs only (A = dG with the dgi_n block skipped: gap_at = 2H, gap = H).  With FS = 1 and zdims = H the
+            # time-constant dW_ih job has the same (M, N, K) -- and reads `dgsum`, which timesum wrote AFTER ev_dec was recorded
+            self._early_wgrads(ev_dec, lambda j: j[0] == 3 * Hf_ and j[1] == Hf_ and j[2] == Kf and j[7] == 2 * Hf_ and j[8] == Hf_
+                               and j[5].startswith("decoder_future.") and ".weight_hh" in j[5])
         self._sum_into(dz, B, Z, dz_jobs)
         H = He
         self.join_cluster()

@@ -234,7 +234,10 @@ class RNN_VAE(nn.Module):
             self.decoder_future = Decoder_Future(self.seq_len, ZDIMS, NUM_FEATURES, FUTURE_STEPS, h_pred, d_pred)
 
     # ---------------------------------------------------------------- flat parameter bucket
-    def _ensure_engine(self):
+    def _ensure_engine(self, touch=True):
+        """The engine over the flat parameter bucket (built on first use / after the model moved).  touch: the caller is about to run the
+        model, so the weights may have changed since the last call -> refresh the padded image and have the GRU packs rebuilt;
+        bookkeeping callers (flat_parameters: optimizer, all-reduce) pass False and leave both alone."""
         plist = list(self.named_parameters())
         dev = plist[0][1].device
         _lib.require_device_tensor(plist[0][1])     # "move the model with .cuda()": there is no CPU fallback
@@ -264,9 +267,10 @@ class RNN_VAE(nn.Module):
             else:
                 self._pad = None
                 self._engine = VAEEngine(self.spec, self._table, flat_p, flat_g)
-        if self._pad is not None:
-            self._pad.push_params(self._flat_p)
-        self._engine.version += 1          # weights may have changed since the last call: repack (a few tiny kernels)
+        if touch or not ok:
+            if self._pad is not None:
+                self._pad.push_params(self._flat_p)
+            self._engine.version += 1          # weights may have changed since the last call: repack (a few tiny kernels)
         return self._engine
 
     def _accumulate_tmp_grads(self):
@@ -282,7 +286,7 @@ class RNN_VAE(nn.Module):
 
     def flat_parameters(self):
         """(flat_p, flat_g): the contiguous fp32 parameter / gradient buckets (RCCL all-reduce + fused Adam)."""
-        self._ensure_engine()
+        self._ensure_engine(touch=False)
         return self._flat_p, self._flat_g
 
     # ---------------------------------------------------------------- forward

@@ -204,7 +204,7 @@ def train(train_loader, epoch, model, optimizer, anneal_function, BETA, kl_start
     scheduler.step(float(acc[5]))
     train_loss, mse_loss, fut_loss, kullback_loss, kmeans_losses = [float(v) for v in acc[:5].cpu()]
     if getattr(model, "_engine", None) is not None:
-        model._engine.check_async_errors()
+        model._engine.check_async_errors(all_ranks=True)
     if future_decoder:
         print('Train loss: {:.3f}, MSE-Loss: {:.3f}, MSE-Future-Loss {:.3f}, KL-Loss: {:.3f}, Kmeans-Loss: {:.3f}, weight: {:.2f}'.format(
             train_loss / idx, mse_loss / idx, fut_loss / idx, BETA * kl_weight * kullback_loss / idx, kl_weight * kmeans_losses / idx, kl_weight))
@@ -231,7 +231,7 @@ def test(test_loader, epoch, model, optimizer, BETA, kl_weight, seq_len, mse_red
         raise ValueError("test(): need at least 2 test batches of batch_size/4 (rnn_vae.py:207-210 divides by the last index)")
     test_loss, mse_loss, kullback_loss, kmeans_losses = [float(v) for v in _rank_mean(acc).cpu()]
     if getattr(model, "_engine", None) is not None:
-        model._engine.check_async_errors()
+        model._engine.check_async_errors(all_ranks=True)
     print('Test loss: {:.3f}, MSE-Loss: {:.3f}, KL-Loss: {:.3f}, Kmeans-Loss: {:.3f}'.format(
         test_loss / idx, mse_loss / idx, BETA * kl_weight * kullback_loss / idx, kl_weight * kmeans_losses / idx))
     return mse_loss / idx, test_loss / idx, kl_weight * kmeans_losses

@@ -7,9 +7,16 @@ import torch
 from . import _lib
 
 GF = dict(GI=0, GI_ROW=1, GI_T=2, WP=3, BHN=4, H0=5, H0_ROW=6, Y=7, Y_ROW=8, Y_T=9, HN=10, HN_ROW=11, STASH=12, T=13,
-          REVERSE=14, PAD=15, WPX=16, BGI=17, XF=18, N=20)
+          REVERSE=14, PAD=15, WPX=16, BGI=17, XF=18, OPT=19, N=20)
 GB = dict(STASH=0, Y=1, Y_ROW=2, Y_T=3, H0=4, H0_ROW=5, WPT=6, DY=7, DY_ROW=8, DY_T=9, DHN=10, DHN_ROW=11, DG=12, DH0=13,
-          DH0_ROW=14, DBIAS=15, RESERVED=16, T=17, REVERSE=18, PAD=19, N=20)
+          DH0_ROW=14, DBIAS=15, OPT=16, T=17, REVERSE=18, PAD=19, N=20)
+# enum vame_gru_kernel / VAME_GRU_OPT(...) of include/vame_hip.h: launch options travel in the descriptor table (GF_OPT / GB_OPT of
+# stream 0), never through the process environment
+KERNEL_AUTO, KERNEL_LOCKSTEP, KERNEL_WS = 0, 1, 2
+
+
+def gru_opt(kernel=KERNEL_AUTO, pace_cp=-1, pace_ld=-1):
+    return int(kernel) | ((pace_cp + 1 if pace_cp >= 0 else 0) << 8) | ((pace_ld + 1 if pace_ld >= 0 else 0) << 16)
 
 
 def _stream():
@@ -82,6 +89,38 @@ def gemm_group(M, N, K, As, a_kmajor, Bs, b_kmajor, C, c_offs, ldc, splitk, ws, 
     _lib.check(rc, "vame_gemm_group_f32")
 
 
+class ClockProbe:
+    """Average shader clock over a stretch of the current stream (vame_clock_stamp before and after it): `start()`, work, `stop()`,
+    then `mhz()` once the stream has been synchronised.  Measurement only (bench.py: roofline.clock_mhz / frac_at_clock)."""
+    NB = 64                                                  # workgroups per stamp: every XCD gets several
+
+    def __init__(self, dev):
+        self.buf = torch.zeros(2, self.NB, 4, dtype=torch.int64, device=dev)
+
+    def _stamp(self, k):
+        rc = _lib.lib().vame_clock_stamp(self.buf[k].data_ptr(), self.NB, _stream())
+        _lib.check(rc, "vame_clock_stamp")
+
+    def start(self):
+        self._stamp(0)
+
+    def stop(self):
+        self._stamp(1)
+
+    def mhz(self):
+        """Median over XCDs of d(shader ticks) / d(100 MHz ticks) x 100; None when the counters did not move (host emulator)."""
+        b = self.buf.cpu().numpy()
+        vals = []
+        for x in range(16):
+            m0, m1 = b[0][b[0][:, 2] == x], b[1][b[1][:, 2] == x]
+            if len(m0) and len(m1):
+                dt, dr = int(m1[:, 0].min()) - int(m0[:, 0].min()), int(m1[:, 1].min()) - int(m0[:, 1].min())
+                if dr > 0 and dt > 0:
+                    vals.append(100.0 * dt / dr)
+        vals.sort()
+        return vals[len(vals) // 2] if vals else None
+
+
 def window_gather(X, N, F, starts, start0, B, L, out):
     rc = _lib.lib().vame_window_gather_f32(_ptr(X), N, F, _ptr(starts), start0, B, L, _ptr(out), _stream())
     _lib.check(rc, "vame_window_gather_f32")
@@ -129,9 +168,10 @@ def _desc_tensor(rows, nfields):
     return d
 
 
-def gru_seq_fwd(streams, B, H):
-    """streams: list of dicts keyed by GF[...] indices."""
+def gru_seq_fwd(streams, B, H, kernel=KERNEL_AUTO):
+    """streams: list of dicts keyed by GF[...] indices.  kernel: KERNEL_* (an argument of the call: GF_OPT of stream 0)."""
     d = _desc_tensor(streams, GF["N"])
+    d[0, GF["OPT"]] = gru_opt(kernel)
     rc = _lib.lib().vame_gru_seq_fwd_f32(d.data_ptr(), len(streams), B, H, _stream())
     _lib.check(rc, "vame_gru_seq_fwd_f32")
 
@@ -180,7 +220,7 @@ class CoopState:
         """Look at the snapshots that have already arrived (start of a step); never blocks.  Not with several ranks: WHEN a copy
         arrives differs between ranks, and a rank that raised here would leave the others waiting in the next all-reduce -- there
         every rank examines the same (all-reduced) word at the same program point, in snapshot() two steps later or in check()."""
-        if self.shared is not None:
+        if self.shared is not None or (torch.distributed.is_available() and torch.distributed.is_initialized()):
             return
         for k in (0, 1):
             ev = self._ev[k]
@@ -206,14 +246,18 @@ class CoopState:
         self.epoch = (self.epoch + T + 2) & 0xffffffff
         return b - (1 << 32) if b >= (1 << 31) else b
 
-    def check(self):
-        """Host sync: raise if a cooperative launch ever gave up waiting for a group member (its results were undefined)."""
-        if not self.dirty:
+    def check(self, reduce=None):
+        """Host sync: raise if a cooperative launch ever gave up waiting for a group member (its results were undefined).
+        reduce: several ranks at the same program point -- maps this rank's count to the maximum over ranks (a collective, so it runs
+        whether or not this rank launched anything since the last check: every rank must enter it)."""
+        if not self.dirty and reduce is None:
             return
-        self.dirty = False
-        n = int(self.status.item())
-        if self.shared is not None:
+        n = int(self.status.item()) if self.dirty else 0
+        if self.shared is not None and self.dirty:
             n = max(n, int(self.shared.item() != 0))
+        self.dirty = False
+        if reduce is not None:
+            n = reduce(n)
         self._raise_if(n)
 
 
@@ -263,8 +307,15 @@ def gru_coop_bwd(streams, B, H, state: CoopState, rows=(0, 0)):
     _lib.check(rc, "vame_gru_coop_bwd_f32")
 
 
-def gru_seq_bwd(streams, B, H):
+def gru_seq_bwd_has_kernel(H, kernel):
+    return bool(_lib.lib().vame_gru_seq_bwd_has_kernel(int(H), int(kernel)))
+
+
+def gru_seq_bwd(streams, B, H, kernel=KERNEL_AUTO, pace_cp=-1, pace_ld=-1):
+    """kernel: KERNEL_AUTO (measured default per hidden size) / KERNEL_LOCKSTEP / KERNEL_WS (wave-specialised; raises where it is not
+    instantiated); pace_*: pacing of the wave-specialised kernel's memory waves (-1 = default).  All of it travels in GB_OPT."""
     d = _desc_tensor(streams, GB["N"])
+    d[0, GB["OPT"]] = gru_opt(kernel, pace_cp, pace_ld)
     rc = _lib.lib().vame_gru_seq_bwd_f32(d.data_ptr(), len(streams), B, H, _stream())
     _lib.check(rc, "vame_gru_seq_bwd_f32")
 
