@@ -127,7 +127,7 @@ def profile_kernels(model, loader, B, steps=3):
     kt = KernelTimer(clocked=mfma_apis)
 
     def gru_flops(tag):
-        def f(streams, B_, Hh):
+        def f(streams, B_, Hh, *a, **k):
             key_t = ops.GF["T"] if tag == "fwd" else ops.GB["T"]
             fl = sum(2.0 * 3 * Hh * Hh * B_ * int(s[key_t]) for s in streams)
             name = "gru_seq" if Hh <= 256 else "gru_wide"
@@ -135,7 +135,7 @@ def profile_kernels(model, loader, B, steps=3):
         return f
 
     def coop_flops(tag):       # column-split GRU launches of the small-batch path: rows = (row0, nrows) restricts the launch to a row range
-        def f(streams, B_, Hh, state, rows=(0, 0)):
+        def f(streams, B_, Hh, state, rows=(0, 0), **k):
             key_t = ops.GF["T"] if tag == "fwd" else ops.GB["T"]
             nrows = rows[1] or B_
             return (f"gru_coop_{tag}_kernel<{Hh}> x{len(streams)} streams", sum(2.0 * 3 * Hh * Hh * nrows * int(s[key_t]) for s in streams))

@@ -99,10 +99,12 @@ enum vame_gru_fwd_field {
  * ARGUMENTS of a call -- the library reads no process-global state (no environment variables) outside its tuning builds, so two
  * callers in one process cannot influence each other.
  *   bits 0..3   kernel: VAME_GRU_KERNEL_AUTO (the measured default per hidden size), _LOCKSTEP (all waves of a workgroup do the
- *               same thing per phase), _WS (wave-specialised: MFMA waves + memory waves; refused where not instantiated)
+ *               same thing per phase), _WS (BPTT, wave-specialised: MFMA waves + memory waves), _SKEWED (forward: the two waves of a
+ *               SIMD run half a step apart, bit-identical to _LOCKSTEP); a kernel that is not instantiated for H is refused
  *   bits 8..15  pace_cp + 1, bits 16..23  pace_ld + 1: pacing of the wave-specialised kernels' memory waves in units of 256
- *               cycles per request group (0 = the measured default for the hidden size) */
-enum vame_gru_kernel { VAME_GRU_KERNEL_AUTO = 0, VAME_GRU_KERNEL_LOCKSTEP = 1, VAME_GRU_KERNEL_WS = 2 };
+ *               cycles per request group (0 = the measured default for the hidden size); _SKEWED: pace_cp = priority mode
+ *               (0 none, 1 = the wave in its gate-math half raises its priority; default 1) */
+enum vame_gru_kernel { VAME_GRU_KERNEL_AUTO = 0, VAME_GRU_KERNEL_LOCKSTEP = 1, VAME_GRU_KERNEL_WS = 2, VAME_GRU_KERNEL_SKEWED = 3 };
 #define VAME_GRU_OPT(kernel, pace_cp, pace_ld) \
     ((int64_t)(kernel) | ((int64_t)((pace_cp) < 0 ? 0 : (pace_cp) + 1) << 8) | ((int64_t)((pace_ld) < 0 ? 0 : (pace_ld) + 1) << 16))
 int64_t vame_gru_stash_floats(int B, int T, int H);
@@ -110,6 +112,8 @@ int64_t vame_gru_stash_floats(int B, int T, int H);
  * the projection x_t W_ih^T is then computed inside the sequence kernel instead of by vame_gemm_f32). */
 int vame_gru_pack_x_f32(const float* W_ih, int F, int H, float* wpx, void* stream);
 int vame_gru_seq_fwd_f32(const int64_t* desc, int nstreams, int B, int H, void* stream);
+/* 1 if vame_gru_seq_fwd_f32 has `kernel` (enum vame_gru_kernel) for hidden size H */
+int vame_gru_seq_fwd_has_kernel(int H, int kernel);
 
 /* GRU sequence backward (BPTT) for the same streams.  Writes dG (B,T,4H) = [da_r|da_z|dgi_n|dgh_n]
  * for the weight-gradient GEMMs, per-tile bias-gradient partials and optional dh0. */

@@ -321,12 +321,62 @@ def check_gru_fwd_fused(dev, H, B, T, I=24):
                      GF["WPX"]: ops.addr(wpx), GF["BGI"]: ops.addr(bgi), GF["XF"]: I})
         st.append((W_ih, W_hh, b_ih, b_hh))
         keep.append((wpf, wpb, bgi, bhn, wpx, stash))
-    ops.gru_seq_fwd(rows, B, H)
+    ops.gru_seq_fwd(rows, B, H, kernel=FWD_KERNEL)
     Yn, hNn = N_(Y), N_(hN)
     for d, (W_ih, W_hh, b_ih, b_hh) in enumerate(st):
         out, hn, _ = vo.gru_dir_forward(win[:, :T], None, W_ih, W_hh, b_ih, b_hh, reverse=bool(d))
         np.testing.assert_allclose(Yn[:, 1:T + 1, d * H:(d + 1) * H], out, atol=2e-5)
         np.testing.assert_allclose(hNn[:, d * H:(d + 1) * H], hn, atol=2e-5)
+    return Y, hN, [k[5] for k in keep]
+
+
+def _valid_stash_mask(B, T, H):
+    """Stash entries of rows past the batch (last tile) are don't-cares: True for the entries of valid rows."""
+    ntiles, NW = (B + 31) // 32, H // 32
+    q, lane, e = np.meshgrid(np.arange(4), np.arange(64), np.arange(4), indexing="ij")
+    r = 4 * q + e
+    row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)                                   # CR(r) + 4 * (lane >> 5)
+    valid = (np.arange(ntiles)[:, None, None, None] * 32 + row[None]) < B              # (ntiles, 4, 64, 4)
+    return np.broadcast_to(valid[:, None, None, None], (ntiles, T, NW, 5, 4, 64, 4)).reshape(-1)
+
+
+def check_gru_skew_fwd(dev, H, B, T):
+    """The skewed forward kernel (gru_seq.hip: gru_skew_fwd_kernel -- the two waves of a SIMD half a step apart) against the numpy oracle
+    and BIT FOR BIT against the lock-step kernel (same arithmetic in the same order): h sequence, final state, BPTT stash -- for per-step gi
+    streams with and without an initial state (both directions), the fused input projection, and a time-constant gi with h0 (decoder
+    form).  The kernel is picked per launch by the GF_OPT descriptor field."""
+    global FWD_KERNEL
+    assert ops.gru_seq_fwd_has_kernel(H, ops.KERNEL_SKEWED)
+    outs = {}
+    try:
+        for kern in (ops.KERNEL_SKEWED, ops.KERNEL_LOCKSTEP):
+            FWD_KERNEL = kern
+            if kern == ops.KERNEL_SKEWED:
+                check_gru_fwd(dev, H, B, T)                       # vs the oracle
+            x, st, Y, hN = run_gru_fwd(dev, H, B, T, seed=2)
+            Yf, hNf, stf = check_gru_fwd_fused(dev, H, B, T)     # vs the oracle, fused input (zero initial state: skipped first K loop)
+            # decoder form: gi constant in time, initial state given, one stream per direction, inference (no stash) on the reverse one
+            rng = np.random.default_rng(4)
+            W_ih, W_hh, b_ih, b_hh = _gru_weights(rng, 5, H)
+            wpf, wpb, bgi, bhn = _pack(dev, W_hh, b_ih, b_hh, H)
+            gi = T_(rng.standard_normal((B, 3 * H)).astype(np.float32), dev)
+            h0 = T_(rng.standard_normal((B, H)).astype(np.float32) * 0.5, dev)
+            Yc, hNc = torch.zeros(B, T + 2, 2 * H, device=dev), torch.zeros(B, 2 * H, device=dev)
+            stc = torch.zeros(ops.gru_stash_floats(B, T, H), device=dev)
+            rows = [{GF["GI"]: ops.addr(gi), GF["GI_ROW"]: 3 * H, GF["GI_T"]: 0, GF["WP"]: ops.addr(wpf), GF["BHN"]: ops.addr(bhn),
+                     GF["H0"]: ops.addr(h0) if d == 0 else 0, GF["H0_ROW"]: H, GF["Y"]: ops.addr(Yc, 2 * H + d * H), GF["Y_ROW"]: (T + 2) * 2 * H,
+                     GF["Y_T"]: 2 * H, GF["HN"]: ops.addr(hNc, d * H), GF["HN_ROW"]: 2 * H, GF["STASH"]: ops.addr(stc) if d == 0 else 0,
+                     GF["T"]: T, GF["REVERSE"]: d, GF["PAD"]: 1} for d in range(2)]
+            launch_gru_fwd(rows, B, H)
+            outs[kern] = [Y, hN, Yf, hNf, Yc, hNc] + [s_["stash"] for s_ in st] + stf + [stc]
+    finally:
+        FWD_KERNEL = ops.KERNEL_AUTO
+    valid = torch.from_numpy(_valid_stash_mask(B, T, H).copy()).to(dev)
+    for i, (a, b) in enumerate(zip(outs[ops.KERNEL_SKEWED], outs[ops.KERNEL_LOCKSTEP])):
+        if a.dim() == 1:                                          # a stash: compare the entries of rows inside the batch
+            assert torch.equal(a[valid], b[valid]), f"stash {i} differs"
+        else:
+            assert torch.equal(a, b), f"output {i} differs: {float((a - b).abs().max())}"
 
 
 def _run_gru_bwd(dev, H, B, T, st, Y, dYt, dhNt, coop=None, coop_chunks=None):

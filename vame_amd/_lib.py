@@ -33,6 +33,7 @@ _SIGS = {
     "vame_gru_seq_fwd_f32": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p]),
     "vame_gru_seq_bwd_f32": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p]),
     "vame_gru_seq_bwd_has_kernel": (c_int, [c_int, c_int]),
+    "vame_gru_seq_fwd_has_kernel": (c_int, [c_int, c_int]),
     "vame_gru_cell_fwd_f32": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64,
                                       c_int, c_int, c_void_p]),
     "vame_gru_cell_bwd_f32": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int, c_int,

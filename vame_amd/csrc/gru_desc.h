@@ -48,7 +48,7 @@ static inline void gru_parse_opt(int64_t opt, int& kernel, int& pace_cp, int& pa
 static inline int gru_parse_fwd(const int64_t* desc, int nstreams, int B, GruFwdParams& P) {
     P.nstreams = nstreams; P.B = B; P.ntiles = (int)cdiv64(B, 32);
     gru_parse_opt(desc[GF_OPT], P.kernel, P.pace_cp, P.pace_ld);
-    VAME_CHECK_ARG(P.kernel <= VAME_GRU_KERNEL_WS, VAME_E_BADARG, "gru_seq_fwd: unknown kernel option %d", P.kernel);
+    VAME_CHECK_ARG(P.kernel <= VAME_GRU_KERNEL_SKEWED, VAME_E_BADARG, "gru_seq_fwd: unknown kernel option %d", P.kernel);
     for (int i = 0; i < nstreams; ++i) {
         const int64_t* d = desc + (int64_t)i * VAME_GRU_FWD_FIELDS;
         GruFwdStream& s = P.s[i];
@@ -73,7 +73,7 @@ static inline int gru_parse_fwd(const int64_t* desc, int nstreams, int B, GruFwd
 static inline int gru_parse_bwd(const int64_t* desc, int nstreams, int B, GruBwdParams& P) {
     P.nstreams = nstreams; P.B = B; P.ntiles = (int)cdiv64(B, 32);
     gru_parse_opt(desc[GB_OPT], P.kernel, P.pace_cp, P.pace_ld);
-    VAME_CHECK_ARG(P.kernel <= VAME_GRU_KERNEL_WS, VAME_E_BADARG, "gru_seq_bwd: unknown kernel option %d", P.kernel);
+    VAME_CHECK_ARG(P.kernel <= VAME_GRU_KERNEL_SKEWED, VAME_E_BADARG, "gru_seq_bwd: unknown kernel option %d", P.kernel);
     for (int i = 0; i < nstreams; ++i) {
         const int64_t* d = desc + (int64_t)i * VAME_GRU_BWD_FIELDS;
         GruBwdStream& s = P.s[i];

@@ -425,6 +425,263 @@ __global__ __launch_bounds__(H / 32 * 64) void gru_seq_fwd_kernel(GruFwdParams P
     GRU_PROBE_END();
 }
 
+// ------------------------------------------------------------------------------------------- forward, two wave groups half a step apart (round 4)
+// Same tile, same LDS images, same stash / Y formats, same arithmetic in the same order as gru_seq_fwd_kernel (bit-identical outputs) -- but
+// the two waves of every SIMD no longer do the same thing at the same time.  The lock-step kernel serialises, per step and per SIMD,
+// [contraction of both waves: 49 k cycles] -> [gate math of both waves: ~7 k cycles of VALU + transcendentals with the matrix pipe idle]
+// -> [barrier, with the stash stores' and the next gi tile's round trips in it]; nothing of a tile's step t+1 can start before ALL of h_t
+// exists.  But h_t is only needed COLUMN BLOCK BY COLUMN BLOCK by the K loop of step t+1.  So the waves form two groups -- X = the first
+// half of the waves (hidden columns [0, H/2)), Y = the second half ([H/2, H)); wave w and wave w + NW/2 share a SIMD -- and every wave
+// runs its step in two parts with a workgroup barrier after each:
+//     part 0:  accumulators <- gi;  K loop over k in [0, H/2)         (needs h_{t-1} of X's columns)
+//     part 1:  K loop over k in [H/2, H);  gate math, h_t -> LDS, stash (needs h_{t-1} of Y's columns)
+// with Y HALF A STEP BEHIND X: in interval J(2s) X runs part 0 of step s while Y runs part 1 of step s-1, in J(2s+1) X runs part 1 of s
+// while Y runs part 0 of s.  Every dependency is one barrier old: X.part0(s) reads the columns X wrote in J(2s-1), X.part1(s) those Y
+// wrote in J(2s), Y.part0(s) reads X's of J(2s-1), Y.part1(s) Y's own of J(2s); a half is overwritten (other LDS image) three intervals
+// after its last reader.  Per accumulator the k order is still ascending, hence the identical bits.  What it buys: on every SIMD one wave
+// is in part 1 while the other is in part 0, so gate math, the wait for the gi tile and the drain of the stash stores of one wave run
+// beside the other wave's MFMAs; the wave in part 1 raises its priority so that its MFMAs go first and its VALU tail is covered.
+// 2 T + 1 intervals for T steps (half an interval of fill and of drain).  Barriers order LDS only (LDS_BARRIER): global stores and
+// the weight ring stay in flight across them.
+// prio (P.pace_cp; tuning): 0 = no priority change, 1 (default) = s_setprio 1 during part 1.
+template <int H, bool XIN>
+__global__ __launch_bounds__(H / 32 * 64) void gru_skew_fwd_kernel(GruFwdParams P) {
+    constexpr int NW = H / 32, GW = NW / 2, GT = GW * 64, LDH = H + 4, KC = H / 8, KH = KC / 2, LDX = 36, PD = 4;
+    static_assert(NW % 2 == 0 && KH % PD == 0, "skewed forward: H a multiple of 64");
+    __shared__ float hs[2][32 * LDH];                          // h_{s-1} lives in hs[s & 1]
+    __shared__ float xs[XIN ? 2 : 1][XIN ? 32 * LDX : 4];      // x_s lives in xs[s & 1]
+    int sidx, tile;
+    if (!map_block(P.nstreams, P.ntiles, sidx, tile)) return;
+    GRU_PROBE_BEGIN();
+    const GruFwdStream& S = P.s[sidx];
+    const int B = P.B, T = (int)S.T;
+    const int tid = threadIdx.x, lane = tid & 63, li = lane & 31, hh = lane >> 5;
+    const int w = UNIFORM(tid >> 6);
+    const int grp = UNIFORM(w >= GW ? 1 : 0);
+    const int gtid = tid - grp * GT;                           // thread index inside the group
+    const int row0 = tile * 32, col0 = 32 * w, lrow = 4 * hh;
+    const int nvalid = B - row0;
+    const bool full = nvalid >= 32;
+    const int prio = P.pace_cp < 0 ? 1 : P.pace_cp;
+    const int delay = P.pace_ld < 0 ? 0 : P.pace_ld;          // part 0 starts `delay` x ~256 cycles late (see the step loop)
+    const int lo_gi = lrow * (int)S.gi_row + li;
+    const float* gi_base = S.gi + (int64_t)row0 * S.gi_row + col0;
+    float* y_tile = S.y ? S.y + (int64_t)row0 * S.y_row : nullptr;
+    // h_t leaves through LDS as 16-byte row stores; a group copies the half it wrote: GT = H threads cover 8 rows x (H/8) float4 per pass
+    const int crow = gtid / (H / 8), cc = grp * (H / 2) + 4 * (gtid % (H / 8));
+    auto store_h = [&](const float* hbuf, int t) {
+        float* yt = y_tile + (int64_t)t * S.y_t + (int64_t)crow * S.y_row + cc;
+        const float* src = hbuf + crow * LDH + cc;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (full || crow + 8 * i < nvalid)
+                *reinterpret_cast<float4*>(yt + (int64_t)(8 * i) * S.y_row) = *reinterpret_cast<const float4*>(src + 8 * i * LDH);
+    };
+    auto time_of = [&](int s) { return S.reverse ? T - 1 - s : s; };
+    f32x16 hprev;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = CR(r) + lrow, grow = row0 + row;
+        float v = 0.0f;
+        if (S.h0 && grow < B) v = S.h0[(int64_t)grow * S.h0_row + col0 + li];
+        hprev[r] = v;
+        hs[0][row * LDH + col0 + li] = v;
+    }
+    // fused input (XIN): the (32 x F) tile of x_s is staged by group X's threads alone -- fetched during X's part 0 of step s-1, written
+    // to xs[s & 1] at the end of its part 1 (read by X one barrier later, by Y two; its previous content x_{s-2} was last read by Y two
+    // intervals earlier); columns F..31 stay zero
+    constexpr int XI = XIN ? (32 * 8 + GT - 1) / GT : 1;
+    const int nq = XIN ? (int)S.xf / 4 : 1;
+    float4 xv[XI];
+    int xgo[XI], xlo[XI];
+#pragma unroll
+    for (int i = 0; i < XI; ++i) {
+        const int idx = gtid + i * GT, xr = idx / nq, xq = idx % nq;
+        const bool mine = XIN && grp == 0 && idx < 32 * nq;
+        xlo[i] = mine ? xr * LDX + 4 * xq : -1;
+        xgo[i] = (mine && xr < nvalid) ? (row0 + xr) * (int)S.gi_row + 4 * xq : -1;
+    }
+    auto load_x = [&](int t) {
+        const float* xt = S.gi + (int64_t)t * S.gi_t;
+#pragma unroll
+        for (int i = 0; i < XI; ++i)
+            xv[i] = xgo[i] >= 0 ? *reinterpret_cast<const float4*>(xt + xgo[i]) : make_float4(0.f, 0.f, 0.f, 0.f);
+    };
+    auto store_x = [&](float* buf) {
+#pragma unroll
+        for (int i = 0; i < XI; ++i)
+            if (xlo[i] >= 0) *reinterpret_cast<float4*>(&buf[xlo[i]]) = xv[i];
+    };
+    if (XIN) {
+        for (int i = tid; i < 2 * 32 * LDX; i += NW * 64) (&xs[0][0])[i] = 0.f;
+        load_x(time_of(0));
+    }
+    __syncthreads();
+    if (XIN) store_x(xs[0]);
+    if (y_tile && S.pad) store_h(hs[0], S.reverse ? T : -1);
+    const float bhn = S.bhn[col0 + li];
+    const float bgr = XIN ? S.bgi[col0 + li] : 0.f, bgu = XIN ? S.bgi[H + col0 + li] : 0.f, bgn = XIN ? S.bgi[2 * H + col0 + li] : 0.f;
+    const float4* __restrict__ wpx = XIN ? reinterpret_cast<const float4*>(S.wpx) + (int64_t)w * 4 * 3 * 64 + lane : nullptr;
+    const float4* __restrict__ wp = reinterpret_cast<const float4*>(S.wp) + (int64_t)w * KC * 3 * 64 + lane;
+    float4* stash = S.stash ? reinterpret_cast<float4*>(S.stash) : nullptr;
+    f32x16 gr, gu, gn;                       // gi of the wave's next step (per-step gi streams: fetched behind part 1's K loop)
+    auto load_gi = [&](int t) {
+        const float* gt = gi_base + (int64_t)t * S.gi_t;
+        if (full) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float* g = gt + (int64_t)CR(r) * S.gi_row;
+                gr[r] = g[lo_gi]; gu[r] = g[lo_gi + H]; gn[r] = g[lo_gi + 2 * H];
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float* g = gt + (int64_t)CR(r) * S.gi_row;
+                if (CR(r) + lrow < nvalid) { gr[r] = g[lo_gi]; gu[r] = g[lo_gi + H]; gn[r] = g[lo_gi + 2 * H]; }
+                else { gr[r] = 0.f; gu[r] = 0.f; gn[r] = 0.f; }
+            }
+        }
+    };
+    if (!XIN) load_gi(time_of(0));
+    f32x4 wq[PD][3];
+    {
+        const float4* w0 = XIN ? wpx : wp;
+#pragma unroll
+        for (int c = 0; c < PD; ++c) { RING_LOAD(wq[c][0], w0, (c * 3 + 0) * 64); RING_LOAD(wq[c][1], w0, (c * 3 + 1) * 64); RING_LOAD(wq[c][2], w0, (c * 3 + 2) * 64); }
+    }
+    // a zero initial state contributes nothing to step 0: its K loops are skipped (acc + 0 * w = acc), the ring keeps its first chunks
+    const bool skip0 = S.h0 == nullptr;
+    if (XIN) __syncthreads();                // xs[0] is complete
+    GRU_PHASE_DECL();
+    // The skew is ONE barrier: group Y passes an extra barrier before its first step, group X one after its last.  Both then run the same
+    // loop -- part 0, barrier, part 1, barrier -- and X's k-th barrier is Y's (k+1)-th, so Y's part 0 of step s runs beside X's part 1 of
+    // step s, Y's part 1 beside X's part 0 of step s + 1 (2 T + 1 barriers for every wave).
+    if (grp == 1) LDS_BARRIER();
+    for (int s = 0; s < T; ++s) {
+        const int t = time_of(s);
+        const bool skip = s == 0 && skip0;
+        const float* hrow = &hs[s & 1][li * LDH + 4 * hh];
+        if (s >= 1 && y_tile) store_h(hs[s & 1], time_of(s - 1));      // h_{s-1} of this group's columns (complete since the last barrier)
+        // The partner wave on this SIMD is entering part 1: K loop, then gate math.  Two K loops side by side advance at the same rate and
+        // end together (the matrix pipe alternates between the waves whatever their priority: measured, profiles/r04_skew_probe.txt) --
+        // and the partner's gate math would then run with the pipe idle.  Starting part 0 late by about the length of that gate math lets
+        // the partner's loop run alone first and end early; this wave's loop then has the pipe to itself while the partner does its VALU work.
+        for (int z = 0; z < delay; ++z) VAME_SLEEP4();
+        GRU_PHASE(0);
+        // ---------------------------------------------------------------- part 0
+        f32x16 ar, au, ani, anh;                 // the gate accumulators live across the barrier between the two parts
+        if (XIN) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { ar[r] = bgr; au[r] = bgu; ani[r] = bgn; anh[r] = bhn; }
+            if (grp == 0 && s + 1 < T) load_x(time_of(s + 1));
+            const float* xrow = &xs[s & 1][li * LDX + 4 * hh];
+#pragma unroll
+            for (int j = 0; j < PD; ++j) {
+                const float4 a = *reinterpret_cast<const float4*>(xrow + 8 * j);
+                RING_WAIT3(3 * (PD - 1), wq[j][0], wq[j][1], wq[j][2]);
+                const f32x4 b0 = wq[j][0], b1 = wq[j][1], b2 = wq[j][2];
+                ar = MFMA_32x32x2(a.x, b0[0], ar); au = MFMA_32x32x2(a.x, b1[0], au); ani = MFMA_32x32x2(a.x, b2[0], ani);
+                ar = MFMA_32x32x2(a.y, b0[1], ar); au = MFMA_32x32x2(a.y, b1[1], au); ani = MFMA_32x32x2(a.y, b2[1], ani);
+                ar = MFMA_32x32x2(a.z, b0[2], ar); au = MFMA_32x32x2(a.z, b1[2], au); ani = MFMA_32x32x2(a.z, b2[2], ani);
+                ar = MFMA_32x32x2(a.w, b0[3], ar); au = MFMA_32x32x2(a.w, b1[3], au); ani = MFMA_32x32x2(a.w, b2[3], ani);
+                RING_FENCE();
+                const float4* nsrc = skip ? wpx : wp;          // no recurrent loop in a zero-state first step: keep the input chunks
+                RING_LOAD(wq[j][0], nsrc, (j * 3 + 0) * 64); RING_LOAD(wq[j][1], nsrc, (j * 3 + 1) * 64); RING_LOAD(wq[j][2], nsrc, (j * 3 + 2) * 64);
+            }
+        } else {
+            ar = gr; au = gu; ani = gn;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) anh[r] = bhn;
+        }
+        // one group of PD chunks of the recurrent K loop: chunk c = c0 + j from ring slot j, refilled behind its last use with chunk
+        // c + PD (the last group of a step wraps into the next step's first chunks: the input-projection chunks when XIN)
+        auto k_group = [&](int c0) {
+#pragma unroll
+            for (int j = 0; j < PD; ++j) {
+                const int c = c0 + j;
+                const float4 a = *reinterpret_cast<const float4*>(hrow + 8 * c);
+                RING_WAIT3(3 * (PD - 1), wq[j][0], wq[j][1], wq[j][2]);
+                const f32x4 b0 = wq[j][0], b1 = wq[j][1], b2 = wq[j][2];
+                ar = MFMA_32x32x2(a.x, b0[0], ar); au = MFMA_32x32x2(a.x, b1[0], au); anh = MFMA_32x32x2(a.x, b2[0], anh);
+                ar = MFMA_32x32x2(a.y, b0[1], ar); au = MFMA_32x32x2(a.y, b1[1], au); anh = MFMA_32x32x2(a.y, b2[1], anh);
+                ar = MFMA_32x32x2(a.z, b0[2], ar); au = MFMA_32x32x2(a.z, b1[2], au); anh = MFMA_32x32x2(a.z, b2[2], anh);
+                ar = MFMA_32x32x2(a.w, b0[3], ar); au = MFMA_32x32x2(a.w, b1[3], au); anh = MFMA_32x32x2(a.w, b2[3], anh);
+                RING_FENCE();
+                {
+                    const bool wrap = c0 + PD == KC;
+                    const float4* src = (XIN && wrap) ? wpx : wp;
+                    const int cn = wrap ? j : c + PD;
+                    RING_LOAD(wq[j][0], src, (cn * 3 + 0) * 64); RING_LOAD(wq[j][1], src, (cn * 3 + 1) * 64); RING_LOAD(wq[j][2], src, (cn * 3 + 2) * 64);
+                }
+            }
+        };
+        if (!skip) {
+#pragma unroll 1
+            for (int c0 = 0; c0 < KH; c0 += PD) k_group(c0);
+        }
+        GRU_PHASE(1);
+        LDS_BARRIER();
+        GRU_PHASE(4);
+        // ---------------------------------------------------------------- part 1
+        if (prio) SETPRIO(1);
+        if (!skip) {
+#pragma unroll 1
+            for (int c0 = KH; c0 < KC; c0 += PD) k_group(c0);
+        }
+        // gi of this wave's next step: requested behind the loop's last ring wait (in front of it, the ring's vmcnt(9) waits would
+        // wait for these loads too); it arrives beside the gate math, the barrier and the partner wave's MFMAs
+        if (!XIN && s + 1 < T && S.gi_t != 0) load_gi(time_of(s + 1));
+        GRU_PHASE(2);
+        float* hnext = &hs[(s + 1) & 1][lrow * LDH + col0 + li];
+        f32x16 ust;
+        float4* sp = stash ? stash + ((((int64_t)tile * T + t) * NW + w) * 20) * 64 + lane : nullptr;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int r = 4 * q + j;
+                const float rr = fast_sigmoid(ar[r]);
+                const float uu = fast_sigmoid(au[r]);
+                const float nn = fast_tanh(ani[r] + rr * anh[r]);
+                const float hp = hprev[r];
+                const float hv = nn + uu * (hp - nn);
+                const float omu = 1.0f - uu;
+                ani[r] = omu * (1.0f - nn * nn);          // cA
+                au[r] = (hp - nn) * uu * omu;             // cB
+                ar[r] = rr;
+                ust[r] = uu;
+                hprev[r] = hv;
+                hnext[CR(r) * LDH] = hv;
+            }
+            if (stash) {
+                const float4 v0 = make_float4(ani[4 * q], ani[4 * q + 1], ani[4 * q + 2], ani[4 * q + 3]);
+                const float4 v1 = make_float4(au[4 * q], au[4 * q + 1], au[4 * q + 2], au[4 * q + 3]);
+                const float4 v2 = make_float4(ust[4 * q], ust[4 * q + 1], ust[4 * q + 2], ust[4 * q + 3]);
+                const float4 v3 = make_float4(ar[4 * q], ar[4 * q + 1], ar[4 * q + 2], ar[4 * q + 3]);
+                const float4 v4 = make_float4(anh[4 * q], anh[4 * q + 1], anh[4 * q + 2], anh[4 * q + 3]);
+                sp[(0 * 4 + q) * 64] = v0; sp[(1 * 4 + q) * 64] = v1; sp[(2 * 4 + q) * 64] = v2; sp[(3 * 4 + q) * 64] = v3; sp[(4 * 4 + q) * 64] = v4;
+            }
+            SCHED_FENCE();
+        }
+        if (XIN && grp == 0 && s + 1 < T) store_x(xs[(s + 1) & 1]);
+        if (prio) SETPRIO(0);
+        GRU_PHASE(3);
+        LDS_BARRIER();
+        GRU_PHASE(5);
+    }
+    if (grp == 0) LDS_BARRIER();
+    if (y_tile) store_h(hs[T & 1], time_of(T - 1));                  // the last step's half (complete since this wave's last in-loop barrier)
+    GRU_PHASE_END();
+    if (S.hn) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int grow = row0 + CR(r) + lrow;
+            if (grow < B) S.hn[(int64_t)grow * S.hn_row + col0 + li] = hprev[r];
+        }
+    }
+    GRU_PROBE_END();
+}
+
 // ------------------------------------------------------------------------------------------- backward
 // ABL: 1 no dG stores, 2 no stash/dy loads (first step's reused), 16 W fragments not re-streamed, 32 no barriers, 256 / 1024 dG copy-out placement (see the step loop)
 template <int H, int ABL = 0>
@@ -915,6 +1172,11 @@ static void tuning_overrides(GruBwdParams& Q) {
     if (const char* e = getenv("VAME_WS_PACE_CP")) Q.pace_cp = atoi(e);
     if (const char* e = getenv("VAME_WS_PACE_LD")) Q.pace_ld = atoi(e);
 }
+static void tuning_overrides(GruFwdParams& Q) {
+    if (const char* e = getenv("VAME_GRU_FWD")) Q.kernel = atoi(e);
+    if (const char* e = getenv("VAME_GRU_FWD_PRIO")) Q.pace_cp = atoi(e);
+    if (const char* e = getenv("VAME_GRU_FWD_DELAY")) Q.pace_ld = atoi(e);
+}
 #define GRU_TUNING_OVERRIDES(Q) tuning_overrides(Q)
 #else
 #define GRU_TUNING_OVERRIDES(Q)
@@ -926,9 +1188,20 @@ static void tuning_overrides(GruBwdParams& Q) {
 // the serial coefficient phase weighs more: measured slower, instantiated for the tests and for callers that ask for it).
 template <int H> static constexpr bool gru_ws_instantiated() { return H == 256 || H == 128; }
 static bool gru_ws_auto(int H) { return H == 256; }
+// forward: AUTO = the skewed kernel where it measured faster (tools/fwd_table.py, profiles/r04_fwd_table.txt): H = 256 and 192 for streams
+// that read something every step (a per-step gi tile: +6-7 %, the fused input projection: +3-4 %); streams with a time-constant gi (the
+// decoders) gain nothing (-0.5 %) and H <= 128 loses 1-4 % (a step's K loop is too short for the second barrier) -> lock-step there
+static bool gru_skew_auto(int H, const GruFwdParams& P) {
+    if (H != 256 && H != 192) return false;
+    for (int i = 0; i < P.nstreams; ++i)
+        if (P.s[i].xf == 0 && P.s[i].gi_t == 0) return false;
+    return true;
+}
 
 template <int H>
-static void launch_fwd(const GruFwdParams& P, hipStream_t st) {
+static void launch_fwd(const GruFwdParams& P_, hipStream_t st) {
+    GruFwdParams P = P_;
+    GRU_TUNING_OVERRIDES(P);
 #if !defined(VAME_EMU) && defined(VAME_GEMM_AB)
     if (H == 256) switch (abl_env("VAME_ABL_FWD")) {      // profiling-only ablations, tuning build (make ab) only
         ABL_CASE(gru_seq_fwd_kernel, 256, 1, P, st) ABL_CASE(gru_seq_fwd_kernel, 256, 2, P, st) ABL_CASE(gru_seq_fwd_kernel, 256, 4, P, st)
@@ -937,6 +1210,14 @@ static void launch_fwd(const GruFwdParams& P, hipStream_t st) {
         default: break;
     }
 #endif
+    if constexpr (H % 64 == 0) {
+        // two wave groups half a step apart (gru_skew_fwd_kernel): bit-identical to the lock-step kernel
+        if (P.kernel == VAME_GRU_KERNEL_SKEWED || (P.kernel == VAME_GRU_KERNEL_AUTO && gru_skew_auto(H, P))) {
+            if (P.s[0].xf > 0) hipLaunchKernelGGL((gru_skew_fwd_kernel<H, true>), dim3(grid_blocks(P.nstreams, P.ntiles)), dim3(H / 32 * 64), 0, st, P);
+            else hipLaunchKernelGGL((gru_skew_fwd_kernel<H, false>), dim3(grid_blocks(P.nstreams, P.ntiles)), dim3(H / 32 * 64), 0, st, P);
+            return;
+        }
+    }
     if (P.s[0].xf > 0) hipLaunchKernelGGL((gru_seq_fwd_kernel<H, 0, true>), dim3(grid_blocks(P.nstreams, P.ntiles)), dim3(H / 32 * 64), 0, st, P);
     else hipLaunchKernelGGL((gru_seq_fwd_kernel<H, 0, false>), dim3(grid_blocks(P.nstreams, P.ntiles)), dim3(H / 32 * 64), 0, st, P);
 }
@@ -976,11 +1257,19 @@ static void launch_bwd(const GruBwdParams& P_, hipStream_t st) {
     hipLaunchKernelGGL((gru_seq_bwd_kernel<H, 0>), dim3(grid_blocks(P.nstreams, P.ntiles)), dim3(H / 32 * 64), 0, st, P);
 }
 
+extern "C" int vame_gru_seq_fwd_has_kernel(int H, int kernel) {
+    if (H < 32 || H > 256 || H % 32) return 0;
+    if (kernel == VAME_GRU_KERNEL_SKEWED) return H % 64 == 0;
+    return kernel == VAME_GRU_KERNEL_AUTO || kernel == VAME_GRU_KERNEL_LOCKSTEP;
+}
+
 extern "C" int vame_gru_seq_fwd_f32(const int64_t* desc, int nstreams, int B, int H, void* stream) {
     VAME_CHECK_ARG(desc && nstreams >= 1 && nstreams <= 8, VAME_E_BADARG, "gru_seq_fwd: nstreams=%d not in 1..8", nstreams);
     VAME_CHECK_ARG(B >= 1, VAME_E_SHAPE, "gru_seq_fwd: empty batch");
     GruFwdParams P;
     if (int rc = gru_parse_fwd(desc, nstreams, B, P)) return rc;
+    VAME_CHECK_ARG(vame_gru_seq_fwd_has_kernel(H, P.kernel) || H > 256 || H % 32, VAME_E_UNSUPPORTED,
+                   "gru_seq_fwd: kernel option %d is not instantiated for H=%d", P.kernel, H);
     hipStream_t st = (hipStream_t)stream;
     switch (H) {
         case 32: launch_fwd<32>(P, st); break;
@@ -1008,8 +1297,8 @@ extern "C" int vame_gru_seq_bwd_f32(const int64_t* desc, int nstreams, int B, in
     VAME_CHECK_ARG(B >= 1, VAME_E_SHAPE, "gru_seq_bwd: empty batch");
     GruBwdParams P;
     if (int rc = gru_parse_bwd(desc, nstreams, B, P)) return rc;
-    VAME_CHECK_ARG(P.kernel != VAME_GRU_KERNEL_WS || vame_gru_seq_bwd_has_kernel(H, VAME_GRU_KERNEL_WS), VAME_E_UNSUPPORTED,
-                   "gru_seq_bwd: the wave-specialised kernel is not instantiated for H=%d", H);
+    VAME_CHECK_ARG(vame_gru_seq_bwd_has_kernel(H, P.kernel) || H > 256 || H % 32, VAME_E_UNSUPPORTED,
+                   "gru_seq_bwd: kernel option %d is not instantiated for H=%d", P.kernel, H);
     hipStream_t st = (hipStream_t)stream;
     switch (H) {
         case 32: launch_bwd<32>(P, st); break;

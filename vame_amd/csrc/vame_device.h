@@ -12,6 +12,7 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 #define VAME_DYN_SMEM(name) char* name = emu::dyn_smem()
 #define SETPRIO(n)
 #define VAME_SLEEP4()
+#define LDS_BARRIER() __syncthreads()
 #define WAVE_SYNC() emu::wave_sync()      /* lanes are fibers on the host: a wave-private LDS exchange needs an explicit rendezvous */
 #define SCHED_FENCE()
 #define RING_FENCE()
@@ -32,6 +33,11 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));      /* pairs for the p
 #define VAME_DYN_SMEM(name) extern __shared__ __attribute__((aligned(16))) char name[]
 #define SETPRIO(n) __builtin_amdgcn_s_setprio(n)
 #define VAME_SLEEP4() __builtin_amdgcn_s_sleep(4)      /* ~256 cycles off the issue ports */
+// Workgroup barrier that orders LDS traffic only: this wave's LDS operations have completed (lgkmcnt(0)), then s_barrier.  Unlike
+// __syncthreads() it does not drain the vector-memory queue (hipcc puts s_waitcnt vmcnt(0) in front of that barrier whenever it knows
+// of outstanding global loads / stores, and the in-order counter then also waits for the inline-asm weight ring), so global stores and
+// ring loads stay in flight across it.  For barriers that publish LDS data to the other waves of the workgroup and nothing else.
+#define LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 #define WAVE_SYNC() __builtin_amdgcn_wave_barrier()   /* lanes of a wave run in lock step and its LDS accesses complete in order: ordering hint only */
 #define SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)   /* keep the scheduler from merging phases (register pressure) */
 #define RING_FENCE() __builtin_amdgcn_sched_barrier(0)    /* prefetch-ring refills stay behind the MFMAs that read the slot */

@@ -12,7 +12,7 @@ GB = dict(STASH=0, Y=1, Y_ROW=2, Y_T=3, H0=4, H0_ROW=5, WPT=6, DY=7, DY_ROW=8, D
           DH0_ROW=14, DBIAS=15, OPT=16, T=17, REVERSE=18, PAD=19, N=20)
 # enum vame_gru_kernel / VAME_GRU_OPT(...) of include/vame_hip.h: launch options travel in the descriptor table (GF_OPT / GB_OPT of
 # stream 0), never through the process environment
-KERNEL_AUTO, KERNEL_LOCKSTEP, KERNEL_WS = 0, 1, 2
+KERNEL_AUTO, KERNEL_LOCKSTEP, KERNEL_WS, KERNEL_SKEWED = 0, 1, 2, 3
 
 
 def gru_opt(kernel=KERNEL_AUTO, pace_cp=-1, pace_ld=-1):
@@ -92,7 +92,7 @@ def gemm_group(M, N, K, As, a_kmajor, Bs, b_kmajor, C, c_offs, ldc, splitk, ws, 
 class ClockProbe:
     """Average shader clock over a stretch of the current stream (vame_clock_stamp before and after it): `start()`, work, `stop()`,
     then `mhz()` once the stream has been synchronised.  Measurement only (bench.py: roofline.clock_mhz / frac_at_clock)."""
-    NB = 64                                                  # workgroups per stamp: every XCD gets several
+    NB = 256                                                 # workgroups per stamp: a few dozen per XCD
 
     def __init__(self, dev):
         self.buf = torch.zeros(2, self.NB, 4, dtype=torch.int64, device=dev)
@@ -108,13 +108,20 @@ class ClockProbe:
         self._stamp(1)
 
     def mhz(self):
-        """Median over XCDs of d(shader ticks) / d(100 MHz ticks) x 100; None when the counters did not move (host emulator)."""
+        """Median over compute units of d(shader ticks) / d(100 MHz ticks) x 100; None when the counters did not move (host emulator).
+        Only stamps taken on the SAME compute unit (XCC id + the SE / SH / CU bits of HW_ID) are paired: s_memtime counters of
+        different CUs are offset against each other by millions of ticks (measured, tools/clock_check.py), which is harmless over a
+        460 ms region and garbage over a 30 us kernel."""
         b = self.buf.cpu().numpy()
-        vals = []
-        for x in range(16):
-            m0, m1 = b[0][b[0][:, 2] == x], b[1][b[1][:, 2] == x]
-            if len(m0) and len(m1):
-                dt, dr = int(m1[:, 0].min()) - int(m0[:, 0].min()), int(m1[:, 1].min()) - int(m0[:, 1].min())
+        first = {}
+        for t, r, xcc, hw in b[0]:
+            first.setdefault((int(xcc), int(hw) & 0xFF00), (int(t), int(r)))
+        vals, seen = [], set()
+        for t, r, xcc, hw in b[1]:
+            key = (int(xcc), int(hw) & 0xFF00)
+            if key in first and key not in seen:
+                seen.add(key)
+                dt, dr = int(t) - first[key][0], int(r) - first[key][1]
                 if dr > 0 and dt > 0:
                     vals.append(100.0 * dt / dr)
         vals.sort()
@@ -168,10 +175,15 @@ def _desc_tensor(rows, nfields):
     return d
 
 
-def gru_seq_fwd(streams, B, H, kernel=KERNEL_AUTO):
-    """streams: list of dicts keyed by GF[...] indices.  kernel: KERNEL_* (an argument of the call: GF_OPT of stream 0)."""
+def gru_seq_fwd_has_kernel(H, kernel):
+    return bool(_lib.lib().vame_gru_seq_fwd_has_kernel(int(H), int(kernel)))
+
+
+def gru_seq_fwd(streams, B, H, kernel=KERNEL_AUTO, prio=-1, delay=-1):
+    """streams: list of dicts keyed by GF[...] indices.  kernel: KERNEL_AUTO / KERNEL_LOCKSTEP / KERNEL_SKEWED (an argument of the call:
+    GF_OPT of stream 0); prio / delay: priority mode and part-0 start delay (x 256 cycles) of the skewed kernel (-1 = default)."""
     d = _desc_tensor(streams, GF["N"])
-    d[0, GF["OPT"]] = gru_opt(kernel)
+    d[0, GF["OPT"]] = gru_opt(kernel, prio, delay)
     rc = _lib.lib().vame_gru_seq_fwd_f32(d.data_ptr(), len(streams), B, H, _stream())
     _lib.check(rc, "vame_gru_seq_fwd_f32")
 
