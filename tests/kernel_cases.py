@@ -191,7 +191,7 @@ def launch_gru_fwd(rows, B, H, coop=None, coop_chunks=None):
         for chunk in (coop_chunks or [(0, 0)]):
             ops.gru_coop_fwd(rows, B, H, coop, rows=chunk)
     elif H > 256 or FORCE_WIDE:
-        ops.gru_wide_fwd(rows, B, H)
+        ops.gru_wide_fwd(rows, B, H, kernel=FWD_KERNEL)
     else:
         ops.gru_seq_fwd(rows, B, H, kernel=FWD_KERNEL)
 
@@ -340,6 +340,29 @@ def _valid_stash_mask(B, T, H):
     return np.broadcast_to(valid[:, None, None, None], (ntiles, T, NW, 5, 4, 64, 4)).reshape(-1)
 
 
+def check_gru_wide_skew_fwd(dev, H, B, T, force_wide=False):
+    """The skewed form of the two-blocks-per-wave forward kernel (gru_wide.hip: gru_wide_skew_fwd_kernel) against the oracle and bit for bit
+    against the lock-step wide kernel: per-step gi streams with and without an initial state, both directions."""
+    global FWD_KERNEL, FORCE_WIDE
+    outs = {}
+    try:
+        FORCE_WIDE = force_wide
+        for kern in (ops.KERNEL_SKEWED, ops.KERNEL_LOCKSTEP):
+            FWD_KERNEL = kern
+            if kern == ops.KERNEL_SKEWED:
+                check_gru_fwd(dev, H, B, T)
+            x, st, Y, hN = run_gru_fwd(dev, H, B, T, seed=2)
+            outs[kern] = [Y, hN] + [s_["stash"] for s_ in st]
+    finally:
+        FWD_KERNEL, FORCE_WIDE = ops.KERNEL_AUTO, False
+    valid = torch.from_numpy(_valid_stash_mask(B, T, H).copy()).to(dev)
+    for i, (a, b) in enumerate(zip(outs[ops.KERNEL_SKEWED], outs[ops.KERNEL_LOCKSTEP])):
+        if a.dim() == 1:
+            assert torch.equal(a[valid], b[valid]), f"stash {i} differs"
+        else:
+            assert torch.equal(a, b), f"output {i} differs: {float((a - b).abs().max())}"
+
+
 def check_gru_skew_fwd(dev, H, B, T):
     """The skewed forward kernel (gru_seq.hip: gru_skew_fwd_kernel -- the two waves of a SIMD half a step apart) against the numpy oracle
     and BIT FOR BIT against the lock-step kernel (same arithmetic in the same order): h sequence, final state, BPTT stash -- for per-step gi
@@ -458,12 +481,13 @@ def check_gru_kernel_option_is_an_argument(dev):
     """The kernel choice is a field of the descriptor (GB_OPT), validated per call: an unknown value is refused, the wave-specialised
     kernel is refused for a hidden size it is not instantiated for, and the library reads no environment variable for it."""
     from vame_amd import _lib
-    H, B, T = 64, 32, 2
+    H, B, T = 96, 32, 2
     x, st, Y, hN = run_gru_fwd(dev, H, B, T, seed=1)
     dYt, dhNt = torch.zeros(B, T, 2 * H, device=dev), torch.zeros(B, 2 * H, device=dev)
     global BWD_KERNEL
     try:
         assert not ops.gru_seq_bwd_has_kernel(H, ops.KERNEL_WS) and ops.gru_seq_bwd_has_kernel(H, ops.KERNEL_LOCKSTEP)
+        assert ops.gru_seq_bwd_has_kernel(192, ops.KERNEL_WS) and ops.gru_seq_fwd_has_kernel(192, ops.KERNEL_SKEWED) and not ops.gru_seq_fwd_has_kernel(96, ops.KERNEL_SKEWED)
         assert ops.gru_seq_bwd_has_kernel(256, ops.KERNEL_WS) and not ops.gru_seq_bwd_has_kernel(512, ops.KERNEL_AUTO)
         BWD_KERNEL = ops.KERNEL_WS
         with pytest.raises(_lib.VameHipError, match="not instantiated"):

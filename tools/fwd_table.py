@@ -71,7 +71,12 @@ def timed(rows, H, kernel, prio, n=3, delay=-1):
     ts = []
     for _ in range(n):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record(); ops.gru_seq_fwd(rows, B, H, kernel=kernel, prio=prio, delay=delay); e1.record(); torch.cuda.synchronize()
+        e0.record()
+        if H > 256:
+            for i in range(0, len(rows), 2): ops.gru_wide_fwd(rows[i:i + 2], B, H, kernel=kernel)
+        else:
+            ops.gru_seq_fwd(rows, B, H, kernel=kernel, prio=prio, delay=delay)
+        e1.record(); torch.cuda.synchronize()
         ts.append(e0.elapsed_time(e1) * 1e3)
     return ts
 
@@ -79,10 +84,12 @@ def timed(rows, H, kernel, prio, n=3, delay=-1):
 def main():
   print(f"B={B} T={T}; us per launch (median of 18, interleaved), TF = algorithmic flops / time")
   for H in SIZES:
-      for form in ("gi", "xin", "dec"):
+      for form in (("gi", "xin", "dec") if H <= 256 else ("gi", "dec")):
           rows, flops, keep = rows_for(form, H)
           variants = [("lock-step", ops.KERNEL_LOCKSTEP, -1)]
-          if ops.gru_seq_fwd_has_kernel(H, ops.KERNEL_SKEWED):
+          if H > 256:
+              variants += [("skewed", ops.KERNEL_SKEWED, -1)] if H % 128 == 0 else []
+          elif ops.gru_seq_fwd_has_kernel(H, ops.KERNEL_SKEWED):
               variants += [(f"skew d{d}", ops.KERNEL_SKEWED, d) for d in DELAYS]
           for _ in range(4):
               for _, k, d in variants: timed(rows, H, k, 0, 2, delay=d)

@@ -891,7 +891,7 @@ __global__ __launch_bounds__(H / 32 * 64) void gru_seq_bwd_kernel(GruBwdParams P
 template <int H, int ABL = 0>
 __global__ __launch_bounds__(H / 32 * 64) void gru_ws_bwd_kernel(GruBwdParams P) {
     constexpr int NW = H / 32, MW = NW / 2, K3 = 3 * H, LDG = K3 + 4, KC = K3 / 8;
-    static_assert(NW % 2 == 0 && 32 % MW == 0, "wave-specialised BPTT: H must be 64 * {1, 2, 4, 8}");
+    static_assert(NW % 2 == 0, "wave-specialised BPTT: H a multiple of 64 (an even number of waves)");
     __shared__ float gs[32 * LDG];                          // per row [da_r | da_z | dgh_n]: the MFMA A operand
     __shared__ float4 xd[NW * 4 * 64];                      // [col-block][q][lane]: dh (after barrier 2) / carry (after barrier 1)
     int sidx, tile;
@@ -1124,8 +1124,7 @@ __global__ __launch_bounds__(H / 32 * 64) void gru_ws_bwd_kernel(GruBwdParams P)
             }
             if (!(ABL & 1)) {
 #pragma unroll 2
-                for (int g = 0; g < 32 / MW; ++g) {
-                    const int row = MW * g + k;
+                for (int row = k; row < 32; row += MW) {
                     const uint32_t s_row = UNIFORM(s_t + (uint32_t)row * dg_row_b);
 #pragma unroll
                     for (int it = 0; it < (K3 / 4 + 63) / 64; ++it)
@@ -1183,11 +1182,12 @@ static void tuning_overrides(GruFwdParams& Q) {
 #endif
 #define ABL_CASE(K, H, A, P, st) case A: hipLaunchKernelGGL((K<H, A>), dim3(grid_blocks(P.nstreams, P.ntiles)), dim3(H / 32 * 64), 0, st, P); return;
 
-// Kernel choice for BPTT (GB_OPT of stream 0, include/vame_hip.h): AUTO = the wave-specialised kernel at H = 256 (measured: 102 -> 120 TF
-// at batch 4096, faster down to batch 100) and the lock-step kernel elsewhere (at H = 128 a step's contraction is four times shorter and
-// the serial coefficient phase weighs more: measured slower, instantiated for the tests and for callers that ask for it).
-template <int H> static constexpr bool gru_ws_instantiated() { return H == 256 || H == 128; }
-static bool gru_ws_auto(int H) { return H == 256; }
+// Kernel choice for BPTT (GB_OPT of stream 0, include/vame_hip.h): AUTO = the wave-specialised kernel at H = 256 (102 -> 120 TF at batch
+// 4096, faster down to batch 100) and H = 192 (+18 %), the lock-step kernel elsewhere (H = 128 / 64: a step's contraction is 4x / 16x
+// shorter and the serial coefficient phase weighs more -- measured 12-16 % slower; instantiated for every multiple of 64 for the tests and
+// for callers that ask).  tools/bwd_table.py, profiles/r04_bwd_table.txt.
+template <int H> static constexpr bool gru_ws_instantiated() { return H % 64 == 0; }
+static bool gru_ws_auto(int H) { return H == 256 || H == 192; }      // measured per hidden size: profiles/r04_bwd_table.txt
 // forward: AUTO = the skewed kernel where it measured faster (tools/fwd_table.py, profiles/r04_fwd_table.txt): H = 256 and 192 for streams
 // that read something every step (a per-step gi tile: +6-7 %, the fused input projection: +3-4 %); streams with a time-constant gi (the
 // decoders) gain nothing (-0.5 %) and H <= 128 loses 1-4 % (a step's K loop is too short for the second barrier) -> lock-step there
@@ -1288,7 +1288,7 @@ extern "C" int vame_gru_seq_fwd_f32(const int64_t* desc, int nstreams, int B, in
 
 extern "C" int vame_gru_seq_bwd_has_kernel(int H, int kernel) {
     if (H < 32 || H > 256 || H % 32) return 0;
-    if (kernel == VAME_GRU_KERNEL_WS) return H == 256 || H == 128;
+    if (kernel == VAME_GRU_KERNEL_WS) return H % 64 == 0;
     return kernel == VAME_GRU_KERNEL_AUTO || kernel == VAME_GRU_KERNEL_LOCKSTEP;
 }
 

@@ -149,6 +149,12 @@ class VAEEngine:
         # CU's registers and LDS free -- unlike the GRU launches, which need whole CUs (a solve beside them was measured to cost
         # as much as it saves).  Joined before dz reads Minv and before the loss terms are handed out.
         self.nuc_side = os.environ.get("VAME_AMD_NUC_SIDE", "1") != "0"
+        # Small batches: the decoders' BPTT launch is the cooperative column-split kernel, one workgroup on EVERY CU, and the solve's single
+        # workgroup still holds a CU when it starts (their LDS footprints exclude each other: 153 KB + 98 KB), so one 8-member group of the
+        # launch starts late.  Measured at batch 256 (tools/step_ab.py, profiles/r04_b256_overlap.txt): joining the solve in front of that
+        # launch 2.873 ms/step, leaving them side by side 2.790, no side stream at all 2.961 -- the late group costs less than the
+        # serialisation, and its members' waits are bounded polls of 0.3 s against a 0.2 ms solve.  True = join (diagnostics).
+        self.nuc_join_before_coop = False
         # the future decoder's two dW_hh contractions beside the small-kernel chain that follows the decoders' BPTT launch (_early_wgrads)
         self.bwd_overlap = os.environ.get("VAME_AMD_BWD_OVERLAP", "1") != "0"
         self.skinny_side = os.environ.get("VAME_AMD_SKINNY_SIDE", "1") != "0"
@@ -473,7 +479,7 @@ class VAEEngine:
             part_rows = [r for r in rows if r["_s"].d.H == H]
             if self._wide(H):
                 for i in range(0, len(part_rows), 2):                # two streams per launch: one XCD parity class each
-                    ops.gru_wide_fwd(part_rows[i:i + 2], B, H)
+                    ops.gru_wide_fwd(part_rows[i:i + 2], B, H, kernel=self.gru_fwd_kernel if (self.gru_fwd_kernel != ops.KERNEL_SKEWED or H % 128 == 0) else ops.KERNEL_AUTO)
                 continue
             if self._stepwise(H):
                 for r in part_rows:
@@ -485,7 +491,8 @@ class VAEEngine:
                     ops.gru_coop_fwd(part, B, H, self._coop_state, rows=chunk)
                 if parts:
                     continue
-            ops.gru_seq_fwd(part_rows, B, H, kernel=self.gru_fwd_kernel)
+            k = self.gru_fwd_kernel
+            ops.gru_seq_fwd(part_rows, B, H, kernel=k if ops.gru_seq_fwd_has_kernel(H, k) else ops.KERNEL_AUTO)
 
     def _gru_bwd(self, rows, B):
         for H in sorted({r["_s"].d.H for r in rows}, reverse=True):
@@ -864,12 +871,9 @@ class VAEEngine:
             rows_f, per_f, Yf, dhid_f = self._decoder_backward("fut", "decoder_future", self.fut, FS, self.buf("dfut", B, FS, F), B, dz, False)
             rows += rows_f
             groups.append(("decoder_future", per_f, Yf, dhid_f, FS))
-        if self._nuc_event is not None and any(self._coop_parts([r for r in rows if r["_s"].d.H == hh_], B, GB["T"], hh_)
-                                               for hh_ in {r["_s"].d.H for r in rows}):
-            # small batches: the BPTT launch is the cooperative column-split kernel (one co-resident workgroup per CU, members spin on
-            # each other) -- the side stream's single-workgroup solve must not hold a CU beside it (the heads / MSE kernels it was
-            # meant to overlap take microseconds at these sizes), so it is joined here instead of before dz
-            self.join_cluster()
+        if self.nuc_join_before_coop and self._nuc_event is not None and any(
+                self._coop_parts([r for r in rows if r["_s"].d.H == hh_], B, GB["T"], hh_) for hh_ in {r["_s"].d.H for r in rows}):
+            self.join_cluster()                  # (off by default: see nuc_join_before_coop)
         self._gru_bwd(rows, B)
         ev_dec = None
         if self.bwd_overlap and self.dev.type == "cuda" and s.future:

@@ -336,9 +336,11 @@ def gru_wide_supported(H):
     return bool(_lib.lib().vame_gru_wide_supported(H))
 
 
-def gru_wide_fwd(streams, B, H):
-    """Persistent forward for 256 < H <= 512 (gru_wide.hip); same `streams` table as gru_seq_fwd."""
+def gru_wide_fwd(streams, B, H, kernel=KERNEL_AUTO):
+    """Persistent forward for 256 < H <= 512 (gru_wide.hip); same `streams` table as gru_seq_fwd.  kernel: KERNEL_AUTO / KERNEL_LOCKSTEP /
+    KERNEL_SKEWED (H a multiple of 128)."""
     d = _desc_tensor(streams, GF["N"])
+    d[0, GF["OPT"]] = gru_opt(kernel)
     rc = _lib.lib().vame_gru_wide_fwd_f32(d.data_ptr(), len(streams), B, H, _stream())
     _lib.check(rc, "vame_gru_wide_fwd_f32")
 
