@@ -141,8 +141,8 @@ __global__ __launch_bounds__(256) void gru_coop_fwd_kernel(GruFwdParams P, int* 
             }
         }
         __syncthreads();
+        f32x16 ca, cb, us, rs;                  // wave 2: the step's BPTT coefficients, stored BEHIND the hand-off (see below)
         if (w == 2) {
-            f32x16 ca, cb, us, rs;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const float rr = ex[(CR(r) + lrow) * LDE + li], uu = ex[32 * LDE + (CR(r) + lrow) * LDE + li];
@@ -156,7 +156,12 @@ __global__ __launch_bounds__(256) void gru_coop_fwd_kernel(GruFwdParams P, int* 
                 hprev[r] = hv;
                 hx[(CR(r) + lrow) * LDX + li] = hv;
             }
-            if (stash) {
+        }
+        // the stash leaves AFTER the slice of h_t has been published and the flag raised (round 4): in front of the publish its 20 KB of
+        // stores sat in wave 2's queue ahead of the drain every member of the group is waiting for; behind it they overlap the poll and
+        // the tile read, and the next step's drain comes a whole step later
+        auto store_stash = [&]() {
+            if (w == 2 && stash) {
                 float4* sp = stash + ((((int64_t)tile * T + t) * NM + m) * 20) * 64 + lane;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
@@ -167,7 +172,7 @@ __global__ __launch_bounds__(256) void gru_coop_fwd_kernel(GruFwdParams P, int* 
                     sp[(4 * 4 + q) * 64] = make_float4(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]);
                 }
             }
-        }
+        };
         if (w < 3 && step + 1 < T && S.gi_t != 0) gcur = gnext;
         __syncthreads();
         // ---- publish this member's 32 x 32 slice of h_t into the sequence tensor (write-through), then raise the flag
@@ -177,8 +182,9 @@ __global__ __launch_bounds__(256) void gru_coop_fwd_kernel(GruFwdParams P, int* 
         }
         COOP_DRAIN();
         __syncthreads();
-        if (step + 1 == T) break;
+        if (step + 1 == T) { store_stash(); break; }
         if (tid == 0) COOP_FLAG_STORE(&gflags[m], (int)((unsigned)base + (unsigned)step + 1u));
+        store_stash();
         // ---- wait for all members' slices of h_t, then rebuild the full 32 x H tile in LDS
         if (tid < NM) {
             if (inject && step == 0 && tid == 0) atomicAdd(status, 1);          // fault injection (diagnostics): report, then wait normally

@@ -244,7 +244,11 @@ class VAEEngine:
         groups, rest = {}, []
         for j in jobs:
             M, N, K, A, Bop, gname, row_off, gap_at, gap = j
-            if M > 32 and K >= 8 * 256 and row_off == 0:          # (M <= 32: the 24/30-row heads keep their own skinny-M tile)
+            # large K: (M <= 32: the 24/30-row heads keep their own skinny-M tile).  Small K (K = batch <= 2048: the contractions
+            # over the batch alone -- decoders' dW_ih, latent_to_hidden, Lambda): every such launch is a chain of <= 8 dependent k-tiles
+            # on a handful of workgroups, 12-17 us of latency each whatever its size, so same-shape ones leave as one grouped launch
+            # of single-k-tile workgroups + one reduction, any M
+            if row_off == 0 and ((M > 32 and K >= 8 * 256) or (256 <= K < 8 * 256 and _slabs(K, 8) >= 8)):
                 key = (M, N, K, A.ld, A.seg, A.seg_stride, Bop.ld, Bop.seg, Bop.seg_stride, gap_at, gap)
                 groups.setdefault(key, []).append(j)
             else:
@@ -955,6 +959,12 @@ class VAEEngine:
         self._flush_wgrads()
         ops.colsum_batch(self._colsum_jobs)
         self._colsum_jobs = []
+
+
+def _slabs(K, sk):
+    """k-slabs vame_gemm_f32 / vame_gemm_group_f32 make of K for a requested split-K of sk (slabs are whole 32-row k-tiles)."""
+    kper = -(-(-(-K // sk)) // 32) * 32
+    return -(-K // kper)
 
 
 def _numel(shape):
