@@ -131,7 +131,16 @@ def profile_kernels(model, loader, B, steps=3):
             key_t = ops.GF["T"] if tag == "fwd" else ops.GB["T"]
             fl = sum(2.0 * 3 * Hh * Hh * B_ * int(s[key_t]) for s in streams)
             name = "gru_seq" if Hh <= 256 else "gru_wide"
-            return (f"{name}_{tag}_kernel<{Hh}> x{len(streams)} streams", fl)
+            # launches of one kernel family that stream different things are different roofline rows: the fused input projection (`xin`),
+            # a per-step gi tile (`gi`), a time-constant gi (`const-gi`: the decoders); T = steps of the longest stream
+            form = ""
+            if tag == "fwd":
+                s0 = streams[0]
+                form = " xin" if s0.get(ops.GF["WPX"]) else (" gi" if int(s0[ops.GF["GI_T"]]) != 0 else " const-gi")
+            else:
+                form = " dy" if streams[0].get(ops.GB["DY"]) else " no-dy"      # BPTT with / without a gradient tile per step (encoder layer 1 has none)
+            steps_ = max(int(s[key_t]) for s in streams)
+            return (f"{name}_{tag}_kernel<{Hh}> x{len(streams)} streams{form} T={steps_}", fl)
         return f
 
     def coop_flops(tag):       # column-split GRU launches of the small-batch path: rows = (row0, nrows) restricts the launch to a row range
@@ -510,7 +519,7 @@ def embed_leg(dev, n_win_per_rank, rank, world, H=256, T=30):
                 roofline=dict(bound="mfma", unit="TFLOP/s", peak=PEAK_F32_MFMA_TFLOPS, achieved=round(tf, 2),
                               frac=round(tf / PEAK_F32_MFMA_TFLOPS, 4), clock_mhz=round(mhz, 0) if mhz else None,
                               frac_at_clock=at_clock(tf / PEAK_F32_MFMA_TFLOPS, mhz),
-                              traffic=pmc_traffic("gru_seq_fwd_kernel<256> x2 streams embed") if dev.type == "cuda" else None))
+                              traffic=pmc_traffic("gru_seq_fwd_kernel<256> x2 streams gi T=30 embed") if dev.type == "cuda" else None))
 
 
 def workload_name(H, T, B, world):

@@ -64,3 +64,15 @@ def test_bench_line_contract(hip):
     assert j["repeat_spread"]["regions"] == 3 and j["repeat_spread"]["min"] <= j["value"] <= j["repeat_spread"]["max"] * 1.0001
     also = j["also"]
     assert also["configs3_h512_t60_b8192"]["value"] > 5_000 and also["configs4_embed_1gpu"]["value"] > 100_000
+    # round 4: the box's sustained shader clock rides on every roofline block (vame_clock_stamp around the dominant launches / the
+    # timed region) with the fraction restated against it, and the reference's stock-config batch is a leg of the default line whose
+    # per-class table includes the cooperative GRU launches that batch runs on
+    for blk in (roof, also["configs3_h512_t60_b8192"]["roofline"], also["batch256"]["roofline"]):
+        assert 1500 < blk["clock_mhz"] < 2600 and 1500 < blk["clock_mhz_timed_region"] < 2600, blk["clock_mhz"]
+        assert abs(blk["frac_at_clock"] - blk["frac"] * 2400.0 / blk["clock_mhz"]) < 5e-3
+        assert abs(blk["step_frac_at_clock"] - blk["step_frac"] * 2400.0 / blk["clock_mhz_timed_region"]) < 5e-3
+    assert 1500 < also["configs4_embed_1gpu"]["roofline"]["clock_mhz"] < 2600
+    assert all(1500 < v["clock_mhz"] < 2600 for k, v in roof["by_class"].items() if v.get("bound") != "hbm")
+    b256 = also["batch256"]
+    assert b256["value"] > 30_000 and b256["steps"] == 30 and "batch=256" in b256["config"]["workload"]
+    assert {"gru_coop_fwd_kernel<256>", "gru_coop_bwd_kernel<256>"} <= set(b256["roofline"]["by_class"])

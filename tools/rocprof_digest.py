@@ -69,13 +69,28 @@ def trace(d, out, stats_only=False):
     print("wrote", out, len(rows), "dispatches")
 
 
-def pmc(fetch_dir, write_dir, lib, out, keys):
+def pmc(fetch_dir, write_dir, lib, out, keys, cycles=()):
+    """cycles: "<kernel substring>@<grid>=label1,label2,..." -- the dispatches of that (kernel, grid) in dispatch order are labelled
+    cyclically (launches of one kernel and grid that differ in what they stream, e.g. the four forward GRU launches of a step: encoder
+    layer 0, layer 1, decoder, future decoder), and every label is summarised on its own as "<kernel> grid=<g> [label]"."""
+    cyc = []
+    for spec in cycles:
+        sel, labels = spec.split("=", 1)
+        sub, grid = sel.rsplit("@", 1)
+        cyc.append((sub, int(grid), labels.split(",")))
+
     def collect(d, counter):
-        agg = {}
-        for r in rows_of(d, "counter_collection.csv"):
-            if r["Counter_Name"] != counter:
-                continue
-            k = (short(r["Kernel_Name"]), int(r["Grid_Size"]))
+        rows = [r for r in rows_of(d, "counter_collection.csv") if r["Counter_Name"] == counter]
+        rows.sort(key=lambda r: int(r.get("Dispatch_Id", 0) or 0))
+        agg, seen = {}, {}
+        for r in rows:
+            name, grid = short(r["Kernel_Name"]), int(r["Grid_Size"])
+            label = ""
+            for sub, g, labels in cyc:
+                if sub in name and g == grid:
+                    i = seen.setdefault((name, grid), {}).setdefault(r.get("Dispatch_Id"), len(seen[(name, grid)]))
+                    label = " [" + labels[i % len(labels)] + "]"
+            k = (name + label, grid)
             a = agg.setdefault(k, [0, 0.0])
             a[0] += 1; a[1] += float(r["Counter_Value"])
         return agg
@@ -85,7 +100,8 @@ def pmc(fetch_dir, write_dir, lib, out, keys):
         fk = f.get(k, [0, 0.0]); wk = w.get(k, [0, 0.0])
         calls = max(fk[0], wk[0])
         fetch_kb = fk[1] / max(fk[0], 1); write_kb = wk[1] / max(wk[0], 1)
-        kernels[f"{k[0]} grid={k[1]}"] = dict(calls=calls, fetch_kb_per_call=round(fetch_kb, 1), write_kb_per_call=round(write_kb, 1),
+        nm, lab = (k[0].split(" [")[0], " [" + k[0].split(" [")[1]) if " [" in k[0] else (k[0], "")
+        kernels[f"{nm} grid={k[1]}{lab}"] = dict(calls=calls, fetch_kb_per_call=round(fetch_kb, 1), write_kb_per_call=round(write_kb, 1),
                                              hbm_bytes_per_call_corrected=int((2 * fetch_kb + write_kb) * 1024))
     import ctypes
     L = ctypes.CDLL(lib)
@@ -94,8 +110,12 @@ def pmc(fetch_dir, write_dir, lib, out, keys):
     by_key = {}
     for spec in keys:
         bench_key, sel = spec.split("=>", 1)                    # "<bench key>=><kernel substring>@<grid>"
-        sub, grid = sel.rsplit("@", 1)
-        hits = [v for k, v in kernels.items() if sub in k and k.endswith(f"grid={grid}")]
+        sub, grid = sel.rsplit("@", 1)                           # "<grid>" or "<grid>[label]" (a label given by --cycle)
+        lab = None
+        if "[" in grid:
+            grid, lab = grid.split("[", 1)
+            lab = lab.rstrip("]")
+        hits = [v for k, v in kernels.items() if sub in k and (k.endswith(f"grid={grid} [{lab}]") if lab else k.endswith(f"grid={grid}"))]
         if len(hits) != 1:
             raise SystemExit(f"key {bench_key!r}: {len(hits)} kernels match {sub!r} @ {grid}")
         by_key[bench_key] = dict(kernel=sub, grid_threads=int(grid), hbm_bytes_per_launch_corrected=hits[0]["hbm_bytes_per_call_corrected"],
@@ -136,6 +156,7 @@ if __name__ == "__main__":
         sq(sys.argv[2], sys.argv[3], sys.argv[4] if len(sys.argv) > 4 else "")
     elif cmd == "pmc":
         keys = [sys.argv[i + 1] for i, a in enumerate(sys.argv) if a == "--key"]
-        pmc(sys.argv[2], sys.argv[3], sys.argv[4], sys.argv[5], keys)
+        cycles = [sys.argv[i + 1] for i, a in enumerate(sys.argv) if a == "--cycle"]
+        pmc(sys.argv[2], sys.argv[3], sys.argv[4], sys.argv[5], keys, cycles)
     else:
         raise SystemExit(__doc__)

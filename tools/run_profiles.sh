@@ -21,11 +21,16 @@ python tools/rocprof_digest.py trace $O/raw_trace $O/kernel_trace.csv
 python tools/rocprof_digest.py stats $O/raw_trace $O/kernel_stats.csv
 python tools/rocprof_digest.py pmc $O/raw_fetch $O/raw_write vame_amd/libvame_hip.so $O/pmc_hbm_traffic.json \
   --key "gemm_kernel TN M=768 N=256 K=122880 x6 grouped=>gemm_kernel<128,128,2,2,true,true,5,2>@589824" \
-  --key "gru_seq_bwd_kernel<256> x2 streams=>gru_ws_bwd_kernel<256,0>@131072" --key "gru_seq_fwd_kernel<256> x2 streams=>gru_seq_fwd_kernel<256,0,false>@131072"
+  --cycle "gru_ws_bwd_kernel<256,0>@131072=enc-l1,enc-l0" \
+  --key "gru_seq_bwd_kernel<256> x2 streams no-dy T=30=>gru_ws_bwd_kernel<256,0>@131072[enc-l1]" --key "gru_seq_bwd_kernel<256> x2 streams dy T=30=>gru_ws_bwd_kernel<256,0>@131072[enc-l0]" --key "gru_seq_fwd_kernel<256> x2 streams gi T=30=>gru_skew_fwd_kernel<256,false>@131072" \
+  --key "gru_seq_fwd_kernel<256> x2 streams xin T=30=>gru_skew_fwd_kernel<256,true>@131072" --key "gru_seq_fwd_kernel<256> x4 streams const-gi T=30=>gru_seq_fwd_kernel<256,0,false>@262144"
 python tools/rocprof_digest.py pmc $O/raw_fetch4 $O/raw_write4 vame_amd/libvame_hip.so $O/cfg4_pmc_hbm_traffic.json \
-  --key "gru_wide_fwd_kernel<512> x2 streams=>gru_wide_fwd_kernel<512>@262144" --key "gru_wide_bwd_kernel<512> x2 streams=>gru_wide_bwd_kernel<512,false>@262144"
+  --cycle "gru_wide_skew_fwd_kernel<512>@262144=enc-l0,enc-l1,dec,fut" --cycle "gru_wide_bwd_kernel<512,false>@262144=dec,fut,enc-l1,enc-l0" \
+  --key "gru_wide_fwd_kernel<512> x2 streams gi T=60=>gru_wide_skew_fwd_kernel<512>@262144[enc-l1]" --key "gru_wide_fwd_kernel<512> x2 streams const-gi T=60=>gru_wide_skew_fwd_kernel<512>@262144[dec]" \
+  --key "gru_wide_fwd_kernel<512> x2 streams const-gi T=15=>gru_wide_skew_fwd_kernel<512>@262144[fut]" --key "gru_wide_bwd_kernel<512> x2 streams no-dy T=60=>gru_wide_bwd_kernel<512,false>@262144[enc-l1]" \
+  --key "gru_wide_bwd_kernel<512> x2 streams dy T=60=>gru_wide_bwd_kernel<512,false>@262144[enc-l0]"
 python tools/rocprof_digest.py pmc $O/raw_fetche $O/raw_writee vame_amd/libvame_hip.so $O/embed_pmc_hbm_traffic.json \
-  --key "gru_seq_fwd_kernel<256> x2 streams embed=>gru_seq_fwd_kernel<256,0,false>@524288"
+  --key "gru_seq_fwd_kernel<256> x2 streams gi T=30 embed=>gru_skew_fwd_kernel<256,false>@524288"
 python tools/rocprof_digest.py sq $O/raw_sq $O/pmc_sq_cfg2.json "rocprofv3 --kernel-trace --pmc SQ_* GRBM_GUI_ACTIVE -- python bench.py --no-also --steps 2 --warmup 1 (BASELINE configs[1])"
 rm -rf $O/raw_*
 # the bench line last, with the traffic summaries of this very build visible to it (bench.py looks under profiles/ for a matching source id)
