@@ -15,7 +15,22 @@ SIZES = [int(v) for v in os.environ.get("FWD_H", "256,192,128,64").split(",")]
 DELAYS = [int(v) for v in os.environ.get("FWD_DELAYS", "0,8,16,24,32").split(",")]
 
 
+NOSTASH = os.environ.get("FWD_NOSTASH", "0") != "0"      # inference form (no BPTT stash): traffic experiments
+FORMS = os.environ.get("FWD_FORMS", "").split(",") if os.environ.get("FWD_FORMS") else None
+
+
 def rows_for(form, H):
+    rows, flops, keep = _rows_for(form, H)
+    if NOSTASH:
+        for r in rows: r[GF["STASH"]] = 0
+    if os.environ.get("FWD_NOY", "0") != "0":                # no output sequence either (only the final state would leave: traffic experiments)
+        for r in rows: r[GF["Y"]] = 0; r[GF["PAD"]] = 0
+    if os.environ.get("FWD_NSTREAMS"):
+        rows = rows[:int(os.environ["FWD_NSTREAMS"])]
+    return rows, flops, keep
+
+
+def _rows_for(form, H):
     keep, rows = [], []
     F = 24
     def pack():
@@ -84,7 +99,7 @@ def timed(rows, H, kernel, prio, n=3, delay=-1):
 def main():
   print(f"B={B} T={T}; us per launch (median of 18, interleaved), TF = algorithmic flops / time")
   for H in SIZES:
-      for form in (("gi", "xin", "dec") if H <= 256 else ("gi", "dec")):
+      for form in (FORMS or (("gi", "xin", "dec") if H <= 256 else ("gi", "dec"))):
           rows, flops, keep = rows_for(form, H)
           variants = [("lock-step", ops.KERNEL_LOCKSTEP, -1)]
           if H > 256:
