@@ -51,3 +51,30 @@ def test_vame_alias_shim_installer(tmp_path):
     assert "ALIAS_OK" in r.stdout, r.stderr[-1500:]
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "install_vame_alias.py"), str(tmp_path)], capture_output=True, text=True)
     assert r.returncode != 0 and "exists" in r.stderr              # never silently overwrites an existing `vame` package
+
+
+def test_pmc_digest_labels_the_launch_forms_of_one_kernel(tmp_path):
+    """tools/rocprof_digest.py pmc --cycle: launches of one (kernel, grid) that stream different things (the four forward GRU launches
+    of a step) are summarised per form, FETCH_SIZE doubled (gfx950), and a bench key can name one form."""
+    import json
+    hdr = ["Dispatch_Id", "Grid_Size", "Kernel_Name", "Counter_Name", "Counter_Value"]
+    k = "void gru_wide_skew_fwd_kernel<512>(GruFwdParams)"
+    fetch = [[10 + i, 262144, k, "FETCH_SIZE", v] for i, v in enumerate([100.0, 300.0, 50.0, 10.0] * 2)]      # KB; dispatch order l0, l1, dec, fut
+    write = [[10 + i, 262144, k, "WRITE_SIZE", v] for i, v in enumerate([1000.0, 1000.0, 900.0, 200.0] * 2)]
+    other = [[99, 589824, "void gemm_kernel<128, 128, 2, 2, true, true, 5, 2>(GemmParams)", "FETCH_SIZE", 7.0]]
+    _write(str(tmp_path / "f" / "p" / "1_counter_collection.csv"), hdr, fetch + other)
+    _write(str(tmp_path / "w" / "p" / "1_counter_collection.csv"), hdr, write)
+    lib = os.path.join(ROOT, "tests", "emu", "libvame_emu.so")
+    if not os.path.exists(lib):
+        subprocess.run(["make", "-s", "tests/emu/libvame_emu.so"], cwd=ROOT, check=True)
+    out = str(tmp_path / "t.json")
+    subprocess.run([sys.executable, DIGEST, "pmc", str(tmp_path / "f"), str(tmp_path / "w"), lib, out,
+                    "--cycle", "gru_wide_skew_fwd_kernel<512>@262144=enc-l0,enc-l1,dec,fut",
+                    "--key", "gru_wide_fwd_kernel<512> x2 streams gi T=60=>gru_wide_skew_fwd_kernel<512>@262144[enc-l1]",
+                    "--key", "gemm=>gemm_kernel<128,128,2,2,true,true,5,2>@589824"], check=True, capture_output=True)
+    j = json.load(open(out))
+    l1 = j["kernels"]["gru_wide_skew_fwd_kernel<512> grid=262144 [enc-l1]"]
+    assert l1["calls"] == 2 and l1["fetch_kb_per_call"] == 300.0 and l1["hbm_bytes_per_call_corrected"] == (2 * 300 + 1000) * 1024
+    assert j["kernels"]["gru_wide_skew_fwd_kernel<512> grid=262144 [fut]"]["write_kb_per_call"] == 200.0
+    assert j["by_bench_key"]["gru_wide_fwd_kernel<512> x2 streams gi T=60"]["hbm_bytes_per_launch_corrected"] == 1600 * 1024
+    assert j["by_bench_key"]["gemm"]["fetch_kb_per_call"] == 7.0 and j["source_id"]
