@@ -384,6 +384,18 @@ def timed_region(step, steps, world, sync, dev, info=None):
     return dt, terms
 
 
+def release_leg(on_gpu):
+    """Between two legs of one bench process: drop everything the finished leg allocated (model, engine workspaces, the ops module's
+    scratch caches) and hand the device memory back, so that every leg starts from the allocator state of a fresh process."""
+    import gc
+    from vame_amd import ops
+    ops._ws_cache.clear()              # the module-level split-K / column-sum scratch grows to the largest leg's size and would stay
+    ops._colsum_ws.clear()             # allocated in the middle of the next leg's address range (measured: the latency-bound batch-256
+    gc.collect()                       # leg runs 2.70 ms/step in a fresh process, 2.75-2.87 behind a large leg, 2.70 again with these dropped)
+    if on_gpu:
+        torch.cuda.empty_cache()
+
+
 def train_leg(dev, H, T, B, steps, warmup, rank, world, repeats=1, profile=True, dump=False, one_rank_leg=False):
     """Build the model at (H, T), run `warmup` untimed + `repeats` timed regions of `steps` steps.  Returns a dict with the region
     times, the last loss terms, the roofline block (GPU only) and -- several ranks -- the collective's own numbers."""
@@ -423,8 +435,7 @@ def train_leg(dev, H, T, B, steps, warmup, rank, world, repeats=1, profile=True,
         agg = profile_kernels(model, loader, B)
         res["roofline"] = roofline_block(agg, B * steps / dts[0], res["mflop"], dts[0] / steps * 1e3, dump, region_mhz=res["mhz"])
     del model, opt, loader
-    if on_gpu:
-        torch.cuda.empty_cache()
+    release_leg(on_gpu)
     return res
 
 
@@ -509,8 +520,7 @@ def embed_leg(dev, n_win_per_rank, rank, world, H=256, T=30):
     tf = value / world * mflop * 1e6 / 1e12
     mhz = probe.mhz() if probe is not None else None
     del model, out
-    if dev.type == "cuda":
-        torch.cuda.empty_cache()
+    release_leg(dev.type == "cuda")
     return dict(metric=f"latent-embedding windows/sec (encoder + Lambda mean) T={T},F={F},h={H}", value=round(value, 1), unit="windows/s",
                 n_gpus=world, seconds=round(dt, 3), windows=n_win,
                 includes="host->device upload of the series + window gather + encoder + mean",
