@@ -127,6 +127,13 @@ def test_stepwise_path_small_models(hip):
     check_step("cuda", "step_h64", 0.5, stepwise=True)
 
 
+def test_hidden_sizes_above_1024_run_the_stepwise_path(hip):
+    """nn.GRU takes any hidden size (rnn_model.py:34,91,125); sizes beyond the persistent kernels run step by step (per-step MFMA GEMM +
+    gate kernels) -- a whole train step at H = 1056 (all losses, all gradients) against the numpy oracle; the engine's limit is 4096."""
+    from model_cases import check_odd_dims_vs_oracle
+    check_odd_dims_vs_oracle("cuda", F=12, Z=7, H=1056, T=3, FS=2, B=5)
+
+
 def test_cfg4_shape_h512_t60_vs_oracle(hip):
     """BASELINE config 4 shape (hidden=512, T=60, 2-layer bi-GRU encoder): per-step MFMA gate-GEMM path vs the numpy oracle."""
     T, F, Z, H, FS, B = 60, 24, 30, 512, 15, 48

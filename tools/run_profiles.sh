@@ -8,7 +8,7 @@ B="python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-also"
 B4="$B --hidden 512 --time-window 60 --batch 8192 --steps 2 --warmup 1"
 BE="python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --mode embed --embed-windows 500000"
 SQ="SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU GRBM_GUI_ACTIVE"
-timeout 400 rocprofv3 --kernel-trace --output-format csv -d $O/raw_trace -- $B --steps 10 --warmup 3 > $O/trace.log 2>&1
+timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/raw_trace -- $B --steps 10 --warmup 3 > $O/trace.log 2>&1
 timeout 400 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/raw_fetch -- $B --steps 2 --warmup 1 > $O/fetch.log 2>&1
 timeout 400 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/raw_write -- $B --steps 2 --warmup 1 > $O/write.log 2>&1
 timeout 400 rocprofv3 --kernel-trace --pmc $SQ --output-format csv -d $O/raw_sq -- $B --steps 2 --warmup 1 > $O/sq.log 2>&1
@@ -19,6 +19,7 @@ timeout 400 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/
 cd $GRAFT_REPO_ROOT
 python tools/rocprof_digest.py trace $O/raw_trace $O/kernel_trace.csv
 python tools/rocprof_digest.py stats $O/raw_trace $O/kernel_stats.csv
+cp "$(find $O/raw_trace -name '*kernel_stats.csv' | head -1)" $O/rocprof_kernel_stats.csv      # rocprofv3's own --stats summary, untouched
 python tools/rocprof_digest.py pmc $O/raw_fetch $O/raw_write vame_amd/libvame_hip.so $O/pmc_hbm_traffic.json \
   --key "gemm_kernel TN M=768 N=256 K=122880 x6 grouped=>gemm_kernel<128,128,2,2,true,true,5,2>@589824" \
   --cycle "gru_ws_bwd_kernel<256,0>@131072=enc-l1,enc-l0" \
@@ -37,4 +38,13 @@ rm -rf $O/raw_*
 for f in pmc_hbm_traffic cfg4_pmc_hbm_traffic embed_pmc_hbm_traffic; do cp $O/$f.json profiles/_this_run_$f.json; done
 timeout 600 python bench.py --dump-kernels > $O/bench.json 2> $O/bench.err; cut -c1-250 $O/bench.json
 rm -f profiles/_this_run_*.json
+# the other committed lines of a round: stock-config batch, 10 M-window embedding, 100 timed steps, kernel tables, small-batch overlap A/B
+python bench.py --batch 256 --steps 60 --warmup 15 --no-cpu-baseline --no-also > $O/b256.json 2>/dev/null
+python bench.py --mode embed --embed-windows 10000000 --no-cpu-baseline > $O/embed10m.json 2>/dev/null
+python bench.py --steps 100 --warmup 20 --no-cpu-baseline --no-also > $O/bench_100steps.json 2>/dev/null
+python -u tools/fwd_table.py 2>&1 | grep -v amdgpu > $O/fwd_table.txt
+FWD_H=512,384 FWD_DELAYS=0 python -u tools/fwd_table.py 8192 60 2>&1 | grep -v amdgpu >> $O/fwd_table.txt
+python -u tools/bwd_table.py 2>&1 | grep -v amdgpu > $O/bwd_table.txt
+python tools/step_ab.py 256 join=nuc_join_before_coop:1 nojoin=nuc_join_before_coop:0 inline=nuc_side:0 2>&1 | grep -v amdgpu > $O/b256_overlap.txt
+python tools/clock_check.py 2>&1 | grep -v amdgpu > $O/clock_check.txt
 ls -la $O

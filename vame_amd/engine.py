@@ -99,8 +99,8 @@ class VAEEngine:
         self.dev = flat_p.device
         H, F, Z, Hd, Hf = spec.H, spec.F, spec.Z, spec.Hd, spec.Hf
         for hh in (H, Hd, Hf):
-            if hh % 32 or hh > 1024:
-                raise ValueError(f"hidden size {hh}: the gfx950 GRU kernels support multiples of 32 up to 1024")
+            if hh % 32 or hh > 4096:
+                raise ValueError(f"hidden size {hh}: the gfx950 GRU kernels support multiples of 32 up to 4096 (other sizes: vame_amd.padding)")
         if spec.legacy and not (H == Hd == Hf):
             raise ValueError("RNN_VAE_LEGACY on the gfx950 kernels needs one hidden size for all GRUs")
         # H <= 256: persistent sequence kernels (h and the gate tiles stay on chip for all T steps).  Larger H: the gate
