@@ -123,9 +123,18 @@ def require_device_tensor(t):
         raise VameHipError("vame_amd ops need CUDA(HIP) tensors; there is no CPU path")
 
 
+_raw_stream = None
+
+
 def stream_handle():
-    """hipStream_t of torch's current stream: every kernel of the path is launched on it."""
+    """hipStream_t of torch's current stream: every kernel of the path is launched on it.  (The raw-handle query: building a
+    torch.cuda.Stream object per launch costs ~2 us of a host-bound small-batch step, ~110 launches.)"""
+    global _raw_stream
     import torch
+    if _raw_stream is None:
+        _raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", False)
+    if _raw_stream:
+        return _raw_stream(torch.cuda.current_device())
     return torch.cuda.current_stream().cuda_stream
 
 

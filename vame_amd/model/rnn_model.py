@@ -224,6 +224,7 @@ class RNN_VAE(nn.Module):
         self._flat_p = self._flat_g = self._flat_gtmp = None
         self._engine = None
         self._pad = None
+        self._bucket_check = None
         self._register_state_dict_hook(_clone_state_dict)
 
     def _build_modules(self, ZDIMS, NUM_FEATURES, FUTURE_DECODER, FUTURE_STEPS, h1, h2, h_rec, h_pred, d_enc, d_rec, d_pred, softplus):
@@ -238,13 +239,27 @@ class RNN_VAE(nn.Module):
         """The engine over the flat parameter bucket (built on first use / after the model moved).  touch: the caller is about to run the
         model, so the weights may have changed since the last call -> refresh the padded image and have the GRU packs rebuilt;
         bookkeeping callers (flat_parameters: optimizer, all-reduce) pass False and leave both alone."""
-        plist = list(self.named_parameters())
-        dev = plist[0][1].device
-        _lib.require_device_tensor(plist[0][1])     # "move the model with .cuda()": there is no CPU fallback
-        ok = self._flat_p is not None and self._flat_p.device == dev
+        # fast path (every step calls this; walking named_parameters() costs ~0.3 ms of a host-bound 2.5 ms step at the stock batch):
+        # the Parameter objects the flat bucket was built over still point into it.  .cuda() / .to() / .float() replace p.data (the
+        # addresses change), load_state_dict copies in place (they do not)
+        chk = self._bucket_check
+        ok = chk is not None
         if ok:
-            base, esz, tab = self._flat_p.data_ptr(), 4, self._table
-            ok = all(p.data_ptr() == base + esz * tab.off(n) for n, p in plist)
+            for p_, addr in chk:
+                if p_.data_ptr() != addr:
+                    ok = False
+                    break
+        plist = None
+        if not ok:
+            plist = list(self.named_parameters())
+            dev = plist[0][1].device
+            _lib.require_device_tensor(plist[0][1])     # "move the model with .cuda()": there is no CPU fallback
+            ok = self._flat_p is not None and self._flat_p.device == dev
+            if ok:
+                base, esz, tab = self._flat_p.data_ptr(), 4, self._table
+                ok = all(p.data_ptr() == base + esz * tab.off(n) for n, p in plist)
+                if ok:
+                    self._bucket_check = [(p, p.data_ptr()) for _, p in plist]
         if not ok:
             self._table = ParamTable([(n, p.shape) for n, p in plist])
             flat_p = torch.zeros(self._table.numel, device=dev)
@@ -259,6 +274,7 @@ class RNN_VAE(nn.Module):
             self._flat_p, self._flat_g = flat_p, flat_g
             self._flat_gtmp = torch.zeros_like(flat_g)
             self._param_list = [p for _, p in plist]
+            self._bucket_check = [(p, p.data_ptr()) for _, p in plist]
             if needs_padding(self.spec):
                 # a hidden size that is not a multiple of 32 (torch.nn.GRU takes any): the kernels run on a zero-padded image of
                 # the parameters; the model, its state_dict, the optimizer and the all-reduce keep the reference's shapes
