@@ -363,40 +363,21 @@ def check_gru_wide_skew_fwd(dev, H, B, T, force_wide=False):
             assert torch.equal(a, b), f"output {i} differs: {float((a - b).abs().max())}"
 
 
-def check_gru_wsf(dev, H, B, T):
-    """The wave-specialised forward kernel (gru_seq.hip: gru_wsf_kernel -- MFMA waves + memory waves, K split by column group) against the
-    oracle and bit for bit against the lock-step kernel: per-step gi with / without an initial state, time-constant gi with h0, inference
-    streams; the fused input projection is refused (it stays with the other kernels)."""
-    check_gru_skew_fwd(dev, H, B, T, kernel=ops.KERNEL_WS, fused=False)
-    from vame_amd import _lib
-    global FWD_KERNEL
-    try:
-        FWD_KERNEL = ops.KERNEL_WS
-        with pytest.raises(_lib.VameHipError, match="no fused input projection"):
-            check_gru_fwd_fused(dev, H, min(B, 33), 2)
-    finally:
-        FWD_KERNEL = ops.KERNEL_AUTO
-
-
-def check_gru_skew_fwd(dev, H, B, T, kernel=None, fused=True):
+def check_gru_skew_fwd(dev, H, B, T):
     """The skewed forward kernel (gru_seq.hip: gru_skew_fwd_kernel -- the two waves of a SIMD half a step apart) against the numpy oracle
     and BIT FOR BIT against the lock-step kernel (same arithmetic in the same order): h sequence, final state, BPTT stash -- for per-step gi
     streams with and without an initial state (both directions), the fused input projection, and a time-constant gi with h0 (decoder
     form).  The kernel is picked per launch by the GF_OPT descriptor field."""
     global FWD_KERNEL
-    kernel = ops.KERNEL_SKEWED if kernel is None else kernel
-    assert ops.gru_seq_fwd_has_kernel(H, kernel)
+    assert ops.gru_seq_fwd_has_kernel(H, ops.KERNEL_SKEWED)
     outs = {}
     try:
-        for kern in (kernel, ops.KERNEL_LOCKSTEP):
+        for kern in (ops.KERNEL_SKEWED, ops.KERNEL_LOCKSTEP):
             FWD_KERNEL = kern
-            if kern == kernel:
+            if kern == ops.KERNEL_SKEWED:
                 check_gru_fwd(dev, H, B, T)                       # vs the oracle
             x, st, Y, hN = run_gru_fwd(dev, H, B, T, seed=2)
-            if fused:
-                Yf, hNf, stf = check_gru_fwd_fused(dev, H, B, T)     # vs the oracle, fused input (zero initial state: skipped first K loop)
-            else:
-                Yf, hNf, stf = torch.zeros(1, 1, device=dev), torch.zeros(1, 1, device=dev), []
+            Yf, hNf, stf = check_gru_fwd_fused(dev, H, B, T)     # vs the oracle, fused input (zero initial state: skipped first K loop)
             # decoder form: gi constant in time, initial state given, one stream per direction, inference (no stash) on the reverse one
             rng = np.random.default_rng(4)
             W_ih, W_hh, b_ih, b_hh = _gru_weights(rng, 5, H)
@@ -414,7 +395,7 @@ def check_gru_skew_fwd(dev, H, B, T, kernel=None, fused=True):
     finally:
         FWD_KERNEL = ops.KERNEL_AUTO
     valid = torch.from_numpy(_valid_stash_mask(B, T, H).copy()).to(dev)
-    for i, (a, b) in enumerate(zip(outs[kernel], outs[ops.KERNEL_LOCKSTEP])):
+    for i, (a, b) in enumerate(zip(outs[ops.KERNEL_SKEWED], outs[ops.KERNEL_LOCKSTEP])):
         if a.dim() == 1:                                          # a stash: compare the entries of rows inside the batch
             assert torch.equal(a[valid], b[valid]), f"stash {i} differs"
         else:

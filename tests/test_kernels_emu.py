@@ -5,7 +5,7 @@ the CPU; the same checks run on the real GPU in test_kernels_gpu.py.
 """
 import pytest
 
-from kernel_cases import (check_head_fused, check_gemm_group_shared_output, check_gru_wide, check_gru_wide_small, check_hmm, check_adam, check_adam_abort_and_mask_scale, check_colsum, check_colsum_batch, check_kmeans, check_gather, check_gemm_cases, check_gemm_group, check_gemm_pipelined_shapes, check_gru_bwd, check_gru_skew_fwd, check_gru_wsf, check_gru_wide_skew_fwd, check_gru_ws_bwd, check_gru_kernel_option_is_an_argument, check_gru_coop_bwd, check_gru_coop_fwd, check_gru_fwd, check_gru_fwd_fused,
+from kernel_cases import (check_head_fused, check_gemm_group_shared_output, check_gru_wide, check_gru_wide_small, check_hmm, check_adam, check_adam_abort_and_mask_scale, check_colsum, check_colsum_batch, check_kmeans, check_gather, check_gemm_cases, check_gemm_group, check_gemm_pipelined_shapes, check_gru_bwd, check_gru_skew_fwd, check_gru_wide_skew_fwd, check_gru_ws_bwd, check_gru_kernel_option_is_an_argument, check_gru_coop_bwd, check_gru_coop_fwd, check_gru_fwd, check_gru_fwd_fused,
                           check_latent, check_mse, check_nuclear, check_prep_fill_rules, check_prepare_series_golden,
                           check_prepare_series_vs_oracle)
 
@@ -51,11 +51,6 @@ def test_gru_skewed_fwd(emu, H, B, T):
 @pytest.mark.parametrize("H,B,T,force", [(128, 37, 2, True), (384, 33, 2, False)])
 def test_gru_wide_skewed_fwd(emu, H, B, T, force):
     check_gru_wide_skew_fwd(DEV, H, B, T, force_wide=force)
-
-
-@pytest.mark.parametrize("H,B,T", [(64, 40, 3), (128, 37, 2), (256, 33, 2)])
-def test_gru_wave_specialised_fwd(emu, H, B, T):
-    check_gru_wsf(DEV, H, B, T)
 
 
 def test_gru_kernel_option_is_a_launch_argument(emu):

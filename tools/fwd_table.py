@@ -13,7 +13,6 @@ B = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 T = int(sys.argv[2]) if len(sys.argv) > 2 else 30
 SIZES = [int(v) for v in os.environ.get("FWD_H", "256,192,128,64").split(",")]
 DELAYS = [int(v) for v in os.environ.get("FWD_DELAYS", "0,8,16,24,32").split(",")]
-WS_PACE = [int(v) for v in os.environ.get("FWD_WS_PACE", "0,1,2").split(",")]      # wave-specialised forward: pacing of the memory waves' request groups
 
 
 NOSTASH = os.environ.get("FWD_NOSTASH", "0") != "0"      # inference form (no BPTT stash): traffic experiments
@@ -107,14 +106,11 @@ def main():
               variants += [("skewed", ops.KERNEL_SKEWED, -1)] if H % 128 == 0 else []
           elif ops.gru_seq_fwd_has_kernel(H, ops.KERNEL_SKEWED):
               variants += [(f"skew d{d}", ops.KERNEL_SKEWED, d) for d in DELAYS]
-          variants = [(n_, k_, 0, d_) for n_, k_, d_ in variants]
-          if H <= 256 and form != "xin" and ops.gru_seq_fwd_has_kernel(H, ops.KERNEL_WS):
-              variants += [(f"ws p{p_}", ops.KERNEL_WS, p_, -1) for p_ in WS_PACE]
           for _ in range(4):
-              for _, k, pr, d in variants: timed(rows, H, k, pr, 2, delay=d)
-          res = {v[0]: [] for v in variants}
+              for _, k, d in variants: timed(rows, H, k, 0, 2, delay=d)
+          res = {name: [] for name, _, _ in variants}
           for _ in range(6):
-              for name, k, pr, d in variants: res[name] += timed(rows, H, k, pr, delay=d)
+              for name, k, d in variants: res[name] += timed(rows, H, k, 0, delay=d)
           line = f"H={H:3d} {form:3s}: "
           for name in res:
               v = sorted(res[name]); med = v[len(v) // 2]

@@ -16,7 +16,7 @@ H, B, T = 256, ft.B, ft.T
 for form in os.environ.get("FORMS", "gi,xin,dec").split(","):
     rows, flops, keep = ft.rows_for(form, H)
     nwg = len(rows) * ((B + 31) // 32) + 64
-    for name, kern, prio in [("lock-step", "1", "1"), ("skewed prio 1", "3", "1")] + ([("wave-specialised", "2", "0")] if form != "xin" else []):
+    for name, kern, prio in (("lock-step", "1", "1"), ("skewed prio 1", "3", "1"), ("skewed prio 0", "3", "0")):
         os.environ.update(VAME_GRU_FWD=kern, VAME_GRU_FWD_PRIO=prio)
         for _ in range(3):
             ops.gru_seq_fwd(rows, B, H)
@@ -29,9 +29,7 @@ for form in os.environ.get("FORMS", "gi,xin,dec").split(","):
         pw = pw[pw[:, 0, :].sum(1) > 0]
         steps = T if form != "dec" else None
         print(f"{form} {name}: {e0.elapsed_time(e1) * 1e3:.0f} us, clock ratio {p[:, 0].sum() / p[:, 1].sum():.2f}; workgroup cycles p50 {sorted(p[:, 0])[len(p) // 2]:.0f}")
-        names = (["P1 / gateB", "wait bx", "P2+handoff / y-copy", "wait by", "P3+P4+handoff / gateA", "wait bz", "6"] if kern == "2"
-                 else ["y-copy", "part0/mfma", "part1", "gates", "bar-mid", "bar-end", "6"])
-        for i, n in enumerate(names):
+        for i, n in enumerate(["y-copy", "part0/mfma", "part1", "gates", "bar-mid", "bar-end", "6"]):
             if pw[:, :, i].sum() > 0:
-                print(f"      {n:>22s}: " + " ".join(f"{pw[:, w_, i].mean() / (steps or T):7.0f}" for w_ in range(8)))
+                print(f"      {n:>11s}: " + " ".join(f"{pw[:, w_, i].mean() / (steps or T):7.0f}" for w_ in range(8)))
     del rows, keep

@@ -682,280 +682,6 @@ __global__ __launch_bounds__(H / 32 * 64) void gru_skew_fwd_kernel(GruFwdParams 
     GRU_PROBE_END();
 }
 
-// ------------------------------------------------------------------------------------------- forward, wave-specialised (round 4)
-// The forward counterpart of gru_ws_bwd_kernel: waves 0 .. MW-1 ("MFMA waves", one per SIMD, MW = H/64) do nothing but the contraction and
-// their vector-memory queue holds only the L2 weight ring; waves MW .. 2MW-1 ("memory waves", the other wave of each SIMD) own every HBM
-// stream (gi in, stash and Y out) AND the gate math.  What makes the role split pay in the forward direction is a split of the hidden
-// columns into two groups -- A = [0, H/2), B = [H/2, H); wave pair w owns block A_w = columns [32w, 32w+32) and block B_w = [H/2 + 32w, ..)
-// -- with the K loop of each output block run over A's columns first and B's second (ascending k: the lock-step kernel's order, hence
-// BIT-IDENTICAL results):
-//     MFMA wave, step s:   P1: acc_A += h_{s-1}[A] W   | bx |   P2: acc_A += h_{s-1}[B] W, acc_A -> LDS   | by |   P3, P4: the same for acc_B, -> LDS   | bz
-//     memory wave:         (gate math of block B, step s-1)  | bx |  Y copy-out of h_{s-1}, gi requests    | by |   gate math of block A, step s           | bz
-// so the gate math of block A runs beside the contraction of block B, that of block B beside P1 of the next step (which only needs A's
-// columns of h_s), and the matrix pipe never waits for VALU work: every dependency is one barrier old (h_s[A] is complete at bz(s), h_s[B]
-// at bx(s+1)).  Hand-offs are pairwise and lane-local: the accumulators go to the memory wave, and the next step's gi_r / gi_u come back as the
-// accumulators' initial values (so the sums start from gi exactly as in the lock-step kernel), through two fragment-order LDS images `xa` / `xb`
-// in which every lane only ever touches its own 16-byte slots.  h lives in LDS as A-columns (double-buffered: gate A of step s writes while P3 of
-// step s still reads h_{s-1}[A]) and B-columns (single: nothing reads h_{s-1}[B] between bz(s) and bx(s+1)).
-// LDS at H = 256: 3 x 32 x 132 floats + 2 x 48 KB = 148,992 B.  No fused input projection (its fourth accumulator tile does not fit the hand-off
-// images): encoder layer 0 keeps the skewed kernel.
-template <int H>
-__global__ __launch_bounds__(H / 32 * 64) void gru_wsf_kernel(GruFwdParams P) {
-    constexpr int NB = H / 32, MW = NB / 2, HA = H / 2, LDA = HA + 4, KC = H / 8, KH = KC / 2, PD = 4;
-    static_assert(NB % 2 == 0 && KH % PD == 0, "wave-specialised forward: H a multiple of 64");
-    __shared__ float hA[2][32 * LDA];                          // h_{s-1}[A] lives in hA[s & 1]
-    __shared__ float hB[32 * LDA];
-    __shared__ float4 xa[MW * 3 * 4 * 64];                     // [pair][tile r, u, nh][q][lane]
-    __shared__ float4 xb[MW * 3 * 4 * 64];
-    int sidx, tile;
-    if (!map_block(P.nstreams, P.ntiles, sidx, tile)) return;
-    const GruFwdStream& S = P.s[sidx];
-    const int B = P.B, T = (int)S.T;
-    const int tid = threadIdx.x, lane = tid & 63, li = lane & 31, hh = lane >> 5;
-    const int w = UNIFORM(tid >> 6);
-    const int row0 = tile * 32, lrow = 4 * hh;
-    const int nvalid = B - row0;
-    const bool full = nvalid >= 32;
-    const bool skip0 = S.h0 == nullptr;          // zero initial state: step 0 has no recurrent term (acc + 0 * w = acc)
-    GRU_PROBE_BEGIN();
-    auto time_of = [&](int s) { return S.reverse ? T - 1 - s : s; };
-
-    if (w < MW) {
-        // ================================================================ MFMA waves
-        const float4* __restrict__ wpA = reinterpret_cast<const float4*>(S.wp) + (int64_t)w * KC * 3 * 64 + lane;
-        const float4* __restrict__ wpB = reinterpret_cast<const float4*>(S.wp) + (int64_t)(MW + w) * KC * 3 * 64 + lane;
-        const float bhnA = S.bhn[32 * w + li], bhnB = S.bhn[HA + 32 * w + li];
-        f32x4 wq[PD][3];
-#pragma unroll
-        for (int c = 0; c < PD; ++c) { RING_LOAD(wq[c][0], wpA, (c * 3 + 0) * 64); RING_LOAD(wq[c][1], wpA, (c * 3 + 1) * 64); RING_LOAD(wq[c][2], wpA, (c * 3 + 2) * 64); }
-        f32x16 ar, au, anh;
-        // PD chunks of the weight sequence of a step (2 KC chunks: block A's, then block B's; i0 = index of the first): slot j is waited for,
-        // used, and refilled behind its last use with chunk i0 + j + PD of the sequence (wrapping into the next step)
-        float4 fa;                                               // A fragment of the chunk about to be contracted, read one chunk ahead: this
-        auto k_group = [&](const float* hrow, int cbase, int i0) {     // wave is alone on its SIMD's matrix pipe, an LDS round trip per chunk would show
-#pragma unroll
-            for (int j = 0; j < PD; ++j) {
-                const float4 a = fa;
-                fa = *reinterpret_cast<const float4*>(hrow + 8 * (cbase + j + 1 < KH ? cbase + j + 1 : 0));
-                RING_WAIT3(3 * (PD - 1), wq[j][0], wq[j][1], wq[j][2]);
-                const f32x4 b0 = wq[j][0], b1 = wq[j][1], b2 = wq[j][2];
-                ar = MFMA_32x32x2(a.x, b0[0], ar); au = MFMA_32x32x2(a.x, b1[0], au); anh = MFMA_32x32x2(a.x, b2[0], anh);
-                ar = MFMA_32x32x2(a.y, b0[1], ar); au = MFMA_32x32x2(a.y, b1[1], au); anh = MFMA_32x32x2(a.y, b2[1], anh);
-                ar = MFMA_32x32x2(a.z, b0[2], ar); au = MFMA_32x32x2(a.z, b1[2], au); anh = MFMA_32x32x2(a.z, b2[2], anh);
-                ar = MFMA_32x32x2(a.w, b0[3], ar); au = MFMA_32x32x2(a.w, b1[3], au); anh = MFMA_32x32x2(a.w, b2[3], anh);
-                RING_FENCE();
-                {
-                    int in = i0 + j + PD;
-                    in = in >= 2 * KC ? in - 2 * KC : in;
-                    const float4* src = in >= KC ? wpB : wpA;
-                    const int cn = in >= KC ? in - KC : in;
-                    RING_LOAD(wq[j][0], src, (cn * 3 + 0) * 64); RING_LOAD(wq[j][1], src, (cn * 3 + 1) * 64); RING_LOAD(wq[j][2], src, (cn * 3 + 2) * 64);
-                }
-            }
-        };
-        auto init_from = [&](const float4* x, float bhn) {      // accumulators <- gi_r, gi_u (written by the memory wave), b_hn
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const float4 vr = x[((w * 3 + 0) * 4 + q) * 64 + lane], vu = x[((w * 3 + 1) * 4 + q) * 64 + lane];
-                ar[4 * q] = vr.x; ar[4 * q + 1] = vr.y; ar[4 * q + 2] = vr.z; ar[4 * q + 3] = vr.w;
-                au[4 * q] = vu.x; au[4 * q + 1] = vu.y; au[4 * q + 2] = vu.z; au[4 * q + 3] = vu.w;
-            }
-#pragma unroll
-            for (int r = 0; r < 16; ++r) anh[r] = bhn;
-        };
-        auto hand_off = [&](float4* x) {                         // pre-activations of a block -> its memory wave
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                x[((w * 3 + 0) * 4 + q) * 64 + lane] = make_float4(ar[4 * q], ar[4 * q + 1], ar[4 * q + 2], ar[4 * q + 3]);
-                x[((w * 3 + 1) * 4 + q) * 64 + lane] = make_float4(au[4 * q], au[4 * q + 1], au[4 * q + 2], au[4 * q + 3]);
-                x[((w * 3 + 2) * 4 + q) * 64 + lane] = make_float4(anh[4 * q], anh[4 * q + 1], anh[4 * q + 2], anh[4 * q + 3]);
-            }
-        };
-        __syncthreads();                                         // prologue: h_{-1}, gi(0) of both blocks are in LDS
-        GRU_PHASE_DECL();
-        for (int s = 0; s < T; ++s) {
-            const bool skip = s == 0 && skip0;
-            const float* rowA = &hA[s & 1][li * LDA + 4 * hh];
-            const float* rowB = &hB[li * LDA + 4 * hh];
-            init_from(xa, bhnA);
-            if (!skip) {
-                fa = *reinterpret_cast<const float4*>(rowA);
-#pragma unroll 1
-                for (int c0 = 0; c0 < KH; c0 += PD) k_group(rowA, c0, c0);                          // P1
-            }
-            GRU_PHASE(0);
-            LDS_BARRIER();                                       // bx: h_{s-1}[B] is complete
-            GRU_PHASE(1);
-            if (!skip) {
-                fa = *reinterpret_cast<const float4*>(rowB);
-#pragma unroll 1
-                for (int c0 = 0; c0 < KH; c0 += PD) k_group(rowB, c0, KH + c0);                     // P2
-            }
-            hand_off(xa);
-            GRU_PHASE(2);
-            LDS_BARRIER();                                       // by
-            GRU_PHASE(3);
-            init_from(xb, bhnB);
-            if (!skip) {
-                fa = *reinterpret_cast<const float4*>(rowA);
-#pragma unroll 1
-                for (int c0 = 0; c0 < KH; c0 += PD) k_group(rowA, c0, KC + c0);                     // P3
-                fa = *reinterpret_cast<const float4*>(rowB);
-#pragma unroll 1
-                for (int c0 = 0; c0 < KH; c0 += PD) k_group(rowB, c0, KC + KH + c0);                // P4
-            }
-            hand_off(xb);
-            GRU_PHASE(4);
-            LDS_BARRIER();                                       // bz: h_s[A] is complete
-            GRU_PHASE(5);
-        }
-        LDS_BARRIER();                                           // (the memory waves' gate math of block B, last step)
-        GRU_PHASE_END();
-    } else {
-        // ================================================================ memory waves: gi in, gate math, stash / Y out
-        const int k = w - MW;                                    // the pair this wave serves: blocks A_k and B_k
-        const int rows_here = full ? 32 : nvalid;
-        const int colA = 32 * k, colB = HA + 32 * k;            // first hidden column of the two blocks
-        const BufRange r_gi = buf_range(S.gi + (int64_t)row0 * S.gi_row, (uint64_t)rows_here * (uint64_t)S.gi_row * 4);
-        const BufRange r_st = buf_range(S.stash ? S.stash + (int64_t)tile * T * NB * 20 * 64 * 4 : nullptr, (uint64_t)T * NB * 20 * 64 * 16);
-        // (based one time slot early: the padded slot of a forward stream is slot -1, and a buffer offset cannot be negative)
-        const BufRange r_y = buf_range(S.y ? S.y + (int64_t)row0 * S.y_row - S.y_t : nullptr, (uint64_t)rows_here * (uint64_t)S.y_row * 4);
-        const uint32_t v_gi = ((uint32_t)lrow * (uint32_t)S.gi_row + (uint32_t)li) * 4u;            // accumulator layout: row CR(r) + lrow, column li
-        const uint32_t gi_row_b = UNIFORM((uint32_t)S.gi_row * 4u), gi_t_b = UNIFORM((uint32_t)S.gi_t * 4u);
-        const uint32_t v_st = (uint32_t)lane * 16u;
-        const bool per_step = S.gi_t != 0;
-        const int pace = P.pace_cp < 0 ? 0 : P.pace_cp;
-        f32x16 hpA, hpB, gnA, gnB, grA, guA, grB, guB;          // h_{s-1} of the blocks; gi_n of the step in flight; gi_r / gi_u of the NEXT step
-        auto load_ru = [&](int t, int col, f32x16& gr, f32x16& gu) {
-            const uint32_t so = UNIFORM((uint32_t)t * gi_t_b + (uint32_t)col * 4u);
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                gr[r] = buf_load_f32(r_gi, v_gi, so + (uint32_t)CR(r) * gi_row_b);
-                gu[r] = buf_load_f32(r_gi, v_gi, so + (uint32_t)CR(r) * gi_row_b + 4u * H);
-            }
-        };
-        auto load_n = [&](int t, int col, f32x16& gn) {
-            const uint32_t so = UNIFORM((uint32_t)t * gi_t_b + (uint32_t)col * 4u + 8u * H);
-#pragma unroll
-            for (int r = 0; r < 16; ++r) gn[r] = buf_load_f32(r_gi, v_gi, so + (uint32_t)CR(r) * gi_row_b);
-        };
-        auto put_ru = [&](float4* x, const f32x16& gr, const f32x16& gu) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                x[((k * 3 + 0) * 4 + q) * 64 + lane] = make_float4(gr[4 * q], gr[4 * q + 1], gr[4 * q + 2], gr[4 * q + 3]);
-                x[((k * 3 + 1) * 4 + q) * 64 + lane] = make_float4(gu[4 * q], gu[4 * q + 1], gu[4 * q + 2], gu[4 * q + 3]);
-            }
-        };
-        // ---- prologue: initial state -> LDS + registers, gi of step 0 -> hand-off images, gi of step 1 requested
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = CR(r) + lrow, grow = row0 + row;
-            float a = 0.f, b = 0.f;
-            if (S.h0 && grow < B) { a = S.h0[(int64_t)grow * S.h0_row + colA + li]; b = S.h0[(int64_t)grow * S.h0_row + colB + li]; }
-            hpA[r] = a; hpB[r] = b;
-            hA[0][row * LDA + 32 * k + li] = a;
-            hB[row * LDA + 32 * k + li] = b;
-        }
-        load_ru(time_of(0), colA, grA, guA); load_ru(time_of(0), colB, grB, guB);
-        load_n(time_of(0), colA, gnA); load_n(time_of(0), colB, gnB);
-        put_ru(xa, grA, guA); put_ru(xb, grB, guB);
-        if (per_step && T > 1) { load_ru(time_of(1), colA, grA, guA); load_ru(time_of(1), colB, grB, guB); }
-        __syncthreads();                                         // prologue
-        // LDS -> global copy of a whole h tile (both column groups) by the MW memory waves: thread j of them moves float4 (row 8 i + j / 32 ... )
-        const int mt = tid - MW * 64;                            // 0 .. MW * 64 - 1
-        constexpr int CPR = HA / 4;                              // float4 per row and column group
-        auto copy_out = [&](int hbuf, int tslot) {
-            if (S.y == nullptr) return;
-            const uint32_t so = UNIFORM((uint32_t)((int64_t)(tslot + 1) * S.y_t * 4));
-#pragma unroll
-            for (int i = 0; i < 32 * CPR / (MW * 64); ++i) {
-                const int idx = mt + i * MW * 64, row = idx / CPR, c4 = idx % CPR;
-                const uint32_t vo = (uint32_t)row * (uint32_t)S.y_row * 4u + (uint32_t)c4 * 16u;
-                buf_store_f32x4(r_y, vo, so, *reinterpret_cast<const float4*>(&hA[hbuf][row * LDA + 4 * c4]));
-                buf_store_f32x4(r_y, vo + (uint32_t)HA * 4u, so, *reinterpret_cast<const float4*>(&hB[row * LDA + 4 * c4]));
-                if ((i & 1) && pace) { SCHED_FENCE(); for (int z = 0; z < pace; ++z) VAME_SLEEP4(); }
-            }
-        };
-        if (S.pad) copy_out(0, S.reverse ? T : -1);
-        // gate math of one block: pre-activations from the hand-off image, h_s -> LDS, BPTT coefficients -> stash
-        auto gates = [&](const float4* x, f32x16& hp, const f32x16& gn, float* hdst, int ob, int t) {
-            const uint32_t s_st = UNIFORM(((uint32_t)t * NB + (uint32_t)ob) * 20u * 1024u);
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const float4 vr = x[((k * 3 + 0) * 4 + q) * 64 + lane], vu = x[((k * 3 + 1) * 4 + q) * 64 + lane], vh = x[((k * 3 + 2) * 4 + q) * 64 + lane];
-                const float pr[4] = {vr.x, vr.y, vr.z, vr.w}, pu[4] = {vu.x, vu.y, vu.z, vu.w}, ph[4] = {vh.x, vh.y, vh.z, vh.w};
-                float ca[4], cb[4], us[4], rs[4];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int r = 4 * q + j;
-                    const float rr = fast_sigmoid(pr[j]);
-                    const float uu = fast_sigmoid(pu[j]);
-                    const float nn = fast_tanh(gn[r] + rr * ph[j]);
-                    const float hpv = hp[r];
-                    const float hv = nn + uu * (hpv - nn);
-                    const float omu = 1.0f - uu;
-                    ca[j] = omu * (1.0f - nn * nn);
-                    cb[j] = (hpv - nn) * uu * omu;
-                    us[j] = uu; rs[j] = rr;
-                    hp[r] = hv;
-                    hdst[(CR(r) + lrow) * LDA + 32 * k + li] = hv;
-                }
-                if (S.stash) {
-                    buf_store_f32x4(r_st, v_st, s_st + (uint32_t)(0 * 4 + q) * 1024u, make_float4(ca[0], ca[1], ca[2], ca[3]));
-                    buf_store_f32x4(r_st, v_st, s_st + (uint32_t)(1 * 4 + q) * 1024u, make_float4(cb[0], cb[1], cb[2], cb[3]));
-                    buf_store_f32x4(r_st, v_st, s_st + (uint32_t)(2 * 4 + q) * 1024u, make_float4(us[0], us[1], us[2], us[3]));
-                    buf_store_f32x4(r_st, v_st, s_st + (uint32_t)(3 * 4 + q) * 1024u, make_float4(rs[0], rs[1], rs[2], rs[3]));
-                    buf_store_f32x4(r_st, v_st, s_st + (uint32_t)(4 * 4 + q) * 1024u, vh);
-                }
-                SCHED_FENCE();
-                for (int z = 0; z < pace; ++z) VAME_SLEEP4();
-            }
-        };
-        GRU_PHASE_DECL();
-        for (int s = 0; s < T; ++s) {
-            const int t = time_of(s);
-            const bool more = s + 1 < T;
-            GRU_PHASE(0);                                        // (probe build) gate math of block B, previous step (+ loop top)
-            LDS_BARRIER();                                       // bx(s): gate math of block B, step s-1, is complete (done above / in the prologue)
-            GRU_PHASE(1);
-            if (s >= 1) copy_out(s & 1, time_of(s - 1));        // h_{s-1}: A columns in hA[s & 1], B columns in hB
-            GRU_PHASE(2);
-            LDS_BARRIER();                                       // by(s): block A's pre-activations are in xa
-            GRU_PHASE(3);
-            gates(xa, hpA, gnA, hA[(s + 1) & 1], k, t);
-            if (more) {
-                put_ru(xa, grA, guA);                            // gi_r, gi_u of step s+1 become block A's initial accumulator values
-                if (per_step) {
-                    load_n(time_of(s + 1), colA, gnA);
-                    if (s + 2 < T) load_ru(time_of(s + 2), colA, grA, guA);
-                }
-            }
-            GRU_PHASE(4);
-            LDS_BARRIER();                                       // bz(s): h_s[A] is complete, block B's pre-activations are in xb
-            GRU_PHASE(5);
-            gates(xb, hpB, gnB, hB, MW + k, t);
-            if (more) {
-                put_ru(xb, grB, guB);
-                if (per_step) {
-                    load_n(time_of(s + 1), colB, gnB);
-                    if (s + 2 < T) load_ru(time_of(s + 2), colB, grB, guB);
-                }
-            }
-        }
-        LDS_BARRIER();                                           // h_{T-1}[B] is complete
-        GRU_PHASE_END();
-        copy_out(T & 1, time_of(T - 1));
-        if (S.hn) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int grow = row0 + CR(r) + lrow;
-                if (grow < B) { S.hn[(int64_t)grow * S.hn_row + colA + li] = hpA[r]; S.hn[(int64_t)grow * S.hn_row + colB + li] = hpB[r]; }
-            }
-        }
-    }
-    GRU_PROBE_END();
-}
-
 // ------------------------------------------------------------------------------------------- backward
 // ABL: 1 no dG stores, 2 no stash/dy loads (first step's reused), 16 W fragments not re-streamed, 32 no barriers, 256 / 1024 dG copy-out placement (see the step loop)
 template <int H, int ABL = 0>
@@ -1465,7 +1191,6 @@ static bool gru_ws_auto(int H) { return H == 256 || H == 192; }      // measured
 // forward: AUTO = the skewed kernel where it measured faster (tools/fwd_table.py, profiles/r04_fwd_table.txt): H = 256 and 192 for streams
 // that read something every step (a per-step gi tile: +6-7 %, the fused input projection: +3-4 %); streams with a time-constant gi (the
 // decoders) gain nothing (-0.5 %) and H <= 128 loses 1-4 % (a step's K loop is too short for the second barrier) -> lock-step there
-static bool gru_wsf_auto(int H, const GruFwdParams& P) { (void)H; (void)P; return false; }      // until measured (tools/fwd_table.py)
 static bool gru_skew_auto(int H, const GruFwdParams& P) {
     if (H != 256 && H != 192) return false;
     for (int i = 0; i < P.nstreams; ++i)
@@ -1486,11 +1211,6 @@ static void launch_fwd(const GruFwdParams& P_, hipStream_t st) {
     }
 #endif
     if constexpr (H % 64 == 0) {
-        // wave-specialised forward (gru_wsf_kernel; no fused input projection): bit-identical to the lock-step kernel
-        if (P.s[0].xf == 0 && (P.kernel == VAME_GRU_KERNEL_WS || (P.kernel == VAME_GRU_KERNEL_AUTO && gru_wsf_auto(H, P)))) {
-            hipLaunchKernelGGL((gru_wsf_kernel<H>), dim3(grid_blocks(P.nstreams, P.ntiles)), dim3(H / 32 * 64), 0, st, P);
-            return;
-        }
         // two wave groups half a step apart (gru_skew_fwd_kernel): bit-identical to the lock-step kernel
         if (P.kernel == VAME_GRU_KERNEL_SKEWED || (P.kernel == VAME_GRU_KERNEL_AUTO && gru_skew_auto(H, P))) {
             if (P.s[0].xf > 0) hipLaunchKernelGGL((gru_skew_fwd_kernel<H, true>), dim3(grid_blocks(P.nstreams, P.ntiles)), dim3(H / 32 * 64), 0, st, P);
@@ -1539,7 +1259,7 @@ static void launch_bwd(const GruBwdParams& P_, hipStream_t st) {
 
 extern "C" int vame_gru_seq_fwd_has_kernel(int H, int kernel) {
     if (H < 32 || H > 256 || H % 32) return 0;
-    if (kernel == VAME_GRU_KERNEL_SKEWED || kernel == VAME_GRU_KERNEL_WS) return H % 64 == 0;
+    if (kernel == VAME_GRU_KERNEL_SKEWED) return H % 64 == 0;
     return kernel == VAME_GRU_KERNEL_AUTO || kernel == VAME_GRU_KERNEL_LOCKSTEP;
 }
 
@@ -1550,8 +1270,6 @@ extern "C" int vame_gru_seq_fwd_f32(const int64_t* desc, int nstreams, int B, in
     if (int rc = gru_parse_fwd(desc, nstreams, B, P)) return rc;
     VAME_CHECK_ARG(vame_gru_seq_fwd_has_kernel(H, P.kernel) || H > 256 || H % 32, VAME_E_UNSUPPORTED,
                    "gru_seq_fwd: kernel option %d is not instantiated for H=%d", P.kernel, H);
-    VAME_CHECK_ARG(P.kernel != VAME_GRU_KERNEL_WS || P.s[0].xf == 0, VAME_E_UNSUPPORTED,
-                   "gru_seq_fwd: the wave-specialised kernel has no fused input projection (use _SKEWED / _LOCKSTEP for such streams)");
     hipStream_t st = (hipStream_t)stream;
     switch (H) {
         case 32: launch_fwd<32>(P, st); break;
