@@ -60,33 +60,89 @@ struct TileIO {
     static constexpr int KQ = BK / 4, XQ = BX / 4;
     float4 v[PER];
     int rowo[KM ? 1 : PER];               // !KM: row offsets in elements (-1 = out of range)
-    int seg_b, seg_t;                      // KM: (segment, index) of row k0 + tid/XQ
-    int kstep;                             // KM: rows between consecutive items of this thread
+    static constexpr int KSTEP = KM ? NT / XQ : 1;     // KM: rows between consecutive items of a thread
 
-    __device__ __forceinline__ void init(const GemmOperand& o, int x0, int X, int kb, int tid) {
+    // Fast-path state (interior tiles: every load legal and 16 bytes wide): a workgroup-uniform base pointer (scalar registers) + ONE
+    // 32-bit byte offset per item, advanced by constants from one k-tile to the next.  The f32-input MFMA runs on the SIMD's vector ALU
+    // (MI355X_MICROARCH.md: at the f32 vector rate), so every VALU instruction of a GEMM wave is matrix time lost; the first form of this
+    // path recomputed (segment, index) -> offset per item and k-tile with 64-bit multiplications and a `while` per item: 164 VALU
+    // instructions per k-tile, 56 of them quarter-rate multiplies (~25 % of the 64 MFMAs' time, profiles/r04_gemm_valu.txt).  Now: 1 VALU
+    // per item for plain rows, 6 for two-level rows, and no more registers than before (the split-K weight gradients share their CUs with
+    // the narrow contractions of the side stream: a fourth wave per SIMD must still fit beside three of these).
+    const char* fbase;                     // uniform: operand base + the offset of this workgroup's first row (rebased: offsets stay < 2^31)
+    unsigned fo[KM ? 1 : PER];             // byte offset of the next load: per item (!KM: arbitrary rows), or of item 0 alone (KM: the thread's
+                                           // items are rows KSTEP apart -- item i sits at fo[0] + i * fitem (+ fwrap if a segment border lies between))
+    int ft[1];                             // KM, two-level rows: item 0's row index inside its segment
+    unsigned fitem;                        // KM: bytes between two items of a thread inside one segment
+    unsigned fstep, fwrap;                 // KM: bytes from one k-tile to the next (incl. the segment borders BK rows always cross); one more border
+    int frem, fq, fseg;                    // KM: BK = fq * seg + frem; fseg = seg, or INT_MAX for plain rows
+    bool f32ok;                            // the workgroup's rows span < 2^31 bytes (else: the general path)
+    __device__ __forceinline__ void init(const GemmOperand& o, int x0, int X, int kb, int tid, int kper) {
         if (!KM) {
+            const int64_t row_first = op_row(o, x0 < X ? x0 : 0);
+            int64_t lo = 0, hi = 0;
 #pragma unroll
             for (int it = 0; it < PER; ++it) {
                 const int idx = tid + it * NT, x = idx / KQ, gx = x0 + x;
                 rowo[it] = ((ITEMS % NT == 0 || idx < ITEMS) && gx < X) ? (int)op_row(o, gx) : -1;
+                const int64_t rel = (rowo[it] >= 0 ? (int64_t)rowo[it] - row_first : 0) + 4 * (tid % KQ);
+                fo[it] = (unsigned)(rel * 4);
+                lo = rel < lo ? rel : lo; hi = rel > hi ? rel : hi;
             }
+            fbase = reinterpret_cast<const char*>(o.p + row_first + kb);
+            // rows of one tile: BX x the row pitch; k advances inside a row by at most kper floats
+            const int64_t pitch = o.seg ? (o.seg_stride > o.ld * o.seg ? o.seg_stride : o.ld * o.seg) : o.ld;
+            f32ok = ((int64_t)BX * pitch + kper + BK) * 4 < ((int64_t)1 << 31) && (!o.seg || o.seg_stride >= 0) && o.ld >= 0;
+            fstep = BK * 4; fwrap = 0; frem = 0; fq = 0; ft[0] = 0; fitem = 0; fseg = 0x7fffffff;
         } else {
             const unsigned g = (unsigned)(kb + tid / XQ);
-            if (o.seg) { seg_b = (int)(g / (unsigned)o.seg); seg_t = (int)(g % (unsigned)o.seg); }
-            else { seg_b = 0; seg_t = (int)g; }
-            kstep = NT / XQ;
             rowo[0] = 0;
+            const int gx = x0 + 4 * (tid % XQ);
+            const int gxs = gx + (gx >= o.gap_at ? o.gap : 0);
+            fq = o.seg ? BK / (int)o.seg : 0;
+            frem = o.seg ? BK % (int)o.seg : 0;
+            fseg = o.seg ? (int)o.seg : 0x7fffffff;
+            const int64_t wrap = o.seg ? o.seg_stride - o.seg * o.ld : 0;
+            const int64_t row_first = o.seg ? (int64_t)(kb / (int)o.seg) * o.seg_stride + (int64_t)(kb % (int)o.seg) * o.ld : (int64_t)kb * o.ld;
+            fbase = reinterpret_cast<const char*>(o.p + row_first);
+            fwrap = (unsigned)(wrap * 4);
+            fstep = (unsigned)(((int64_t)BK * o.ld + (int64_t)fq * wrap) * 4);
+            // the workgroup's k-slab: kper (+ BK of run-ahead) rows of pitch ld, plus one border per segment; at most one border between a
+            // thread's first and last item (else: the general path)
+            const int64_t span = ((int64_t)(kper + 2 * BK) * o.ld + (o.seg ? ((kper + 2 * BK) / o.seg + 2) * (wrap > 0 ? wrap : 0) : 0) + o.gap + BX) * 4;
+            f32ok = span < ((int64_t)1 << 31) && wrap >= 0 && o.ld >= 0 && (!o.seg || KSTEP * (PER - 1) < o.seg);
+            fitem = (unsigned)((int64_t)KSTEP * o.ld * 4);
+            {
+                const unsigned b = o.seg ? g / (unsigned)o.seg : 0u, t = o.seg ? g % (unsigned)o.seg : 0u;
+                ft[0] = (int)t;
+                fo[0] = (unsigned)((((o.seg ? (int64_t)b * o.seg_stride + (int64_t)t * o.ld : (int64_t)g * o.ld) - row_first) + gxs) * 4);
+            }
         }
+    }
+    // KM fast path: byte offset of item `it` (see fo) and the step to the next k-tile.  Branch-free (the pipelined loop places these
+    // between MFMAs): plain rows have fseg = INT_MAX, frem = 0, fwrap = 0 and fall through the same selects.
+    __device__ __forceinline__ unsigned item_off(int it) const {
+        unsigned off = fo[0] + (unsigned)it * fitem;
+        if (it > 0) off += (ft[0] + KSTEP * it >= fseg) ? fwrap : 0u;
+        return off;
+    }
+    __device__ __forceinline__ void next_tile() {
+        const int tn = ft[0] + frem;
+        const bool w = tn >= fseg;
+        ft[0] = w ? tn - fseg : tn;
+        fo[0] += fstep + (w ? fwrap : 0u);
     }
     // `fast` (wave-uniform): the tile is interior in X and in k, 16-byte loads are legal -> no predication
     template <bool FAST>
     __device__ __forceinline__ void fetch(const GemmOperand& o, int x0, int X, int k0, int ke, int tid) {
-        const bool fast = FAST && o.vec && (ITEMS % NT == 0) && x0 + BX <= X && k0 + BK <= ke;
+        const bool fast = FAST && o.vec && f32ok && (ITEMS % NT == 0) && x0 + BX <= X && k0 + BK <= ke;
         if (!KM) {
             const int gk = k0 + 4 * (tid % KQ);
             if (fast) {
 #pragma unroll
-                for (int it = 0; it < PER; ++it) v[it] = *reinterpret_cast<const float4*>(o.p + rowo[it] + gk);
+                for (int it = 0; it < PER; ++it) v[it] = *reinterpret_cast<const float4*>(fbase + fo[it]);
+#pragma unroll
+                for (int it = 0; it < PER; ++it) fo[it] += BK * 4;
                 return;
             }
 #pragma unroll
@@ -102,36 +158,24 @@ struct TileIO {
         } else {
             const int gx = x0 + 4 * (tid % XQ);
             const int gxs = gx + (gx >= o.gap_at ? o.gap : 0);       // source column (gap_at, gap multiples of 4)
-            int b = seg_b, t = seg_t;
             if (fast) {
-                const int seg = (int)o.seg;
 #pragma unroll
-                for (int it = 0; it < PER; ++it) {
-                    const float* src = o.p + (seg ? (int64_t)b * o.seg_stride + (int64_t)t * o.ld : (int64_t)t * o.ld) + gxs;
-                    v[it] = *reinterpret_cast<const float4*>(src);
-                    t += kstep;
-                    if (seg) while (t >= seg) { t -= seg; ++b; }
-                }
-                seg_t += BK;
-                if (seg) while (seg_t >= seg) { seg_t -= seg; ++seg_b; }
+                for (int it = 0; it < PER; ++it) v[it] = *reinterpret_cast<const float4*>(fbase + item_off(it));
+                next_tile();
                 return;
             }
+            // (general path: edge tiles and the last, partial k-tile of a slab -- rows resolved from scratch, rare)
 #pragma unroll
             for (int it = 0; it < PER; ++it) {
-                const int gk = k0 + tid / XQ + it * kstep;
+                const int gk = k0 + tid / XQ + it * KSTEP;
                 float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
                 if ((ITEMS % NT == 0 || tid + it * NT < ITEMS) && gk < ke && gx < X) {
-                    const float* src = o.p + (o.seg ? (int64_t)b * o.seg_stride + (int64_t)t * o.ld : (int64_t)t * o.ld) + gxs;
+                    const float* src = o.p + op_row(o, gk) + gxs;
                     if (o.vec && gx + 3 < X) r = *reinterpret_cast<const float4*>(src);
                     else { r.x = src[0]; if (gx + 1 < X) r.y = src[1]; if (gx + 2 < X) r.z = src[2]; if (gx + 3 < X) r.w = src[3]; }
                 }
                 v[it] = r;
-                t += kstep;
-                if (o.seg) while (t >= (int)o.seg) { t -= (int)o.seg; ++b; }
             }
-            // advance the thread's first row by BK for the next k-tile
-            seg_t += BK;
-            if (o.seg) while (seg_t >= (int)o.seg) { seg_t -= (int)o.seg; ++seg_b; }
         }
     }
     // LDS image.  k-major [BK][BX+4] (default; fragment = ds_read_b32 of row k; a row-major (!KM) operand is transposed by
@@ -143,36 +187,16 @@ struct TileIO {
     static constexpr int LDS_FLOATS = XMAJ ? BX * (BK + 4) : BK * (BX + 4);
     // ---- item-wise, branch-free forms for the software-pipelined loop (interior tiles only: 16-byte loads legal, nothing
     // predicated; k-major operands: seg == 0 or seg >= BK, so advancing a row index by BK crosses at most one segment border)
-    int64_t poff[PER];                     // element offset of the item's next load
-    int pt[KM ? PER : 1];                  // KM: index of the item's row inside its segment
-    int64_t pstep, pwrap;                  // KM: offset step per k-tile; correction when the row index wraps into the next segment
-    __device__ __forceinline__ void pipe_init(const GemmOperand& o, int x0, int kb, int tid) {
-        if (!KM) {
-#pragma unroll
-            for (int it = 0; it < PER; ++it) poff[it] = (int64_t)rowo[it] + kb + 4 * (tid % KQ);
-            pstep = BK; pwrap = 0;
-        } else {
-            const int gx = x0 + 4 * (tid % XQ);
-            const int gxs = gx + (gx >= o.gap_at ? o.gap : 0);
-            pstep = (int64_t)BK * o.ld;
-            pwrap = o.seg ? o.seg_stride - o.seg * o.ld : 0;
-#pragma unroll
-            for (int it = 0; it < PER; ++it) {
-                const unsigned g = (unsigned)(kb + tid / XQ + it * (NT / XQ));
-                const unsigned b = o.seg ? g / (unsigned)o.seg : 0u, t = o.seg ? g % (unsigned)o.seg : g;
-                pt[it] = (int)t;
-                poff[it] = (o.seg ? (int64_t)b * o.seg_stride : 0) + (int64_t)t * o.ld + gxs;
-            }
-        }
-    }
+    // (the fast-path state fp / ft / fstep / fwrap of init() serves the pipelined loop too: one pointer per item, constants per k-tile;
+    // eligibility there guarantees seg == 0 or seg >= BK, i.e. at most the one conditional border)
+    __device__ __forceinline__ void pipe_init(const GemmOperand&, int, int, int) {}
     __device__ __forceinline__ void pipe_fetch_item(const GemmOperand& o, int it) {
-        v[it] = *reinterpret_cast<const float4*>(o.p + poff[it]);
-        poff[it] += pstep;
         if (KM) {
-            pt[it] += BK;
-            const bool w = o.seg != 0 && pt[it] >= (int)o.seg;
-            pt[it] -= w ? (int)o.seg : 0;
-            poff[it] += w ? pwrap : 0;
+            v[it] = *reinterpret_cast<const float4*>(fbase + item_off(it));
+            if (it == PER - 1) next_tile();           // (the pipelined loop fetches a tile's items in order 0 .. PER-1)
+        } else {
+            v[it] = *reinterpret_cast<const float4*>(fbase + fo[it]);
+            fo[it] += BK * 4;
         }
     }
     __device__ __forceinline__ void store_item(float* lds, int tid, int it) const {
@@ -305,15 +329,15 @@ __global__ __launch_bounds__(WM * WN * 64, ((BM / WM) * (BN / WN) > 64 * 64 || (
 
     TA ta;
     TB tb;
-    ta.init(opA, m0, p.M, kb, tid);
-    tb.init(opB, n0, p.N, kb, tid);
+    ta.init(opA, m0, p.M, kb, tid, p.kper);
+    tb.init(opB, n0, p.N, kb, tid, p.kper);
     PROBE_DECL;
     bool piped = false;
     constexpr bool PIPE_STATIC = PIPE && TA::ITEMS == 4 * NT && TB::ITEMS == 4 * NT && TM == 2 && TN == 2;
     if constexpr (PIPE_STATIC) {
     // eligibility of the pipelined loop (wave-uniform): interior tile, 16-byte loads, whole k-tiles and at least three of them,
     // at most one segment border per BK rows of a k-major operand; everything else takes the plain loop below
-    const bool pipe_ok = opA.vec && opB.vec && m0 + BM <= p.M &&
+    const bool pipe_ok = opA.vec && opB.vec && ta.f32ok && tb.f32ok && m0 + BM <= p.M &&
                          n0 + BN <= p.N && (ke - kb) % BK == 0 && ke - kb >= 3 * BK && (!AKM || opA.seg == 0 || opA.seg >= BK) &&
                          (!BKM || opB.seg == 0 || opB.seg >= BK);
     if (pipe_ok) {
