@@ -154,7 +154,7 @@ def _pack(dev, W_hh, b_ih, b_hh, H):
 FORCE_WIDE = False           # set by check_gru_wide_small: the two-blocks-per-wave kernels at H <= 256
 
 
-def run_gru_fwd(dev, H, B, T, seed=0, coop=None, coop_chunks=None, want_rows=False):
+def run_gru_fwd(dev, H, B, T, seed=0, coop=None, coop_chunks=None, want_rows=False, coop_kernel=None):
     """Two streams (forward + reverse dir, with h0) in one launch; returns everything needed for bwd.
     coop: an ops.CoopState -> the column-split small-batch kernel instead of the batch-tile-persistent one."""
     rng = np.random.default_rng(seed)
@@ -169,7 +169,8 @@ def run_gru_fwd(dev, H, B, T, seed=0, coop=None, coop_chunks=None, want_rows=Fal
         h0 = rng.standard_normal((B, H)).astype(np.float32) * 0.5 if d == 1 else None
         wpf, wpb, bgi, bhn = _pack(dev, W_hh, b_ih, b_hh, H)
         gi = T_((x.reshape(B * T, I) @ W_ih.T + N_(bgi)).reshape(B, T, 3 * H), dev)
-        stash = torch.zeros(ops.gru_stash_floats(B, T, H), device=dev)
+        # NaN-filled: every stash entry of a tile (also of its rows past the batch, which BPTT multiplies by zero) must be written
+        stash = torch.full((ops.gru_stash_floats(B, T, H),), float("nan"), device=dev)
         h0t = T_(h0, dev) if h0 is not None else None
         rows.append({GF["GI"]: ops.addr(gi), GF["GI_ROW"]: T * 3 * H, GF["GI_T"]: 3 * H, GF["WP"]: ops.addr(wpf),
                      GF["BHN"]: ops.addr(bhn), GF["H0"]: ops.addr(h0t), GF["H0_ROW"]: H,
@@ -177,7 +178,7 @@ def run_gru_fwd(dev, H, B, T, seed=0, coop=None, coop_chunks=None, want_rows=Fal
                      GF["HN"]: ops.addr(hN, d * H), GF["HN_ROW"]: 2 * H, GF["STASH"]: ops.addr(stash), GF["T"]: T,
                      GF["REVERSE"]: d, GF["PAD"]: 1})
         st.append(dict(W_ih=W_ih, W_hh=W_hh, b_ih=b_ih, b_hh=b_hh, h0=h0, wpb=wpb, stash=stash, keep=(gi, wpf, bhn, h0t)))
-    launch_gru_fwd(rows, B, H, coop, coop_chunks)
+    launch_gru_fwd(rows, B, H, coop, coop_chunks, coop_kernel)
     if want_rows:
         return x, st, Y, hN, rows
     return x, st, Y, hN
@@ -186,10 +187,10 @@ def run_gru_fwd(dev, H, B, T, seed=0, coop=None, coop_chunks=None, want_rows=Fal
 FWD_KERNEL = ops.KERNEL_AUTO      # kernel argument of launch_gru_fwd's gru_seq_fwd launches (GF_OPT descriptor field)
 
 
-def launch_gru_fwd(rows, B, H, coop=None, coop_chunks=None):
+def launch_gru_fwd(rows, B, H, coop=None, coop_chunks=None, coop_kernel=None):
     if coop is not None:
         for chunk in (coop_chunks or [(0, 0)]):
-            ops.gru_coop_fwd(rows, B, H, coop, rows=chunk)
+            ops.gru_coop_fwd(rows, B, H, coop, rows=chunk, kernel=coop_kernel or ops.KERNEL_AUTO)
     elif H > 256 or FORCE_WIDE:
         ops.gru_wide_fwd(rows, B, H, kernel=FWD_KERNEL)
     else:
@@ -226,30 +227,41 @@ def check_gru_fwd_ring_stress(dev, H, B, T, launches=200):
     return overlapped
 
 
-def check_gru_coop_fwd(dev, H, B, T, launches=2):
-    """Column-split kernel = batch-tile-persistent kernel bit for bit (outputs, final state, stash), over repeated launches that
-    reuse the flag words (epoch logic), and it agrees with the oracle."""
+def check_gru_coop_fwd(dev, H, B, T, launches=3):
+    """Column-split kernel vs the batch-tile-persistent one: outputs, final state and stash agree to summation-order rounding (the
+    column-split kernel sums K = H in two halves of 16 x 16 x 4 MFMAs), it agrees with the oracle, and ITS results are the same bits
+    whichever form a launch takes -- whole batch in 16-row groups, 32-row groups (kernel option), two row-range launches -- over
+    repeated launches that reuse the flag words (epoch logic)."""
     assert ops.gru_coop_supported(2, B, H) and not ops.gru_coop_supported(2, 8192, H)
     state = ops.CoopState(torch.device(dev))
     state.epoch = (1 << 32) - T - 3                       # the second launch crosses the 2^32 wrap of the flag epoch
     state.flags.fill_(-T - 4)                             # ... as left behind by a launch just before it
     x, st0, Y0, hN0 = run_gru_fwd(dev, H, B, T)
-    chunks = [None, [(0, 32), (32, B - 32)]] if B > 32 else [None]       # whole batch, then two row-range launches
+    forms = [(None, ops.KERNEL_AUTO), (None, ops.KERNEL_LOCKSTEP)]
+    if B > 32:
+        forms.append(([(0, 32), (32, B - 32)], ops.KERNEL_AUTO))         # whole batch, then two row-range launches
+    ntiles, NW = (B + 31) // 32, H // 32
+    q, lane, e = np.meshgrid(np.arange(4), np.arange(64), np.arange(4), indexing="ij")
+    r = 4 * q + e
+    row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)                                   # CR(r) + 4 * (lane >> 5)
+    valid = (np.arange(ntiles)[:, None, None, None] * 32 + row[None]) < B              # (ntiles, 4, 64, 4)
+    valid = np.broadcast_to(valid[:, None, None, None], (ntiles, T, NW, 5, 4, 64, 4)).reshape(-1)
+    first = None
     for it in range(launches):
-        x, st, Y, hN = run_gru_fwd(dev, H, B, T, coop=state, coop_chunks=chunks[it % len(chunks)])
-        np.testing.assert_array_equal(N_(Y), N_(Y0))
-        np.testing.assert_array_equal(N_(hN), N_(hN0))
+        chunks, kern = forms[it % len(forms)]
+        x, st, Y, hN = run_gru_fwd(dev, H, B, T, coop=state, coop_chunks=chunks, coop_kernel=kern)
+        np.testing.assert_allclose(N_(Y), N_(Y0), rtol=0, atol=2e-6)
+        np.testing.assert_allclose(N_(hN), N_(hN0), rtol=0, atol=2e-6)
         # stash entries of rows past the batch (last tile) are don't-cares of both kernels: compare the valid rows
-        ntiles, NW = (B + 31) // 32, H // 32
-        q, lane, e = np.meshgrid(np.arange(4), np.arange(64), np.arange(4), indexing="ij")
-        r = 4 * q + e
-        row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)                                   # CR(r) + 4 * (lane >> 5)
-        valid = (np.arange(ntiles)[:, None, None, None] * 32 + row[None]) < B              # (ntiles, 4, 64, 4)
-        valid = np.broadcast_to(valid[:, None, None, None], (ntiles, T, NW, 5, 4, 64, 4)).reshape(-1)
         for a, b in zip(st, st0):
             sa, sb = N_(a["stash"]), N_(b["stash"])
-            np.testing.assert_allclose(sa[valid], sb[valid], rtol=0, atol=2.5e-7)      # BPTT coefficients: fma contraction may differ by 1 ulp
+            np.testing.assert_allclose(sa[valid], sb[valid], rtol=0, atol=4e-6)      # (the fifth quantity is a pre-activation of a few units)
             assert np.isfinite(sa).all()
+        got = [N_(Y), N_(hN)] + [N_(a["stash"])[valid] for a in st]
+        if first is None:
+            first = got
+        for g_, f_ in zip(got, first):
+            np.testing.assert_array_equal(g_, f_)
     assert int(state.status.item()) == 0
     check_gru_fwd(dev, H, B, T)
 

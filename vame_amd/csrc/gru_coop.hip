@@ -20,6 +20,7 @@
 #include <chrono>
 #include <thread>
 #define COOP_STORE16(ptr, v) (*reinterpret_cast<f32x4*>(ptr) = (v))
+#define COOP_STORE4(ptr, v) (*(ptr) = (v))
 #define COOP_LOAD16(dst, ptr) ((dst) = *reinterpret_cast<const f32x4*>(ptr))
 #define COOP_WAIT_LOADS8(a, b, c, d, e, f, g, h)
 #define COOP_DRAIN()
@@ -29,6 +30,7 @@
 #else
 // 16-byte write-through store / L1-bypassing load (sc1); asm because HIP has no 16-byte agent-scope access
 #define COOP_STORE16(ptr, v) asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(ptr), "v"(v) : "memory")
+#define COOP_STORE4(ptr, v) asm volatile("global_store_dword %0, %1, off sc1" : : "v"(ptr), "v"(v) : "memory")
 #define COOP_LOAD16(dst, ptr) asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(dst) : "v"(ptr) : "memory")
 #define COOP_WAIT_LOADS8(a, b, c, d, e, f, g, h) \
     asm volatile("s_waitcnt vmcnt(0)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f), "+v"(g), "+v"(h))
@@ -64,128 +66,186 @@ __device__ __forceinline__ bool coop_map(int ngroups, int& g, int& m) {
 }
 template <int NM>
 static int coop_grid(int ngroups) { return (int)cdiv64(ngroups, 8) * 8 * NM; }
+// ... with NH row halves per 32-row tile, each a group of its own on the same XCD (forward, R = 32 / NH rows per group)
+template <int NM, int NH>
+__device__ __forceinline__ bool coop_map(int ngroups, int& g, int& m, int& half) {
+    const int b = blockIdx.x, xcd = b & 7, q = b >> 3;
+    m = q % NM;
+    half = (q / NM) % NH;
+    g = (q / (NM * NH)) * 8 + xcd;
+    return g < ngroups;
+}
 
-template <int H>
+// Forward.  A group is the R rows of a batch tile (R = 32, or 16 when twice the workgroups still fit one per CU: the launches with two
+// streams at batch 256) x the S members.  A member's step is R x 32 columns x 3 gates over K = H, as 16 x 16 tiles of
+// v_mfma_f32_16x16x4_f32: wave w owns the 16 x 16 tile (row half, column half) = (w >> 1, w & 1) at R = 32, or column half w & 1 and
+// K half w >> 1 at R = 16 (the halves meet through LDS).  All three gates of a tile sit in the same lanes -- lane l holds column l & 15,
+// rows 4 (l >> 4) .. +3 -- so the gate math, the publish of h_t and the BPTT stash (one float4 per quantity and lane, the layout of the
+// batch-tile kernels) need no exchange between waves, and all four SIMDs share the contraction (192 / 96 MFMAs of 32 cycles per wave
+// and step against 128 of 64 cycles on three of four SIMDs in the 32 x 32 form of rounds 2-3).  Both K halves are summed separately
+// and then added in either form, so a launch gives the same bits whichever R its row range selects.
+template <int H, int R>
 __global__ __launch_bounds__(256) void gru_coop_fwd_kernel(GruFwdParams P, int* __restrict__ flags, int base, int* __restrict__ status,
                                                            int max_polls) {
-    constexpr int NM = H / 32, LDH = H + 4, KC = H / 8, LDE = 33, LDX = 36;
+    constexpr int NM = H / 32, NH = 32 / R, LDW = H + 4, LDH = H + 4, NCH = H / 16, HALF = NCH / 2;
+    static_assert(R == 32 || R == 16, "row tiles of 32 or 16");
     VAME_DYN_SMEM(smem_raw);
-    f32x4* wl = reinterpret_cast<f32x4*>(smem_raw);                         // [KC][3][64] B fragments of this member's W_hh slice
-    float* hs = reinterpret_cast<float*>(wl + KC * 3 * 64);                // [32][LDH] h_{t-1} (A operand)
-    float* ex = hs + 32 * LDH;                                             // [2][32][LDE] sigmoid(r), sigmoid(u)
-    float* hx = ex + 2 * 32 * LDE;                                         // [32][LDX] this member's h_t slice, row-major
-    int g, m;
-    if (!coop_map<NM>(P.nstreams * P.ntiles, g, m)) return;
+    float* wl = reinterpret_cast<float*>(smem_raw);                        // [3][32][LDW] this member's rows of W_hh, k contiguous
+    float* hs = wl + 96 * LDW;                                             // [R][LDH] h_{t-1} (A operand)
+    float* pb = hs + R * LDH;                                              // R = 16: [2][12][64] partial sums of the upper K half
+    int g, m, half;
+    if (!coop_map<NM, NH>(P.nstreams * P.ntiles, g, m, half)) return;
     const bool inject = max_polls < 0;
     if (inject) max_polls = COOP_DEFAULT_POLLS;
     const int sidx = g % P.nstreams, tile = g / P.nstreams + P.tile_off;
     const GruFwdStream& S = P.s[sidx];
     const int B = P.B, T = (int)S.T;
-    const int tid = threadIdx.x, lane = tid & 63, li = lane & 31, hh = lane >> 5;
-    const int w = UNIFORM(tid >> 6);                                       // 0,1,2 = gates r,u,n; 3 = helper
-    const int row0 = tile * 32, col0 = 32 * m, lrow = 4 * hh;
+    const int row0 = tile * 32 + half * R, col0 = 32 * m;
     const int nvalid = B - row0;
-    int* gflags = flags + (int64_t)g * NM;
-
-    // ---- prologue: W slice -> LDS, initial state -> LDS (+ padded slot of the sequence), first gi
-    {
-        const f32x4* src = reinterpret_cast<const f32x4*>(S.wp) + (int64_t)m * KC * 3 * 64;
-        for (int i = tid; i < KC * 3 * 64; i += 256) wl[i] = src[i];
+    const int tid = threadIdx.x, lane = tid & 63, c16 = lane & 15, kg = lane >> 4;
+    const int w = UNIFORM(tid >> 6);
+    const int ch = w & 1, rh = R == 32 ? (w >> 1) : 0, kh = R == 32 ? 0 : (w >> 1);
+    const int lrow = rh * 16 + 4 * kg, lcol = ch * 16 + c16;               // this lane: rows lrow .. lrow + 3, column lcol of the slice
+    const bool owner = R == 32 || kh == 0;                                 // lanes that finish the sums and do the gate math
+    int* gflags = flags + ((int64_t)g * NH + half) * NM;
+    float4* stash = S.stash ? reinterpret_cast<float4*>(S.stash) : nullptr;
+    const int rg = (half * R + lrow) >> 2;                                 // 4-row group inside the 32-row stash tile: CR layout (hh, q) = (rg & 1, rg >> 1)
+    const int slane = (rg & 1) * 32 + lcol, sq = rg >> 1;
+    if (nvalid <= 0) {                                                     // the second half of a last tile with <= 16 rows: nothing to compute, but
+        if (owner && stash)                                                // BPTT multiplies the tile's stash rows past the batch by zero -> keep them finite
+            for (int t = 0; t < T; ++t)
+#pragma unroll
+                for (int k5 = 0; k5 < 5; ++k5)
+                    stash[((((int64_t)tile * T + t) * NM + m) * 20 + k5 * 4 + sq) * 64 + slane] = make_float4(0.f, 0.f, 0.f, 0.f);
+        return;
     }
-    for (int i = tid; i < 32 * (H / 4); i += 256) {
+
+    // ---- prologue: W slice -> LDS (the 32 x 32 x 2 fragment pack un-permuted: fragment (c, gate, lane) = 4 consecutive k of one row)
+    {
+        const f32x4* src = reinterpret_cast<const f32x4*>(S.wp) + (int64_t)m * (H / 8) * 3 * 64;
+        for (int i = tid; i < (H / 8) * 3 * 64; i += 256) {
+            const int c = i / 192, gt = (i % 192) / 64, l = i % 64;
+            *reinterpret_cast<f32x4*>(&wl[(gt * 32 + (l & 31)) * LDW + 8 * c + 4 * (l >> 5)]) = src[i];
+        }
+    }
+    for (int i = tid; i < R * (H / 4); i += 256) {
         const int r = i / (H / 4), c4 = i % (H / 4);
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (S.h0 && r < nvalid) v = *reinterpret_cast<const float4*>(S.h0 + (int64_t)(row0 + r) * S.h0_row + 4 * c4);
         *reinterpret_cast<float4*>(&hs[r * LDH + 4 * c4]) = v;
     }
     __syncthreads();
-    const int prow = tid >> 3, pc4 = tid & 7;                              // publish / pad pass: 32 rows x 8 float4 of the slice
-    float* y_pub = S.y + (int64_t)(row0 + prow) * S.y_row + col0 + 4 * pc4;
-    if (S.pad && prow < nvalid)
-        *reinterpret_cast<float4*>(y_pub + (int64_t)(S.reverse ? T : -1) * S.y_t) = *reinterpret_cast<const float4*>(&hs[prow * LDH + col0 + 4 * pc4]);
-    f32x16 hprev, gcur, gnext;
+    if (S.pad && tid < R * 8 && (tid >> 3) < nvalid) {                     // padded slot of the sequence: this member's slice of h_0
+        const int prow = tid >> 3, pc4 = tid & 7;
+        *reinterpret_cast<float4*>(S.y + (int64_t)(row0 + prow) * S.y_row + (int64_t)(S.reverse ? T : -1) * S.y_t + col0 + 4 * pc4) =
+            *reinterpret_cast<const float4*>(&hs[prow * LDH + col0 + 4 * pc4]);
+    }
+    float hprev[4], gcur[3][4], gnext[3][4];
     float bhn = 0.f;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { hprev[r] = hs[(CR(r) + lrow) * LDH + col0 + li]; gcur[r] = 0.f; gnext[r] = 0.f; }
-    const float* gi_lane = S.gi + (int64_t)(row0 + lrow) * S.gi_row + (w < 3 ? w : 0) * H + col0 + li;
-    auto load_gi = [&](int t, f32x16& dst) {
+    for (int i = 0; i < 4; ++i) hprev[i] = hs[(lrow + i) * LDH + col0 + lcol];
+    const float* gi_lane = S.gi + (int64_t)(row0 + lrow) * S.gi_row + col0 + lcol;
+    auto load_gi = [&](int t, float (&dst)[3][4]) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r)
-            dst[r] = (CR(r) + lrow < nvalid) ? gi_lane[(int64_t)CR(r) * S.gi_row + (int64_t)t * S.gi_t] : 0.f;
+        for (int gt = 0; gt < 3; ++gt)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                dst[gt][i] = (lrow + i < nvalid) ? gi_lane[(int64_t)i * S.gi_row + (int64_t)t * S.gi_t + gt * H] : 0.f;
     };
-    if (w < 3) load_gi(S.reverse ? T - 1 : 0, gcur);
-    if (w == 2) bhn = S.bhn[col0 + li];
-    const float* hrow = &hs[li * LDH + 4 * hh];
-    const f32x4* wrow = wl + w * 64 + lane;
-    float4* stash = S.stash ? reinterpret_cast<float4*>(S.stash) : nullptr;
+#pragma unroll
+    for (int gt = 0; gt < 3; ++gt)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { gcur[gt][i] = 0.f; gnext[gt][i] = 0.f; }
+    if (owner) { load_gi(S.reverse ? T - 1 : 0, gcur); bhn = S.bhn[col0 + lcol]; }
+    const float* arow = &hs[(rh * 16 + c16) * LDH + 4 * kg];
+    const float* brow = &wl[(ch * 16 + c16) * LDW + 4 * kg];
+    float* y_lane = S.y + (int64_t)(row0 + lrow) * S.y_row + col0 + lcol;
 
     for (int step = 0; step < T; ++step) {
         const int t = S.reverse ? T - 1 - step : step;
-        f32x16 acc;
-        if (w < 3) {
-            const bool more = step + 1 < T && S.gi_t != 0;
-            if (more) load_gi(S.reverse ? t - 1 : t + 1, gnext);           // lands during the MFMA loop
+        f32x4 lo[3], hi[3];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[r] = (w == 2) ? bhn : gcur[r];
-            if (!(step == 0 && S.h0 == nullptr))                           // zero initial state: no recurrent term in the first step
+        for (int gt = 0; gt < 3; ++gt)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { lo[gt][i] = owner ? (gt == 2 ? bhn : gcur[gt][i]) : 0.f; hi[gt][i] = 0.f; }
+        const bool more = step + 1 < T && S.gi_t != 0;
+        if (owner && more) load_gi(S.reverse ? t - 1 : t + 1, gnext);      // lands during the MFMA loop
+        const bool recur = !(step == 0 && S.h0 == nullptr);                // zero initial state: no recurrent term in the first step
+        if (recur) {
+            auto chunk = [&](int c, f32x4 (&acc)[3]) {
+                const float4 a = *reinterpret_cast<const float4*>(arow + 16 * c);
+#pragma unroll
+                for (int gt = 0; gt < 3; ++gt) {
+                    const float4 b = *reinterpret_cast<const float4*>(brow + gt * 32 * LDW + 16 * c);
+                    acc[gt] = MFMA_16x16x4(a.x, b.x, acc[gt]); acc[gt] = MFMA_16x16x4(a.y, b.y, acc[gt]);
+                    acc[gt] = MFMA_16x16x4(a.z, b.z, acc[gt]); acc[gt] = MFMA_16x16x4(a.w, b.w, acc[gt]);
+                }
+            };
+            if (R == 32) {
+#pragma unroll 2
+                for (int c = 0; c < HALF; ++c) { chunk(c, lo); chunk(c + HALF, hi); }
+            } else {
 #pragma unroll 4
-            for (int c = 0; c < KC; ++c) {
-                const float4 a = *reinterpret_cast<const float4*>(hrow + 8 * c);
-                const f32x4 b = wrow[c * 3 * 64];
-                acc = MFMA_32x32x2(a.x, b[0], acc); acc = MFMA_32x32x2(a.y, b[1], acc);
-                acc = MFMA_32x32x2(a.z, b[2], acc); acc = MFMA_32x32x2(a.w, b[3], acc);
-            }
-            if (w < 2) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) ex[w * 32 * LDE + (CR(r) + lrow) * LDE + li] = fast_sigmoid(acc[r]);
+                for (int c = 0; c < HALF; ++c) chunk(kh * HALF + c, lo);
             }
         }
-        __syncthreads();
-        f32x16 ca, cb, us, rs;                  // wave 2: the step's BPTT coefficients, stored BEHIND the hand-off (see below)
-        if (w == 2) {
+        if (R == 16) {                                                     // the upper K half of each tile crosses to the lower half's wave
+            if (kh == 1) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float rr = ex[(CR(r) + lrow) * LDE + li], uu = ex[32 * LDE + (CR(r) + lrow) * LDE + li];
-                const float nn = fast_tanh(gcur[r] + rr * acc[r]);
-                const float hp = hprev[r];
+                for (int gt = 0; gt < 3; ++gt)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) pb[(ch * 12 + gt * 4 + i) * 64 + lane] = lo[gt][i];
+            }
+            __syncthreads();
+            if (kh == 0) {
+#pragma unroll
+                for (int gt = 0; gt < 3; ++gt)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) hi[gt][i] = pb[(ch * 12 + gt * 4 + i) * 64 + lane];
+            }
+        }
+        float ca[4], cb[4], us[4], rs[4], an[4];
+        if (owner) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float rr = fast_sigmoid(lo[0][i] + hi[0][i]), uu = fast_sigmoid(lo[1][i] + hi[1][i]);
+                an[i] = lo[2][i] + hi[2][i];
+                const float nn = fast_tanh(gcur[2][i] + rr * an[i]);
+                const float hp = hprev[i];
                 const float hv = nn + uu * (hp - nn);
                 const float omu = 1.0f - uu;
-                ca[r] = omu * (1.0f - nn * nn);
-                cb[r] = (hp - nn) * uu * omu;
-                us[r] = uu; rs[r] = rr;
-                hprev[r] = hv;
-                hx[(CR(r) + lrow) * LDX + li] = hv;
+                ca[i] = omu * (1.0f - nn * nn);
+                cb[i] = (hp - nn) * uu * omu;
+                us[i] = uu; rs[i] = rr;
+                hprev[i] = hv;
+                // ---- publish: this lane's four rows of h_t into the sequence tensor (write-through)
+                if (lrow + i < nvalid) COOP_STORE4(y_lane + (int64_t)i * S.y_row + (int64_t)t * S.y_t, hv);
             }
-        }
-        // the stash leaves AFTER the slice of h_t has been published and the flag raised (round 4): in front of the publish its 20 KB of
-        // stores sat in wave 2's queue ahead of the drain every member of the group is waiting for; behind it they overlap the poll and
-        // the tile read, and the next step's drain comes a whole step later
-        auto store_stash = [&]() {
-            if (w == 2 && stash) {
-                float4* sp = stash + ((((int64_t)tile * T + t) * NM + m) * 20) * 64 + lane;
+            if (more) {
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    sp[(0 * 4 + q) * 64] = make_float4(ca[4 * q], ca[4 * q + 1], ca[4 * q + 2], ca[4 * q + 3]);
-                    sp[(1 * 4 + q) * 64] = make_float4(cb[4 * q], cb[4 * q + 1], cb[4 * q + 2], cb[4 * q + 3]);
-                    sp[(2 * 4 + q) * 64] = make_float4(us[4 * q], us[4 * q + 1], us[4 * q + 2], us[4 * q + 3]);
-                    sp[(3 * 4 + q) * 64] = make_float4(rs[4 * q], rs[4 * q + 1], rs[4 * q + 2], rs[4 * q + 3]);
-                    sp[(4 * 4 + q) * 64] = make_float4(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]);
-                }
+                for (int gt = 0; gt < 3; ++gt)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) gcur[gt][i] = gnext[gt][i];
             }
-        };
-        if (w < 3 && step + 1 < T && S.gi_t != 0) gcur = gnext;
-        __syncthreads();
-        // ---- publish this member's 32 x 32 slice of h_t into the sequence tensor (write-through), then raise the flag
-        if (prow < nvalid) {
-            const f32x4 v = *reinterpret_cast<const f32x4*>(&hx[prow * LDX + 4 * pc4]);
-            COOP_STORE16(y_pub + (int64_t)t * S.y_t, v);
         }
         COOP_DRAIN();
         __syncthreads();
+        // the stash leaves AFTER the slice of h_t has been published and the flag raised: behind the hand-off its stores overlap the
+        // poll and the tile read, and the next step's drain comes a whole step later
+        auto store_stash = [&]() {
+            if (owner && stash) {
+                float4* sp = stash + ((((int64_t)tile * T + t) * NM + m) * 20 + sq) * 64 + slane;
+                sp[0 * 4 * 64] = make_float4(ca[0], ca[1], ca[2], ca[3]);
+                sp[1 * 4 * 64] = make_float4(cb[0], cb[1], cb[2], cb[3]);
+                sp[2 * 4 * 64] = make_float4(us[0], us[1], us[2], us[3]);
+                sp[3 * 4 * 64] = make_float4(rs[0], rs[1], rs[2], rs[3]);
+                sp[4 * 4 * 64] = make_float4(an[0], an[1], an[2], an[3]);
+            }
+        };
         if (step + 1 == T) { store_stash(); break; }
         if (tid == 0) COOP_FLAG_STORE(&gflags[m], (int)((unsigned)base + (unsigned)step + 1u));
         store_stash();
-        // ---- wait for all members' slices of h_t, then rebuild the full 32 x H tile in LDS
+        // ---- wait for all members' slices of h_t, then rebuild the full R x H tile in LDS
         if (tid < NM) {
             if (inject && step == 0 && tid == 0) atomicAdd(status, 1);          // fault injection (diagnostics): report, then wait normally
             int polls = COOP_FLAG_LOAD(status) != 0 && !inject ? max_polls : 0;
@@ -196,8 +256,8 @@ __global__ __launch_bounds__(256) void gru_coop_fwd_kernel(GruFwdParams P, int* 
         }
         __syncthreads();
         {
-            constexpr int PER = 32 * (H / 4) / 256;                       // float4 per thread (8 at H = 256)
-            static_assert(PER == 8 || PER == 4, "tile copy is written for H = 128 / 256");
+            constexpr int PER = R * (H / 4) / 256;                        // float4 per thread (8 at R = 32, H = 256)
+            static_assert(PER == 8 || PER == 4 || PER == 2, "tile copy is written for H = 128 / 256");
             f32x4 v[8];
             const float* yt = S.y + (int64_t)t * S.y_t;
 #pragma unroll
@@ -215,12 +275,10 @@ __global__ __launch_bounds__(256) void gru_coop_fwd_kernel(GruFwdParams P, int* 
         }
         __syncthreads();
     }
-    if (S.hn && w == 2) {
+    if (S.hn && owner) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int grow = row0 + CR(r) + lrow;
-            if (grow < B) S.hn[(int64_t)grow * S.hn_row + col0 + li] = hprev[r];
-        }
+        for (int i = 0; i < 4; ++i)
+            if (lrow + i < nvalid) S.hn[(int64_t)(row0 + lrow + i) * S.hn_row + col0 + lcol] = hprev[i];
     }
 }
 
@@ -232,13 +290,11 @@ __global__ __launch_bounds__(256) void gru_coop_fwd_kernel(GruFwdParams P, int* 
                    VAME_E_HIP, "gru_coop: cannot reserve %d bytes of LDS", (int)(bytes))
 #endif
 
-template <int H>
-static size_t coop_fwd_lds() {
-    constexpr int KC = H / 8, LDH = H + 4;
-    return (size_t)KC * 3 * 64 * 16 + (size_t)(32 * LDH + 2 * 32 * 33 + 32 * 36) * 4;
-}
+template <int H, int R>
+static size_t coop_fwd_lds() { return (size_t)(96 * (H + 4) + R * (H + 4) + (R == 16 ? 2 * 12 * 64 : 0)) * 4; }
 
-extern "C" int64_t vame_gru_coop_flag_ints(int nstreams, int B, int H) { return (int64_t)nstreams * cdiv64(B, 32) * (H / 32) + 16; }
+// one flag word per (stream, 16-row half tile, member)
+extern "C" int64_t vame_gru_coop_flag_ints(int nstreams, int B, int H) { return (int64_t)nstreams * cdiv64(B, 32) * 2 * (H / 32) + 16; }
 
 // 1 if (nstreams, B, H) can run cooperatively: every workgroup of the grid must be resident at once (one per CU)
 // compute units of the current device: every workgroup of a cooperative grid needs its own (LDS allows one per CU)
@@ -272,11 +328,17 @@ static int coop_kernels_resident(int H) {
         int nf = 0, nb = 0;
         hipError_t e1, e2;
         if (H == 256) {
-            e1 = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nf, gru_coop_fwd_kernel<256>, 256, coop_fwd_lds<256>());
+            int n16 = 0;
+            e1 = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nf, gru_coop_fwd_kernel<256, 32>, 256, coop_fwd_lds<256, 32>());
+            if (e1 == hipSuccess) e1 = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n16, gru_coop_fwd_kernel<256, 16>, 256, coop_fwd_lds<256, 16>());
             e2 = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, gru_coop_bwd_kernel<256>, 256, coop_bwd_lds<256>());
+            nf = nf < n16 ? nf : n16;
         } else {
-            e1 = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nf, gru_coop_fwd_kernel<128>, 256, coop_fwd_lds<128>());
+            int n16 = 0;
+            e1 = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nf, gru_coop_fwd_kernel<128, 32>, 256, coop_fwd_lds<128, 32>());
+            if (e1 == hipSuccess) e1 = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n16, gru_coop_fwd_kernel<128, 16>, 256, coop_fwd_lds<128, 16>());
             e2 = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, gru_coop_bwd_kernel<128>, 256, coop_bwd_lds<128>());
+            nf = nf < n16 ? nf : n16;
         }
         r = (e1 == hipSuccess && e2 == hipSuccess && nf >= 1 && nb >= 1) ? 1 : 0;
         (void)hipGetLastError();
@@ -290,6 +352,11 @@ extern "C" int vame_gru_coop_supported(int nstreams, int B, int H) {
     const int64_t groups = (int64_t)nstreams * cdiv64(B, 32);
     const int64_t grid = cdiv64(groups, 8) * 8 * (H / 32);
     return grid <= 256 && grid <= coop_cu_count() && coop_kernels_resident(H);
+}
+// forward: split the 32-row tiles of a launch into 16-row groups?  (twice the workgroups must still get a CU each)
+static bool coop_rows16(int ngroups, int H) {
+    const int64_t grid = cdiv64(ngroups, 8) * 8 * (H / 32) * 2;
+    return grid <= 256 && grid <= coop_cu_count();
 }
 // rows [row0, row0 + nrows) of the batch (row0 a multiple of 32; nrows = 0: all of it)
 static int coop_row_range(int B, int row0, int nrows, int& tile_off, int& ntiles) {
@@ -321,13 +388,20 @@ extern "C" int vame_gru_coop_fwd_f32(const int64_t* desc, int nstreams, int B, i
 #ifdef VAME_EMU
     emu::g_coop = true;
 #endif
-    if (H == 256) {
-        COOP_ALLOW_LDS(gru_coop_fwd_kernel<256>, coop_fwd_lds<256>());
-        hipLaunchKernelGGL((gru_coop_fwd_kernel<256>), dim3(coop_grid<8>(ngroups)), dim3(256), coop_fwd_lds<256>(), st, P, flags, epoch_base, status, g_coop_polls);
-    } else {
-        COOP_ALLOW_LDS(gru_coop_fwd_kernel<128>, coop_fwd_lds<128>());
-        hipLaunchKernelGGL((gru_coop_fwd_kernel<128>), dim3(coop_grid<4>(ngroups)), dim3(256), coop_fwd_lds<128>(), st, P, flags, epoch_base, status, g_coop_polls);
-    }
+    VAME_CHECK_ARG(P.kernel == VAME_GRU_KERNEL_AUTO || P.kernel == VAME_GRU_KERNEL_LOCKSTEP, VAME_E_UNSUPPORTED,
+                   "gru_coop_fwd: kernel option %d (AUTO, or LOCKSTEP = 32-row groups)", P.kernel);
+    // 16-row groups when twice the workgroups still get a CU each (GF_OPT kernel = LOCKSTEP keeps 32-row groups: same bits, A/B tests)
+    const bool r16 = P.kernel == VAME_GRU_KERNEL_AUTO && coop_rows16(ngroups, H);
+#define COOP_FWD_LAUNCH(HH, RR)                                                                                                  \
+    do {                                                                                                                         \
+        const size_t lds_ = coop_fwd_lds<HH, RR>();                                                                              \
+        const int grid_ = coop_grid<HH / 32>(ngroups) * (32 / RR);                                                               \
+        COOP_ALLOW_LDS((gru_coop_fwd_kernel<HH, RR>), lds_);                                                                     \
+        hipLaunchKernelGGL((gru_coop_fwd_kernel<HH, RR>), dim3(grid_), dim3(256), lds_, st, P, flags, epoch_base, status, g_coop_polls); \
+    } while (0)
+    if (H == 256) { if (r16) COOP_FWD_LAUNCH(256, 16); else COOP_FWD_LAUNCH(256, 32); }
+    else          { if (r16) COOP_FWD_LAUNCH(128, 16); else COOP_FWD_LAUNCH(128, 32); }
+#undef COOP_FWD_LAUNCH
 #ifdef VAME_EMU
     emu::g_coop = false;
 #endif

@@ -315,10 +315,13 @@ def coop_row_chunks(nstreams, B, H, max_rounds=2):
     return [(r, min(cap, B - r)) for r in range(0, B, cap)] if n <= max_rounds else []
 
 
-def gru_coop_fwd(streams, B, H, state: CoopState, rows=(0, 0)):
-    """Column-split forward for small batches: same `streams` table and results as gru_seq_fwd.  rows = (row0, nrows) restricts
-    the launch to a row range of the batch (multiple of 32; (0, 0) = everything)."""
+def gru_coop_fwd(streams, B, H, state: CoopState, rows=(0, 0), kernel=KERNEL_AUTO):
+    """Column-split forward for small batches: same `streams` table as gru_seq_fwd, results equal to summation-order rounding (the
+    K = H contraction is summed in two halves).  rows = (row0, nrows) restricts the launch to a row range of the batch (multiple of
+    32; (0, 0) = everything).  kernel: KERNEL_AUTO = 16-row groups where twice the workgroups fit one per CU, KERNEL_LOCKSTEP = 32-row
+    groups always (the same bits either way)."""
     d = _desc_tensor(streams, GF["N"])
+    d[0, GF["OPT"]] = gru_opt(kernel, -1, -1)
     need = _lib.lib().vame_gru_coop_flag_ints(len(streams), rows[1] or B, H)
     assert state.flags.numel() >= need, "cooperative flag buffer too small"
     T = max(int(s[GF["T"]]) for s in streams)
