@@ -414,7 +414,7 @@ def check_gru_skew_fwd(dev, H, B, T):
             assert torch.equal(a, b), f"output {i} differs: {float((a - b).abs().max())}"
 
 
-def _run_gru_bwd(dev, H, B, T, st, Y, dYt, dhNt, coop=None, coop_chunks=None):
+def _run_gru_bwd(dev, H, B, T, st, Y, dYt, dhNt, coop=None, coop_chunks=None, coop_kernel=None):
     ntiles = (B + 31) // 32
     rows, outs = [], []
     for d, s in enumerate(st):
@@ -430,7 +430,7 @@ def _run_gru_bwd(dev, H, B, T, st, Y, dYt, dhNt, coop=None, coop_chunks=None):
         outs.append((dG, dh0, dbias, dgsum))
     if coop is not None:
         for chunk in (coop_chunks or [(0, 0)]):
-            ops.gru_coop_bwd(rows, B, H, coop, rows=chunk)
+            ops.gru_coop_bwd(rows, B, H, coop, rows=chunk, kernel=coop_kernel or ops.KERNEL_AUTO)
     elif H > 256 or FORCE_WIDE:
         ops.gru_wide_bwd(rows, B, H)
     else:
@@ -438,22 +438,32 @@ def _run_gru_bwd(dev, H, B, T, st, Y, dYt, dhNt, coop=None, coop_chunks=None):
     return outs
 
 
-def check_gru_coop_bwd(dev, H, B, T, launches=2):
+def check_gru_coop_bwd(dev, H, B, T, launches=3):
     """Column-split BPTT kernel vs the batch-tile-persistent one on the same stash: dG, dh0 and the bias partial sums agree to
-    summation-order rounding (the K = 3H contraction is split by member), over repeated launches sharing the flag words."""
+    summation-order rounding (the K = 3H contraction is split by member), over repeated launches sharing the flag words; the
+    column-split results are the same bits in every form of the launch (16-row groups, 32-row groups, two row-range launches)."""
     x, st, Y, hN = run_gru_fwd(dev, H, B, T, seed=1)
     rng = np.random.default_rng(5)
     dYt = T_(rng.standard_normal((B, T, 2 * H)).astype(np.float32), dev)
     dhNt = T_(rng.standard_normal((B, 2 * H)).astype(np.float32), dev)
     ref = _run_gru_bwd(dev, H, B, T, st, Y, dYt, dhNt)
     state = ops.CoopState(torch.device(dev))
-    chunks = [None, [(0, 32), (32, B - 32)]] if B > 32 else [None]
+    forms = [(None, ops.KERNEL_AUTO), (None, ops.KERNEL_LOCKSTEP)]
+    if B > 32:
+        forms.append(([(0, 32), (32, B - 32)], ops.KERNEL_AUTO))
+    first = None
     for it in range(launches):
-        got = _run_gru_bwd(dev, H, B, T, st, Y, dYt, dhNt, coop=state, coop_chunks=chunks[it % len(chunks)])
+        chunks, kern = forms[it % len(forms)]
+        got = _run_gru_bwd(dev, H, B, T, st, Y, dYt, dhNt, coop=state, coop_chunks=chunks, coop_kernel=kern)
         for (dG, dh0, dbias, _), (dGr, dh0r, dbiasr, _) in zip(got, ref):
             np.testing.assert_allclose(N_(dG), N_(dGr), atol=2e-5 * float(np.abs(N_(dGr)).max()))
             np.testing.assert_allclose(N_(dh0), N_(dh0r), atol=2e-5 * float(np.abs(N_(dh0r)).max()))
             np.testing.assert_allclose(N_(dbias).sum(0), N_(dbiasr).sum(0), atol=1e-4 * float(np.abs(N_(dbiasr).sum(0)).max()))
+        flat = [N_(t_) for o in got for t_ in o[:3]]
+        if first is None:
+            first = flat
+        for a, b in zip(flat, first):
+            np.testing.assert_array_equal(a, b)
     assert int(state.status.item()) == 0
 
 

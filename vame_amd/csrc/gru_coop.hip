@@ -22,8 +22,11 @@
 #define COOP_STORE16(ptr, v) (*reinterpret_cast<f32x4*>(ptr) = (v))
 #define COOP_STORE4(ptr, v) (*(ptr) = (v))
 #define COOP_LOAD16(dst, ptr) ((dst) = *reinterpret_cast<const f32x4*>(ptr))
+#define COOP_LOAD4(dst, ptr) ((dst) = *(ptr))
 #define COOP_WAIT_LOADS8(a, b, c, d, e, f, g, h)
 #define COOP_DRAIN()
+#define COOP_ONE_WAVE_PER_SIMD
+#define COOP_MFMA_SETTLE()
 #define COOP_FLAG_STORE(p, v) __atomic_store_n((p), (v), __ATOMIC_RELEASE)
 #define COOP_FLAG_LOAD(p) __atomic_load_n((p), __ATOMIC_ACQUIRE)
 #define COOP_BACKOFF() std::this_thread::sleep_for(std::chrono::microseconds(20))   /* one OS thread per workgroup: let the others run */
@@ -32,12 +35,34 @@
 #define COOP_STORE16(ptr, v) asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(ptr), "v"(v) : "memory")
 #define COOP_STORE4(ptr, v) asm volatile("global_store_dword %0, %1, off sc1" : : "v"(ptr), "v"(v) : "memory")
 #define COOP_LOAD16(dst, ptr) asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(dst) : "v"(ptr) : "memory")
+#define COOP_LOAD4(dst, ptr) asm volatile("global_load_dword %0, %1, off sc1\n s_waitcnt vmcnt(0)" : "=v"(dst) : "v"(ptr) : "memory")
 #define COOP_WAIT_LOADS8(a, b, c, d, e, f, g, h) \
     asm volatile("s_waitcnt vmcnt(0)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f), "+v"(g), "+v"(h))
 #define COOP_DRAIN() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+// LDS allows one workgroup per CU = one wave per SIMD: the register allocator may use the whole file instead of spilling at 128
+#define COOP_ONE_WAVE_PER_SIMD __attribute__((amdgpu_waves_per_eu(1, 2)))
+// MFMA results read by an asm store: the hazard recognizer does not look inside inline asm, so the wait states an 8-pass MFMA needs
+// before a VMEM instruction may read its destination (11) are spelled out
+#define COOP_MFMA_SETTLE() asm volatile("s_nop 15\n s_nop 3" ::: "memory")
 #define COOP_FLAG_STORE(p, v) __hip_atomic_store((p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
 #define COOP_FLAG_LOAD(p) __hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
 #define COOP_BACKOFF() __builtin_amdgcn_s_sleep(2)
+#endif
+
+#if defined(VAME_PROBE) && !defined(VAME_EMU)   // tuning build (make probe): per-wave phase cycle sums, tools/coop_probe.py
+__device__ long long* g_coop_probe;
+extern "C" int vame_probe_set_coop(long long* p) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_coop_probe), &p, sizeof(p)); }
+#define COOP_PHASE_DECL() long long pp_[8] = {0}, pa_ = (long long)__builtin_amdgcn_s_memtime()
+#define COOP_PHASE(i) do { const long long t_ = (long long)__builtin_amdgcn_s_memtime(); pp_[i] += t_ - pa_; pa_ = t_; } while (0)
+#define COOP_PHASE_END()                                                                            \
+    if ((threadIdx.x & 63) == 0 && g_coop_probe) {                                                   \
+        long long* o_ = g_coop_probe + ((long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * 8;         \
+        for (int i_ = 0; i_ < 8; ++i_) o_[i_] = pp_[i_];                                             \
+    }
+#else
+#define COOP_PHASE_DECL()
+#define COOP_PHASE(i)
+#define COOP_PHASE_END()
 #endif
 
 // Poll budget of one hand-off wait.  A stuck group reports through *status instead of hanging the queue; once *status != 0 every
@@ -85,7 +110,7 @@ __device__ __forceinline__ bool coop_map(int ngroups, int& g, int& m, int& half)
 // and step against 128 of 64 cycles on three of four SIMDs in the 32 x 32 form of rounds 2-3).  Both K halves are summed separately
 // and then added in either form, so a launch gives the same bits whichever R its row range selects.
 template <int H, int R>
-__global__ __launch_bounds__(256) void gru_coop_fwd_kernel(GruFwdParams P, int* __restrict__ flags, int base, int* __restrict__ status,
+__global__ __launch_bounds__(256) COOP_ONE_WAVE_PER_SIMD void gru_coop_fwd_kernel(GruFwdParams P, int* __restrict__ flags, int base, int* __restrict__ status,
                                                            int max_polls) {
     constexpr int NM = H / 32, NH = 32 / R, LDW = H + 4, LDH = H + 4, NCH = H / 16, HALF = NCH / 2;
     static_assert(R == 32 || R == 16, "row tiles of 32 or 16");
@@ -145,12 +170,17 @@ __global__ __launch_bounds__(256) void gru_coop_fwd_kernel(GruFwdParams P, int* 
 #pragma unroll
     for (int i = 0; i < 4; ++i) hprev[i] = hs[(lrow + i) * LDH + col0 + lcol];
     const float* gi_lane = S.gi + (int64_t)(row0 + lrow) * S.gi_row + col0 + lcol;
+    // rows past the batch re-read the group's first row: a load under a per-lane condition makes hipcc wait for every load in flight
+    // before the other branch may write the register (probe: ~2000 cycles per step in the BPTT kernel's prefetch); h of such rows is
+    // never published or stored, so what they compute from is immaterial
+    int64_t gi_off[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) gi_off[i] = (lrow + i < nvalid ? (int64_t)i : -(int64_t)lrow) * S.gi_row;
     auto load_gi = [&](int t, float (&dst)[3][4]) {
 #pragma unroll
         for (int gt = 0; gt < 3; ++gt)
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
-                dst[gt][i] = (lrow + i < nvalid) ? gi_lane[(int64_t)i * S.gi_row + (int64_t)t * S.gi_t + gt * H] : 0.f;
+            for (int i = 0; i < 4; ++i) dst[gt][i] = gi_lane[gi_off[i] + (int64_t)t * S.gi_t + gt * H];
     };
 #pragma unroll
     for (int gt = 0; gt < 3; ++gt)
@@ -161,6 +191,7 @@ __global__ __launch_bounds__(256) void gru_coop_fwd_kernel(GruFwdParams P, int* 
     const float* brow = &wl[(ch * 16 + c16) * LDW + 4 * kg];
     float* y_lane = S.y + (int64_t)(row0 + lrow) * S.y_row + col0 + lcol;
 
+    COOP_PHASE_DECL();
     for (int step = 0; step < T; ++step) {
         const int t = S.reverse ? T - 1 - step : step;
         f32x4 lo[3], hi[3];
@@ -172,23 +203,60 @@ __global__ __launch_bounds__(256) void gru_coop_fwd_kernel(GruFwdParams P, int* 
         if (owner && more) load_gi(S.reverse ? t - 1 : t + 1, gnext);      // lands during the MFMA loop
         const bool recur = !(step == 0 && S.h0 == nullptr);                // zero initial state: no recurrent term in the first step
         if (recur) {
-            auto chunk = [&](int c, f32x4 (&acc)[3]) {
-                const float4 a = *reinterpret_cast<const float4*>(arow + 16 * c);
-#pragma unroll
-                for (int gt = 0; gt < 3; ++gt) {
-                    const float4 b = *reinterpret_cast<const float4*>(brow + gt * 32 * LDW + 16 * c);
-                    acc[gt] = MFMA_16x16x4(a.x, b.x, acc[gt]); acc[gt] = MFMA_16x16x4(a.y, b.y, acc[gt]);
-                    acc[gt] = MFMA_16x16x4(a.z, b.z, acc[gt]); acc[gt] = MFMA_16x16x4(a.w, b.w, acc[gt]);
-                }
-            };
+            // the next chunk's fragments are requested before the current chunk's MFMAs (registers double-buffered, order pinned): left to
+            // itself hipcc issues every chunk's ds_reads right in front of their first use and the LDS latency is exposed once per chunk
+            // (probe: 51 cycles per 32-cycle MFMA).  Element-major issue order: consecutive MFMAs go to different accumulators.
+            auto ldf = [](const float* p_) { return *reinterpret_cast<const f32x4*>(p_); };
             if (R == 32) {
+                f32x4 a0 = ldf(arow), a1 = ldf(arow + 16 * HALF), b0[3], b1[3];
+#pragma unroll
+                for (int gt = 0; gt < 3; ++gt) { b0[gt] = ldf(brow + gt * 32 * LDW); b1[gt] = ldf(brow + gt * 32 * LDW + 16 * HALF); }
 #pragma unroll 2
-                for (int c = 0; c < HALF; ++c) { chunk(c, lo); chunk(c + HALF, hi); }
+                for (int c = 0; c < HALF; ++c) {
+                    const int cn = c + 1 < HALF ? c + 1 : c;
+                    const f32x4 na0 = ldf(arow + 16 * cn), na1 = ldf(arow + 16 * (cn + HALF));
+                    f32x4 nb0[3], nb1[3];
+#pragma unroll
+                    for (int gt = 0; gt < 3; ++gt) { nb0[gt] = ldf(brow + gt * 32 * LDW + 16 * cn); nb1[gt] = ldf(brow + gt * 32 * LDW + 16 * (cn + HALF)); }
+                    SCHED_FENCE();
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+#pragma unroll
+                        for (int gt = 0; gt < 3; ++gt) {
+                            lo[gt] = MFMA_16x16x4(a0[e], b0[gt][e], lo[gt]);
+                            hi[gt] = MFMA_16x16x4(a1[e], b1[gt][e], hi[gt]);
+                        }
+                    SCHED_FENCE();
+                    a0 = na0; a1 = na1;
+#pragma unroll
+                    for (int gt = 0; gt < 3; ++gt) { b0[gt] = nb0[gt]; b1[gt] = nb1[gt]; }
+                }
             } else {
-#pragma unroll 4
-                for (int c = 0; c < HALF; ++c) chunk(kh * HALF + c, lo);
+                const float* ar = arow + 16 * kh * HALF;
+                const float* br = brow + 16 * kh * HALF;
+                f32x4 a0 = ldf(ar), b0[3];
+#pragma unroll
+                for (int gt = 0; gt < 3; ++gt) b0[gt] = ldf(br + gt * 32 * LDW);
+#pragma unroll 2
+                for (int c = 0; c < HALF; ++c) {
+                    const int cn = c + 1 < HALF ? c + 1 : c;
+                    const f32x4 na0 = ldf(ar + 16 * cn);
+                    f32x4 nb0[3];
+#pragma unroll
+                    for (int gt = 0; gt < 3; ++gt) nb0[gt] = ldf(br + gt * 32 * LDW + 16 * cn);
+                    SCHED_FENCE();
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+#pragma unroll
+                        for (int gt = 0; gt < 3; ++gt) lo[gt] = MFMA_16x16x4(a0[e], b0[gt][e], lo[gt]);
+                    SCHED_FENCE();
+                    a0 = na0;
+#pragma unroll
+                    for (int gt = 0; gt < 3; ++gt) b0[gt] = nb0[gt];
+                }
             }
         }
+        COOP_PHASE(0);
         if (R == 16) {                                                     // the upper K half of each tile crosses to the lower half's wave
             if (kh == 1) {
 #pragma unroll
@@ -204,6 +272,7 @@ __global__ __launch_bounds__(256) void gru_coop_fwd_kernel(GruFwdParams P, int* 
                     for (int i = 0; i < 4; ++i) hi[gt][i] = pb[(ch * 12 + gt * 4 + i) * 64 + lane];
             }
         }
+        COOP_PHASE(1);
         float ca[4], cb[4], us[4], rs[4], an[4];
         if (owner) {
 #pragma unroll
@@ -228,8 +297,11 @@ __global__ __launch_bounds__(256) void gru_coop_fwd_kernel(GruFwdParams P, int* 
                     for (int i = 0; i < 4; ++i) gcur[gt][i] = gnext[gt][i];
             }
         }
+        COOP_PHASE(2);
         COOP_DRAIN();
+        COOP_PHASE(3);
         __syncthreads();
+        COOP_PHASE(4);
         // the stash leaves AFTER the slice of h_t has been published and the flag raised: behind the hand-off its stores overlap the
         // poll and the tile read, and the next step's drain comes a whole step later
         auto store_stash = [&]() {
@@ -255,6 +327,7 @@ __global__ __launch_bounds__(256) void gru_coop_fwd_kernel(GruFwdParams P, int* 
             }
         }
         __syncthreads();
+        COOP_PHASE(5);
         {
             constexpr int PER = R * (H / 4) / 256;                        // float4 per thread (8 at R = 32, H = 256)
             static_assert(PER == 8 || PER == 4 || PER == 2, "tile copy is written for H = 128 / 256");
@@ -273,8 +346,11 @@ __global__ __launch_bounds__(256) void gru_coop_fwd_kernel(GruFwdParams P, int* 
                 *reinterpret_cast<f32x4*>(&hs[r * LDH + 4 * c4]) = v[i];
             }
         }
+        COOP_PHASE(6);
         __syncthreads();
+        COOP_PHASE(7);
     }
+    COOP_PHASE_END();
     if (S.hn && owner) {
 #pragma unroll
         for (int i = 0; i < 4; ++i)
@@ -314,8 +390,8 @@ static int coop_cu_count() {
 #endif
 }
 
-template <int H> static size_t coop_bwd_lds();
-template <int H> __global__ void gru_coop_bwd_kernel(GruBwdParams, float*, int*, int, int*, int);
+template <int H, int R> static size_t coop_bwd_lds();
+template <int H, int R> __global__ __launch_bounds__(256) COOP_ONE_WAVE_PER_SIMD void gru_coop_bwd_kernel(GruBwdParams, float*, int*, int, int*, int);
 // The runtime's own answer to "how many of these workgroups does one CU hold" (registers, LDS, waves): every cooperative kernel
 // must get >= 1, and the grid is then limited to ONE workgroup per CU (their LDS footprints exclude a second one anyway).
 static int coop_kernels_resident(int H) {
@@ -331,13 +407,15 @@ static int coop_kernels_resident(int H) {
             int n16 = 0;
             e1 = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nf, gru_coop_fwd_kernel<256, 32>, 256, coop_fwd_lds<256, 32>());
             if (e1 == hipSuccess) e1 = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n16, gru_coop_fwd_kernel<256, 16>, 256, coop_fwd_lds<256, 16>());
-            e2 = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, gru_coop_bwd_kernel<256>, 256, coop_bwd_lds<256>());
+            e2 = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, gru_coop_bwd_kernel<256, 32>, 256, coop_bwd_lds<256, 32>());
+            if (e2 == hipSuccess) e2 = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n16, gru_coop_bwd_kernel<256, 16>, 256, coop_bwd_lds<256, 16>());
             nf = nf < n16 ? nf : n16;
         } else {
             int n16 = 0;
             e1 = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nf, gru_coop_fwd_kernel<128, 32>, 256, coop_fwd_lds<128, 32>());
             if (e1 == hipSuccess) e1 = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n16, gru_coop_fwd_kernel<128, 16>, 256, coop_fwd_lds<128, 16>());
-            e2 = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, gru_coop_bwd_kernel<128>, 256, coop_bwd_lds<128>());
+            e2 = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, gru_coop_bwd_kernel<128, 32>, 256, coop_bwd_lds<128, 32>());
+            if (e2 == hipSuccess) e2 = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n16, gru_coop_bwd_kernel<128, 16>, 256, coop_bwd_lds<128, 16>());
             nf = nf < n16 ? nf : n16;
         }
         r = (e1 == hipSuccess && e2 == hipSuccess && nf >= 1 && nb >= 1) ? 1 : 0;
@@ -411,91 +489,122 @@ extern "C" int vame_gru_coop_fwd_f32(const int64_t* desc, int nstreams, int B, i
 
 // ------------------------------------------------------------------------------------------------------------- backward
 // BPTT with the same split: member m owns hidden columns C_m = [32m, 32m+32).  Per step it turns dh_t[:, C_m] (+ dy) into its
-// slice of dG (the BPTT coefficients of its columns come from its part of the forward stash), multiplies the 32 x 96 tile
+// slice of dG (the BPTT coefficients of its columns come from its part of the forward stash), multiplies the R x 96 tile
 // [da_r | da_z | dgh_n] with its 96 x H slice of W_hh (LDS-resident, taken from the backward-packed weights) -- a partial
 // dh_{t-1} over ALL H columns -- and the members reduce-scatter those partials through a double-buffered exchange buffer:
 // write-through stores + flag, then every member sums the S partials of its own 32 columns in member order and adds the
 // u-gated carry.  Same descriptor table / dG / dbias / dh0 contract as vame_gru_seq_bwd_f32; results equal up to the
 // summation order of that K = 3H contraction (split by member here).
-template <int H>
-__global__ __launch_bounds__(256) void gru_coop_bwd_kernel(GruBwdParams P, float* __restrict__ xbuf, int* __restrict__ flags, int base,
+//
+// Round 4: 16 x 16 x 4 MFMA tiles and R = 32 or 16 rows per group like the forward kernel.  A lane of the element-wise phase owns
+// four consecutive rows of one column -- one float4 of each stash quantity -- which is also one accumulator of a 16 x 16 tile, so
+// the partials leave the MFMA waves as float4 packets straight from the accumulators ([column tile][4-row group][column] in the
+// exchange buffer), the reduce-scatter lands in the registers of the lane that needs the sum for the next step, and neither the
+// partial tile nor the carry passes through LDS.  The two 16-row groups of a tile add their bias partials in a fixed order
+// (the upper one hands its sums to the lower one at the end of the launch), and the 32-row form sums in the same order.
+template <int H, int R>
+__global__ __launch_bounds__(256) COOP_ONE_WAVE_PER_SIMD void gru_coop_bwd_kernel(GruBwdParams P, float* __restrict__ xbuf, int* __restrict__ flags, int base,
                                                            int* __restrict__ status, int max_polls) {
-    constexpr int NM = H / 32, LDG = 132, LDP = H + 4, LDC = 36, TPW = NM / 4;      // TPW: 32-column output tiles per wave
-    static_assert(NM == 8 || NM == 4, "written for H = 128 / 256");
+    constexpr int NM = H / 32, NH = 32 / R, LDK = 100, LDG = 132, NCT = H / 16, TPW = NCT * (R / 16) / 4, RG = R / 4;
+    static_assert((NM == 8 || NM == 4) && (R == 32 || R == 16), "written for H = 128 / 256, 32- or 16-row groups");
     VAME_DYN_SMEM(smem_raw);
-    f32x4* wl = reinterpret_cast<f32x4*>(smem_raw);                     // [NM col tiles][12 chunks][64] B fragments
-    float* gs = reinterpret_cast<float*>(wl + NM * 12 * 64);           // [32][LDG]  da_r | da_z | dgh_n | dgi_n of this member's columns
-    float* ps = gs + 32 * LDG;                                          // [32][LDP]  partial dh_{t-1} over all H columns
-    float* cd = ps + 32 * LDP;                                          // [32][LDC]  dh_t slice in, u-gated carry / reduced dh_{t-1} out
-    int g, m;
-    if (!coop_map<NM>(P.nstreams * P.ntiles, g, m)) return;
+    float* wl = reinterpret_cast<float*>(smem_raw);                    // [H][LDK]  W_hh[gate*H + C_m][n] as wl[n][gate*32 + j]
+    float* gs = wl + H * LDK;                                           // [R][LDG]  da_r | da_z | dgh_n | dgi_n of this member's columns
+    int g, m, half;
+    if (!coop_map<NM, NH>(P.nstreams * P.ntiles, g, m, half)) return;
     const bool inject = max_polls < 0;
     if (inject) max_polls = COOP_DEFAULT_POLLS;
     const int sidx = g % P.nstreams, tile = g / P.nstreams + P.tile_off;
     const GruBwdStream& S = P.s[sidx];
     const int B = P.B, T = (int)S.T;
-    const int tid = threadIdx.x, lane = tid & 63, li = lane & 31, hh = lane >> 5;
-    const int w = UNIFORM(tid >> 6);
-    const int row0 = tile * 32, col0 = 32 * m, lrow = 4 * hh;
+    const int row0 = tile * 32 + half * R, col0 = 32 * m;
     const int nvalid = B - row0;
+    if (nvalid <= 0) return;                                            // the upper half of a last tile with <= 16 rows
+    const int tid = threadIdx.x, lane = tid & 63, c16 = lane & 15, kg = lane >> 4;
+    const int w = UNIFORM(tid >> 6);
+    // element-wise phase: lane (hh, li) of wave w < R/8 owns rows 8w + 4hh .. + 3 of the group, column li of the slice
+    const bool ew = w < R / 8;
+    const int li = lane & 31, hh = lane >> 5, rgl = 2 * w + hh, erow = 4 * rgl;         // 4-row group / first row inside the group
+    const int sq = (half * R + erow) >> 3;                             // q of the 32-row stash tile (hh is the same)
     const int prow = tid >> 3, pc4 = tid & 7;
-    int* gflags = flags + (int64_t)g * NM;
+    const int gidx = g * NH + half;
+    int* gflags = flags + (int64_t)gidx * NM;
 
-    {   // W_hh rows {gate*H + C_m} x all columns, from the backward pack: wp_bwd[((ct*(3H/8) + c)*64 + l)*4 + e]
+    {   // W_hh rows {gate*H + C_m} x all columns, from the backward pack: wp_bwd[((ct*(3H/8) + c)*64 + l)*4 + e] = W[8c + 4(l>>5) + e][32ct + (l&31)]
         const f32x4* src = reinterpret_cast<const f32x4*>(S.wpt);
         for (int i = tid; i < NM * 12 * 64; i += 256) {
-            const int ct = i / (12 * 64), rem = i % (12 * 64), gg = rem / 256, c64 = rem % 256;
-            wl[i] = src[((int64_t)ct * (3 * H / 8) + (gg * H + 32 * m) / 8) * 64 + c64];
+            const int ct = i / (12 * 64), rem = i % (12 * 64), gg = rem / 256, c64 = rem % 256, cc = c64 / 64, l = c64 % 64;
+            *reinterpret_cast<f32x4*>(&wl[(32 * ct + (l & 31)) * LDK + gg * 32 + 8 * cc + 4 * (l >> 5)]) =
+                src[((int64_t)ct * (3 * H / 8) + (gg * H + 32 * m) / 8) * 64 + c64];
         }
     }
-    {
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (S.dhn && prow < nvalid) {
-            const float* p = S.dhn + (int64_t)(row0 + prow) * S.dhn_row + col0 + 4 * pc4;
-            v = make_float4(p[0], p[1], p[2], p[3]);
-        }
-        *reinterpret_cast<float4*>(&cd[prow * LDC + 4 * pc4]) = v;
+    float carry[4] = {0.f, 0.f, 0.f, 0.f};
+    if (ew && S.dhn) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (erow + j < nvalid) carry[j] = S.dhn[(int64_t)(row0 + erow + j) * S.dhn_row + col0 + li];
     }
     const float4* stash = reinterpret_cast<const float4*>(S.stash);
     float4 sa, sb, su, sr, sg;
     float dyv[4];
+    // The next step's coefficients and dy are requested one step ahead, by EVERY wave, unconditionally: behind a per-wave or per-step
+    // condition the loaded values reach the loop-carried registers through copies, and hipcc waits for the loads right where they were
+    // issued (probe: 1500-3000 cycles per step).  Waves without an element-wise share re-read wave 0/1's packets, a missing dy reads the
+    // stash instead, rows past the batch re-read the group's first row -- all masked where the values are used.
+    const int wl_ = ew ? w : (w & (R / 8 - 1));
+    const int sq_l = (half * R + 8 * wl_ + 4 * hh) >> 3, erow_l = 8 * wl_ + 4 * hh;
+    const float* dy_lane = S.dy ? S.dy + (int64_t)(row0 + erow_l) * S.dy_row + col0 + li : S.stash;
+    int64_t dy_off[4];
+    float dy_mask[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        dy_off[j] = S.dy ? (erow_l + j < nvalid ? (int64_t)j : -(int64_t)erow_l) * S.dy_row : 0;
+        dy_mask[j] = (S.dy && ew && erow + j < nvalid) ? 1.0f : 0.0f;
+    }
+    const int64_t dy_t = S.dy ? S.dy_t : 0;
     auto load_step = [&](int step) {
         const int fstep = T - 1 - step;
         const int t = S.reverse ? T - 1 - fstep : fstep;
-        const float4* sp = stash + ((((int64_t)tile * T + t) * NM + m) * 20 + w) * 64 + lane;       // rq = w: rows CR(4w..4w+3)
+        const float4* sp = stash + ((((int64_t)tile * T + t) * NM + m) * 20 + sq_l) * 64 + lane;
         sa = sp[0 * 4 * 64]; sb = sp[1 * 4 * 64]; su = sp[2 * 4 * 64]; sr = sp[3 * 4 * 64]; sg = sp[4 * 4 * 64];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int row = CR(4 * w + j) + lrow;
-            dyv[j] = (S.dy && row < nvalid) ? S.dy[(int64_t)(row0 + row) * S.dy_row + (int64_t)t * S.dy_t + col0 + li] : 0.f;
-        }
+        for (int j = 0; j < 4; ++j) dyv[j] = dy_lane[dy_off[j] + (int64_t)t * dy_t];
     };
+    sa = sb = su = sr = sg = make_float4(0.f, 0.f, 0.f, 0.f);
+    dyv[0] = dyv[1] = dyv[2] = dyv[3] = 0.f;
     load_step(0);
     float dbs0 = 0.f, dbs1 = 0.f, dbs2 = 0.f, dbs3 = 0.f;
+    // MFMA phase: wave w owns the 16-row half rh and TPW column tiles from ct0 on
+    const int rh = R == 32 ? (w >> 1) : 0, ct0 = R == 32 ? (w & 1) * TPW : w * TPW;
+    const float* arow = &gs[(rh * 16 + c16) * LDG + 4 * kg];
+    const float* brow = &wl[(ct0 * 16 + c16) * LDK + 4 * kg];
     __syncthreads();
 
+    COOP_PHASE_DECL();
     for (int step = 0; step < T; ++step) {
         const int fstep = T - 1 - step;
         const int t = S.reverse ? T - 1 - fstep : fstep;
-        {
+        if (ew) {
             const float av[4] = {sa.x, sa.y, sa.z, sa.w}, bv[4] = {sb.x, sb.y, sb.z, sb.w}, uv[4] = {su.x, su.y, su.z, su.w},
                         rv[4] = {sr.x, sr.y, sr.z, sr.w}, gv[4] = {sg.x, sg.y, sg.z, sg.w};
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const int row = CR(4 * w + j) + lrow;
-                const float d = cd[row * LDC + li] + dyv[j];
+                const float d = carry[j] + (dy_mask[j] != 0.f ? dyv[j] : 0.f);
                 const float dan = d * av[j];
                 const float dau = d * bv[j];
                 const float dgh = dan * rv[j];
                 const float dar = dgh * gv[j] * (1.0f - rv[j]);
-                cd[row * LDC + li] = d * uv[j];                      // dh carried through the update gate
-                float* gw = &gs[row * LDG + li];
+                carry[j] = d * uv[j];                                // dh carried through the update gate
+                float* gw = &gs[(erow + j) * LDG + li];
                 gw[0] = dar; gw[32] = dau; gw[64] = dgh; gw[96] = dan;
                 dbs0 += dar; dbs1 += dau; dbs2 += dan; dbs3 += dgh;
             }
         }
+        load_step(step + 1 < T ? step + 1 : step);  // (the last step re-reads its own)
+        COOP_PHASE(0);
         __syncthreads();
-        if (prow < nvalid) {    // dG[b][t][da_r | da_z | dgi_n | dgh_n] columns C_m: LDS blocks (r, z, gh_n, gi_n) -> global (r, z, gi_n, gh_n)
+        COOP_PHASE(1);
+        if (tid < R * 8 && prow < nvalid) {    // dG[b][t][da_r | da_z | dgi_n | dgh_n] columns C_m: LDS blocks (r, z, gh_n, gi_n) -> global (r, z, gi_n, gh_n)
             float* dgt = S.dg + ((int64_t)(row0 + prow) * T + t) * 4 * H + col0 + 4 * pc4;
             const float* src = &gs[prow * LDG + 4 * pc4];
             *reinterpret_cast<float4*>(dgt) = *reinterpret_cast<const float4*>(src);
@@ -503,44 +612,45 @@ __global__ __launch_bounds__(256) void gru_coop_bwd_kernel(GruBwdParams P, float
             *reinterpret_cast<float4*>(dgt + 3 * H) = *reinterpret_cast<const float4*>(src + 64);
             *reinterpret_cast<float4*>(dgt + 2 * H) = *reinterpret_cast<const float4*>(src + 96);
         }
-        if (step + 1 < T) load_step(step + 1);
         if (step + 1 == T && S.dh0 == nullptr) break;                     // nobody asks for dh before the first step
+        // ---- partial dh_{t-1} = [da_r | da_z | dgh_n] W_hh[C_m rows], published straight from the accumulators (write-through)
+        float* xs = xbuf + ((int64_t)(gidx * 2 + (step & 1)) * NM) * R * H;
+        COOP_PHASE(2);
         {
-            f32x16 acc[TPW];
+            f32x4 acc[TPW];
 #pragma unroll
-            for (int i = 0; i < TPW; ++i)
+            for (int i = 0; i < TPW; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+            auto ldf = [](const float* p_) { return *reinterpret_cast<const f32x4*>(p_); };
+            f32x4 a = ldf(arow), b[TPW];            // next chunk requested before this chunk's MFMAs (see the forward kernel)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
-            const float* arow = &gs[li * LDG + 4 * hh];
-#pragma unroll 4
-            for (int c = 0; c < 12; ++c) {
-                const float4 a = *reinterpret_cast<const float4*>(arow + 8 * c);
+            for (int i = 0; i < TPW; ++i) b[i] = ldf(brow + i * 16 * LDK);
+#pragma unroll 2
+            for (int c = 0; c < 6; ++c) {
+                const int cn = c + 1 < 6 ? c + 1 : c;
+                const f32x4 na = ldf(arow + 16 * cn);
+                f32x4 nb[TPW];
 #pragma unroll
-                for (int i = 0; i < TPW; ++i) {
-                    const f32x4 b = wl[((w * TPW + i) * 12 + c) * 64 + lane];
-                    acc[i] = MFMA_32x32x2(a.x, b[0], acc[i]); acc[i] = MFMA_32x32x2(a.y, b[1], acc[i]);
-                    acc[i] = MFMA_32x32x2(a.z, b[2], acc[i]); acc[i] = MFMA_32x32x2(a.w, b[3], acc[i]);
-                }
+                for (int i = 0; i < TPW; ++i) nb[i] = ldf(brow + i * 16 * LDK + 16 * cn);
+                SCHED_FENCE();
+#pragma unroll
+                for (int e = 0; e < 4; ++e)           // element-major: consecutive MFMAs go to different accumulators
+#pragma unroll
+                    for (int i = 0; i < TPW; ++i) acc[i] = MFMA_16x16x4(a[e], b[i][e], acc[i]);
+                SCHED_FENCE();
+                a = na;
+#pragma unroll
+                for (int i = 0; i < TPW; ++i) b[i] = nb[i];
             }
+            float* xm = xs + (int64_t)m * R * H + ((rh * 4 + kg) * 16 + c16) * 4;          // packet (column tile, 4-row group, column)
+            COOP_MFMA_SETTLE();
+            COOP_PHASE(3);
 #pragma unroll
-            for (int i = 0; i < TPW; ++i)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) ps[(CR(r) + lrow) * LDP + (w * TPW + i) * 32 + li] = acc[i][r];
-        }
-        __syncthreads();
-        // ---- publish the 32 x H partial (write-through), raise the flag, wait for everybody, sum this member's columns
-        float* xs = xbuf + ((int64_t)(g * 2 + (step & 1)) * NM) * 32 * H;
-        {
-            constexpr int PER = 32 * (H / 4) / 256;
-#pragma unroll
-            for (int i = 0; i < PER; ++i) {
-                const int idx = tid + i * 256, r = idx / (H / 4), c4 = idx % (H / 4);
-                const f32x4 v = *reinterpret_cast<const f32x4*>(&ps[r * LDP + 4 * c4]);
-                COOP_STORE16(xs + ((int64_t)m * 32 + r) * H + 4 * c4, v);
-            }
+            for (int i = 0; i < TPW; ++i) COOP_STORE16(xm + (int64_t)(ct0 + i) * RG * 64, acc[i]);
         }
         COOP_DRAIN();
+        COOP_PHASE(4);
         __syncthreads();
+        COOP_PHASE(5);
         if (tid == 0) COOP_FLAG_STORE(&gflags[m], (int)((unsigned)base + (unsigned)step + 1u));
         if (tid < NM) {
             if (inject && step == 0 && tid == 0) atomicAdd(status, 1);          // fault injection (diagnostics): report, then wait normally
@@ -551,46 +661,81 @@ __global__ __launch_bounds__(256) void gru_coop_bwd_kernel(GruBwdParams P, float
             }
         }
         __syncthreads();
-        {
+        COOP_PHASE(6);
+        if (ew) {       // the S partials of this lane's packet (column tile 2m + (li >> 4), row group rgl, column li & 15), in member order
             f32x4 v[8];
+            const float* xr = xs + (((2 * m + (li >> 4)) * RG + rgl) * 16 + (li & 15)) * 4;
 #pragma unroll
             for (int mm = 0; mm < 8; ++mm) {
-                if (mm < NM) COOP_LOAD16(v[mm], xs + ((int64_t)mm * 32 + prow) * H + col0 + 4 * pc4); else v[mm] = v[0];
+                if (mm < NM) COOP_LOAD16(v[mm], xr + (int64_t)mm * R * H); else v[mm] = v[0];
             }
             COOP_WAIT_LOADS8(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]);
-            f32x4 s = *reinterpret_cast<const f32x4*>(&cd[prow * LDC + 4 * pc4]);
 #pragma unroll
-            for (int mm = 0; mm < NM; ++mm) s += v[mm];
-            *reinterpret_cast<f32x4*>(&cd[prow * LDC + 4 * pc4]) = s;
+            for (int mm = 0; mm < NM; ++mm) {
+                carry[0] += v[mm][0]; carry[1] += v[mm][1]; carry[2] += v[mm][2]; carry[3] += v[mm][3];
+            }
+        }
+        COOP_PHASE(7);
+    }
+    COOP_PHASE_END();
+    if (S.dh0 && ew) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (erow + j < nvalid) S.dh0[(int64_t)(row0 + erow + j) * S.dh0_row + col0 + li] = carry[j];
+    }
+    if (S.dbias) {      // per-column sums over the tile's rows and all steps: the 4-row groups' partials meet in LDS, 16 rows at a time
+        __syncthreads();                                                 // (the last step's dG pass has read gs)
+        float* red = gs;                                                 // [RG][4][32]
+        if (ew) {
+            red[(rgl * 4 + 0) * 32 + li] = dbs0; red[(rgl * 4 + 1) * 32 + li] = dbs1;
+            red[(rgl * 4 + 2) * 32 + li] = dbs2; red[(rgl * 4 + 3) * 32 + li] = dbs3;
         }
         __syncthreads();
-    }
-    if (S.dh0 && prow < nvalid) {
-        float* o = S.dh0 + (int64_t)(row0 + prow) * S.dh0_row + col0 + 4 * pc4;
-        const float* c = &cd[prow * LDC + 4 * pc4];
-        o[0] = c[0]; o[1] = c[1]; o[2] = c[2]; o[3] = c[3];
-    }
-    if (S.dbias) {      // per-column sums over the tile's rows and all steps: 2 half-waves x 4 waves of partials per column
-        float* red = ps;                                                 // [8][4][32]
-        const int slot = w * 2 + hh;
-        red[(slot * 4 + 0) * 32 + li] = dbs0; red[(slot * 4 + 1) * 32 + li] = dbs1;
-        red[(slot * 4 + 2) * 32 + li] = dbs2; red[(slot * 4 + 3) * 32 + li] = dbs3;
-        __syncthreads();
+        float s = 0.f;
+        const int k = (tid >> 5) & 3, c = tid & 31;
         if (tid < 128) {
-            const int k = tid >> 5, c = tid & 31;
-            float s = 0.f;
 #pragma unroll
-            for (int sl = 0; sl < 8; ++sl) s += red[(sl * 4 + k) * 32 + c];
-            S.dbias[(int64_t)tile * 4 * H + k * H + col0 + c] = s;
+            for (int sl = 0; sl < 4; ++sl) s += red[(sl * 4 + k) * 32 + c];
+            if (R == 32) {
+                float s2 = 0.f;
+#pragma unroll
+                for (int sl = 4; sl < 8; ++sl) s2 += red[((sl % RG) * 4 + k) * 32 + c];
+                s += s2;
+            }
         }
+        if (R == 16) {
+            // hand-over between the two 16-row groups of a tile: the upper one leaves its sums in the exchange slot it is not reading
+            // any more and raises its flag once more; the lower one adds them to its own and writes the tile's row
+            const bool partner = tile * 32 + 16 < B;
+            const int steps_x = S.dh0 ? T : T - 1;                       // exchange steps of this launch; the last one used parity (steps_x - 1) & 1
+            float* hx = xbuf + ((int64_t)((g * NH + 1) * 2 + (steps_x & 1)) * NM + m) * R * H;
+            int* pflag = flags + ((int64_t)(g * NH + 1) * NM + m);
+            const int done = (int)((unsigned)base + (unsigned)T + 1u);
+            if (half == 1) {
+                if (tid < 128) COOP_STORE4(hx + tid, s);
+                COOP_DRAIN();
+                __syncthreads();
+                if (tid == 0) COOP_FLAG_STORE(pflag, done);
+                return;
+            }
+            if (partner) {
+                if (tid == 0) {
+                    int polls = COOP_FLAG_LOAD(status) != 0 && !inject ? max_polls : 0;
+                    while ((int)((unsigned)COOP_FLAG_LOAD(pflag) - (unsigned)done) < 0) {
+                        COOP_BACKOFF();
+                        if (++polls > max_polls) { atomicAdd(status, 1); break; }
+                    }
+                }
+                __syncthreads();
+                if (tid < 128) { float o; COOP_LOAD4(o, hx + tid); s += o; }
+            }
+        }
+        if (tid < 128) S.dbias[(int64_t)tile * 4 * H + k * H + col0 + c] = s;
     }
 }
 
-template <int H>
-static size_t coop_bwd_lds() {
-    constexpr int NM = H / 32;
-    return (size_t)NM * 12 * 64 * 16 + (size_t)(32 * 132 + 32 * (H + 4) + 32 * 36) * 4;
-}
+template <int H, int R>
+static size_t coop_bwd_lds() { return (size_t)(H * 100 + R * 132) * 4; }
 
 extern "C" int64_t vame_gru_coop_xbuf_floats(int nstreams, int B, int H) { return (int64_t)nstreams * cdiv64(B, 32) * 2 * 32 * H * (H / 32); }
 
@@ -612,13 +757,19 @@ extern "C" int vame_gru_coop_bwd_f32(const int64_t* desc, int nstreams, int B, i
 #ifdef VAME_EMU
     emu::g_coop = true;
 #endif
-    if (H == 256) {
-        COOP_ALLOW_LDS(gru_coop_bwd_kernel<256>, coop_bwd_lds<256>());
-        hipLaunchKernelGGL((gru_coop_bwd_kernel<256>), dim3(coop_grid<8>(ngroups)), dim3(256), coop_bwd_lds<256>(), st, P, xbuf, flags, epoch_base, status, g_coop_polls);
-    } else {
-        COOP_ALLOW_LDS(gru_coop_bwd_kernel<128>, coop_bwd_lds<128>());
-        hipLaunchKernelGGL((gru_coop_bwd_kernel<128>), dim3(coop_grid<4>(ngroups)), dim3(256), coop_bwd_lds<128>(), st, P, xbuf, flags, epoch_base, status, g_coop_polls);
-    }
+    VAME_CHECK_ARG(P.kernel == VAME_GRU_KERNEL_AUTO || P.kernel == VAME_GRU_KERNEL_LOCKSTEP, VAME_E_UNSUPPORTED,
+                   "gru_coop_bwd: kernel option %d (AUTO, or LOCKSTEP = 32-row groups)", P.kernel);
+    const bool r16 = P.kernel == VAME_GRU_KERNEL_AUTO && coop_rows16(ngroups, H);
+#define COOP_BWD_LAUNCH(HH, RR)                                                                                                  \
+    do {                                                                                                                         \
+        const size_t lds_ = coop_bwd_lds<HH, RR>();                                                                              \
+        const int grid_ = coop_grid<HH / 32>(ngroups) * (32 / RR);                                                               \
+        COOP_ALLOW_LDS((gru_coop_bwd_kernel<HH, RR>), lds_);                                                                     \
+        hipLaunchKernelGGL((gru_coop_bwd_kernel<HH, RR>), dim3(grid_), dim3(256), lds_, st, P, xbuf, flags, epoch_base, status, g_coop_polls); \
+    } while (0)
+    if (H == 256) { if (r16) COOP_BWD_LAUNCH(256, 16); else COOP_BWD_LAUNCH(256, 32); }
+    else          { if (r16) COOP_BWD_LAUNCH(128, 16); else COOP_BWD_LAUNCH(128, 32); }
+#undef COOP_BWD_LAUNCH
 #ifdef VAME_EMU
     emu::g_coop = false;
 #endif

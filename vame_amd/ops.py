@@ -331,8 +331,9 @@ def gru_coop_fwd(streams, B, H, state: CoopState, rows=(0, 0), kernel=KERNEL_AUT
     _lib.check(rc, "vame_gru_coop_fwd_f32")
 
 
-def gru_coop_bwd(streams, B, H, state: CoopState, rows=(0, 0)):
+def gru_coop_bwd(streams, B, H, state: CoopState, rows=(0, 0), kernel=KERNEL_AUTO):
     d = _desc_tensor(streams, GB["N"])
+    d[0, GB["OPT"]] = gru_opt(kernel, -1, -1)
     need = _lib.lib().vame_gru_coop_xbuf_floats(len(streams), rows[1] or B, H)
     if getattr(state, "xbuf", None) is None or state.xbuf.numel() < need:
         state.xbuf = torch.empty(need, device=state.flags.device)
