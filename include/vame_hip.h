@@ -225,12 +225,16 @@ int vame_mask_scale_f32(const float* x, int64_t off, int64_t ld, int64_t seg, in
 /* y = a*x + y style helpers for the host orchestration */
 int vame_axpy_f32(const float* x, float a, float* y, int64_t n, void* stream);
 
-/* ---- column-split GRU forward for small batches (vame_amd/csrc/gru_coop.hip): same descriptor table, stash and sequence layout
- * and bit-identical results as vame_gru_seq_fwd_f32, but a 32-row tile is shared by H/32 workgroups that keep their slice of W_hh in
- * LDS and exchange h_t through the output sequence (needs GF_Y, a precomputed gi, H = 128 or 256, and a grid that fits one
- * workgroup per CU: vame_gru_coop_supported).  flags: vame_gru_coop_flag_ints() ints, zeroed ONCE by the caller and then only
- * passed back; epoch_base: a value that grows by more than T between launches sharing `flags`; *status is incremented if a
- * bounded poll ever expires (results are then undefined, the launch still terminates). */
+/* ---- column-split GRU forward for small batches (vame_amd/csrc/gru_coop.hip): same descriptor table, stash and sequence layout as
+ * vame_gru_seq_fwd_f32, results equal to summation-order rounding (K = H is summed in two halves of 16 x 16 x 4 MFMAs; the same bits
+ * for every form a launch can take).  A 32-row tile -- or each 16-row half of it, when twice the workgroups still get a CU each -- is
+ * shared by H/32 workgroups that keep their slice of W_hh in LDS and hand their 32 columns of h_t to each other every step as
+ * self-validating (value, tag) pairs (needs GF_Y, a precomputed gi, H = 128 or 256, and a grid that fits one workgroup per CU:
+ * vame_gru_coop_supported).  GF_OPT / GB_OPT kernel: AUTO, or LOCKSTEP = 32-row groups even where 16-row groups fit.
+ * flags: vame_gru_coop_flag_ints() ints (flag words + the hand-off packets), initialised ONCE by the caller to a value older than
+ * the first epoch_base (zero for a fresh epoch counter) and then only passed back; epoch_base: a value that grows by at least T + 2
+ * between launches sharing `flags`; *status is incremented if a bounded poll ever expires (results are then undefined, the launch
+ * still terminates). */
 int64_t vame_gru_coop_flag_ints(int nstreams, int B, int H);
 int vame_gru_coop_supported(int nstreams, int B, int H);   /* grid <= CUs and the runtime's occupancy query admits each kernel */
 /* Poll budget of one hand-off wait (0 = default, about 0.3 s on the device); returns the previous value.  Process-wide;
@@ -240,7 +244,8 @@ int vame_gru_coop_set_poll_limit(int polls);
 int vame_gru_coop_fwd_f32(const int64_t* desc, int nstreams, int B, int H, int row0, int nrows, int* flags, int epoch_base, int* status,
                           void* stream);   /* rows [row0, row0+nrows) of the batch, row0 % 32 == 0; nrows = 0: all rows */
 /* BPTT counterpart (contract of vame_gru_seq_bwd_f32; results equal up to the summation order of the K = 3H contraction, which is
- * split by member): xbuf = vame_gru_coop_xbuf_floats() floats of scratch for the per-step reduce-scatter of the dh partials. */
+ * split by member; the same bits in 32- and 16-row groups): xbuf = vame_gru_coop_xbuf_floats() floats of scratch for the per-step
+ * reduce-scatter of the dh partials (and, at the end of a launch in 16-row groups, the hand-over of the upper group's bias sums). */
 int64_t vame_gru_coop_xbuf_floats(int nstreams, int B, int H);
 int vame_gru_coop_bwd_f32(const int64_t* desc, int nstreams, int B, int H, int row0, int nrows, float* xbuf, int* flags, int epoch_base,
                           int* status, void* stream);

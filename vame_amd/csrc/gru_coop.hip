@@ -23,13 +23,34 @@
 #define COOP_STORE4(ptr, v) (*(ptr) = (v))
 #define COOP_LOAD16(dst, ptr) ((dst) = *reinterpret_cast<const f32x4*>(ptr))
 #define COOP_LOAD4(dst, ptr) ((dst) = *(ptr))
+// (value, tag) pairs: values first, then the tags with release order; the reader takes the tags first (acquire), then the values
+static inline void emu_store_ll(float* p, float a, float b, unsigned tag) {
+    p[0] = a; p[2] = b;
+    __atomic_store_n(reinterpret_cast<unsigned*>(p) + 1, tag, __ATOMIC_RELEASE);
+    __atomic_store_n(reinterpret_cast<unsigned*>(p) + 3, tag, __ATOMIC_RELEASE);
+}
+static inline f32x4 emu_load_ll(const float* p) {
+    const unsigned t1 = __atomic_load_n(reinterpret_cast<const unsigned*>(p) + 1, __ATOMIC_ACQUIRE);
+    const unsigned t3 = __atomic_load_n(reinterpret_cast<const unsigned*>(p) + 3, __ATOMIC_ACQUIRE);
+    f32x4 v; float f1, f3;
+    __builtin_memcpy(&f1, &t1, 4); __builtin_memcpy(&f3, &t3, 4);
+    v[0] = p[0]; v[1] = f1; v[2] = p[2]; v[3] = f3;
+    return v;
+}
+#define COOP_STORE16_LL(ptr, a, b, tag) emu_store_ll((ptr), (a), (b), (tag))
+#define COOP_LOAD16_LL(dst, ptr) ((dst) = emu_load_ll(ptr))
+#define COOP_WAIT_LL8(v)
+#define COOP_WAIT_LL16(v)
+static inline unsigned emu_tag(float x) { unsigned u; __builtin_memcpy(&u, &x, 4); return u; }
+#define COOP_TAG(x) emu_tag(x)
 #define COOP_WAIT_LOADS8(a, b, c, d, e, f, g, h)
 #define COOP_DRAIN()
 #define COOP_ONE_WAVE_PER_SIMD
 #define COOP_MFMA_SETTLE()
 #define COOP_FLAG_STORE(p, v) __atomic_store_n((p), (v), __ATOMIC_RELEASE)
 #define COOP_FLAG_LOAD(p) __atomic_load_n((p), __ATOMIC_ACQUIRE)
-#define COOP_BACKOFF() std::this_thread::sleep_for(std::chrono::microseconds(20))   /* one OS thread per workgroup: let the others run */
+/* one OS thread per workgroup, one fiber per thread: let the workgroup's other fibers run (they may be the producers), and the other workgroups */
+#define COOP_BACKOFF() do { emu::yield(); if (threadIdx.x == 0) std::this_thread::sleep_for(std::chrono::microseconds(20)); } while (0)
 #else
 // 16-byte write-through store / L1-bypassing load (sc1); asm because HIP has no 16-byte agent-scope access
 #define COOP_STORE16(ptr, v) asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(ptr), "v"(v) : "memory")
@@ -38,6 +59,21 @@
 #define COOP_LOAD4(dst, ptr) asm volatile("global_load_dword %0, %1, off sc1\n s_waitcnt vmcnt(0)" : "=v"(dst) : "v"(ptr) : "memory")
 #define COOP_WAIT_LOADS8(a, b, c, d, e, f, g, h) \
     asm volatile("s_waitcnt vmcnt(0)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f), "+v"(g), "+v"(h))
+// tagged hand-off: (value, tag, value, tag) in one 16-byte write-through store; the s_nop keeps a VALU write off the data registers
+// until the store has read them (the recogniser does not see into the asm)
+#define COOP_STORE16_LL(ptr, a, b, tag)                                                                          \
+    do {                                                                                                         \
+        const f32x4 ll_ = {(a), __uint_as_float(tag), (b), __uint_as_float(tag)};                                \
+        asm volatile("global_store_dwordx4 %0, %1, off sc1\n s_nop 1" : : "v"(ptr), "v"(ll_) : "memory");        \
+    } while (0)
+#define COOP_LOAD16_LL(dst, ptr) COOP_LOAD16(dst, ptr)
+#define COOP_WAIT_LL8(v) COOP_WAIT_LOADS8(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7])
+#define COOP_WAIT_LL16(v)                                                                                        \
+    do {                                                                                                         \
+        COOP_WAIT_LOADS8(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]);                                        \
+        asm volatile("" : "+v"(v[8]), "+v"(v[9]), "+v"(v[10]), "+v"(v[11]), "+v"(v[12]), "+v"(v[13]), "+v"(v[14]), "+v"(v[15])); \
+    } while (0)
+#define COOP_TAG(x) __float_as_uint(x)
 #define COOP_DRAIN() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
 // LDS allows one workgroup per CU = one wave per SIMD: the register allocator may use the whole file instead of spilling at 128
 #define COOP_ONE_WAVE_PER_SIMD __attribute__((amdgpu_waves_per_eu(1, 2)))
@@ -75,6 +111,7 @@ constexpr int COOP_DEFAULT_POLLS = 1 << 30;
 constexpr int COOP_DEFAULT_POLLS = 1 << 18;
 #endif
 static int g_coop_polls = COOP_DEFAULT_POLLS;
+constexpr int COOP_LL_OFF = 4096;        // (the flag words of a launch: <= 256 workgroups)
 extern "C" int vame_gru_coop_set_poll_limit(int polls) {
     const int old = g_coop_polls;
     g_coop_polls = polls != 0 ? polls : COOP_DEFAULT_POLLS;      // < 0: fault injection -- every launch reports one timeout
@@ -123,7 +160,9 @@ __global__ __launch_bounds__(256) COOP_ONE_WAVE_PER_SIMD void gru_coop_fwd_kerne
     const bool inject = max_polls < 0;
     if (inject) max_polls = COOP_DEFAULT_POLLS;
     const int sidx = g % P.nstreams, tile = g / P.nstreams + P.tile_off;
-    const GruFwdStream& S = P.s[sidx];
+    // a COPY of the stream's descriptor: behind a reference into the kernel arguments every asm statement with a memory clobber makes
+    // hipcc re-read the fields it needs next (s_load + wait, ~1000 cycles per step in the probe's publish phase)
+    const GruFwdStream S = P.s[sidx];
     const int B = P.B, T = (int)S.T;
     const int row0 = tile * 32 + half * R, col0 = 32 * m;
     const int nvalid = B - row0;
@@ -132,7 +171,8 @@ __global__ __launch_bounds__(256) COOP_ONE_WAVE_PER_SIMD void gru_coop_fwd_kerne
     const int ch = w & 1, rh = R == 32 ? (w >> 1) : 0, kh = R == 32 ? 0 : (w >> 1);
     const int lrow = rh * 16 + 4 * kg, lcol = ch * 16 + c16;               // this lane: rows lrow .. lrow + 3, column lcol of the slice
     const bool owner = R == 32 || kh == 0;                                 // lanes that finish the sums and do the gate math
-    int* gflags = flags + ((int64_t)g * NH + half) * NM;
+    const int gidx = g * NH + half;
+    float* ll = reinterpret_cast<float*>(flags + COOP_LL_OFF);             // tagged hand-off packets, behind the flag words
     float4* stash = S.stash ? reinterpret_cast<float4*>(S.stash) : nullptr;
     const int rg = (half * R + lrow) >> 2;                                 // 4-row group inside the 32-row stash tile: CR layout (hh, q) = (rg & 1, rg >> 1)
     const int slane = (rg & 1) * 32 + lcol, sq = rg >> 1;
@@ -273,8 +313,9 @@ __global__ __launch_bounds__(256) COOP_ONE_WAVE_PER_SIMD void gru_coop_fwd_kerne
             }
         }
         COOP_PHASE(1);
-        float ca[4], cb[4], us[4], rs[4], an[4];
+        float ca[4], cb[4], us[4], rs[4], an[4], hnew[4] = {0.f, 0.f, 0.f, 0.f};
         if (owner) {
+#pragma clang fp contract(off)      // the two instantiations (R = 32 / 16) must round alike: no fma formed here in one and not the other
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const float rr = fast_sigmoid(lo[0][i] + hi[0][i]), uu = fast_sigmoid(lo[1][i] + hi[1][i]);
@@ -287,8 +328,7 @@ __global__ __launch_bounds__(256) COOP_ONE_WAVE_PER_SIMD void gru_coop_fwd_kerne
                 cb[i] = (hp - nn) * uu * omu;
                 us[i] = uu; rs[i] = rr;
                 hprev[i] = hv;
-                // ---- publish: this lane's four rows of h_t into the sequence tensor (write-through)
-                if (lrow + i < nvalid) COOP_STORE4(y_lane + (int64_t)i * S.y_row + (int64_t)t * S.y_t, hv);
+                hnew[i] = hv;
             }
             if (more) {
 #pragma unroll
@@ -298,14 +338,20 @@ __global__ __launch_bounds__(256) COOP_ONE_WAVE_PER_SIMD void gru_coop_fwd_kerne
             }
         }
         COOP_PHASE(2);
-        COOP_DRAIN();
-        COOP_PHASE(3);
-        __syncthreads();
-        COOP_PHASE(4);
-        // the stash leaves AFTER the slice of h_t has been published and the flag raised: behind the hand-off its stores overlap the
-        // poll and the tile read, and the next step's drain comes a whole step later
-        auto store_stash = [&]() {
-            if (owner && stash) {
+        const unsigned tag = (unsigned)base + (unsigned)step + 1u;
+        if (owner) {
+            // ---- hand-off: this lane's four values as two 16-byte stores of (value, tag) pairs -- each 8-byte pair validates itself, so the
+            // consumers poll the DATA: no drain, no flag, no second round trip (the LL idiom of the collective libraries).  Rows past
+            // the batch travel too (finite, unused).
+            if (step + 1 < T) {
+                float* xp = ll + ((int64_t)((gidx * 2 + (step & 1)) * NM + m) * R * 16 + (R == 32 ? w : ch) * 128 + lane) * 4;
+                COOP_STORE16_LL(xp, hnew[0], hnew[1], tag);
+                COOP_STORE16_LL(xp + 64 * 4, hnew[2], hnew[3], tag);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (lrow + i < nvalid) y_lane[(int64_t)i * S.y_row + (int64_t)t * S.y_t] = hnew[i];      // the output sequence itself: plain stores
+            if (stash) {
                 float4* sp = stash + ((((int64_t)tile * T + t) * NM + m) * 20 + sq) * 64 + slane;
                 sp[0 * 4 * 64] = make_float4(ca[0], ca[1], ca[2], ca[3]);
                 sp[1 * 4 * 64] = make_float4(cb[0], cb[1], cb[2], cb[3]);
@@ -313,37 +359,44 @@ __global__ __launch_bounds__(256) COOP_ONE_WAVE_PER_SIMD void gru_coop_fwd_kerne
                 sp[3 * 4 * 64] = make_float4(rs[0], rs[1], rs[2], rs[3]);
                 sp[4 * 4 * 64] = make_float4(an[0], an[1], an[2], an[3]);
             }
-        };
-        if (step + 1 == T) { store_stash(); break; }
-        if (tid == 0) COOP_FLAG_STORE(&gflags[m], (int)((unsigned)base + (unsigned)step + 1u));
-        store_stash();
-        // ---- wait for all members' slices of h_t, then rebuild the full R x H tile in LDS
-        if (tid < NM) {
-            if (inject && step == 0 && tid == 0) atomicAdd(status, 1);          // fault injection (diagnostics): report, then wait normally
-            int polls = COOP_FLAG_LOAD(status) != 0 && !inject ? max_polls : 0;
-            while ((int)((unsigned)COOP_FLAG_LOAD(&gflags[tid]) - ((unsigned)base + (unsigned)step + 1u)) < 0) {   // wrap-safe
-                COOP_BACKOFF();
-                if (++polls > max_polls) { atomicAdd(status, 1); break; }
-            }
         }
-        __syncthreads();
-        COOP_PHASE(5);
+        COOP_PHASE(3);
+        if (step + 1 == T) break;
+        if (R == 32) __syncthreads();              // every wave is done reading h_{t-1} (at R = 16 the K-half exchange barrier says so)
+        COOP_PHASE(4);
+        // ---- every thread polls its share of the S members' packets until all tags are this step's, then rebuilds the R x H tile in LDS
         {
-            constexpr int PER = R * (H / 4) / 256;                        // float4 per thread (8 at R = 32, H = 256)
-            static_assert(PER == 8 || PER == 4 || PER == 2, "tile copy is written for H = 128 / 256");
-            f32x4 v[8];
-            const float* yt = S.y + (int64_t)t * S.y_t;
+            constexpr int NK = R * NM / 16;                                // 16-byte packets per thread: R * 16 per member, 256 threads
+            static_assert(NK == 8 || NK == 16 || NK == 4, "packet poll is written for H = 128 / 256");
+            f32x4 v[16];
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const int idx = tid + (i % PER) * 256, r = idx / (H / 4), c4 = idx % (H / 4);
-                const int rr = r < nvalid ? r : 0;                        // rows past the batch re-read a valid row (unused)
-                if (i < PER) COOP_LOAD16(v[i], yt + (int64_t)(row0 + rr) * S.y_row + 4 * c4); else v[i] = v[0];
+            for (int k = NK; k < 16; ++k) v[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+            const float* xr = ll + (int64_t)(gidx * 2 + (step & 1)) * NM * R * 64 + (int64_t)tid * 4;
+            unsigned need = (1u << NK) - 1u;
+            int polls = 0;
+            if (inject && step == 0 && tid == 0) atomicAdd(status, 1);      // fault injection (diagnostics): report, then wait normally
+            while (true) {
+#pragma unroll
+                for (int k = 0; k < NK; ++k)
+                    if (need >> k & 1u) COOP_LOAD16_LL(v[k], xr + (int64_t)k * 1024);
+                if (NK > 8) COOP_WAIT_LL16(v); else COOP_WAIT_LL8(v);
+#pragma unroll
+                for (int k = 0; k < NK; ++k)
+                    if ((need >> k & 1u) && COOP_TAG(v[k][1]) == tag && COOP_TAG(v[k][3]) == tag) need &= ~(1u << k);
+                if (need == 0u) break;
+                COOP_BACKOFF();
+                ++polls;
+                // a launch that has already reported a timeout gives up at once (results undefined, the launch ends)
+                if (polls > max_polls || (polls == 64 && !inject && COOP_FLAG_LOAD(status) != 0)) { atomicAdd(status, 1); break; }
             }
-            COOP_WAIT_LOADS8(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]);
+            COOP_PHASE(5);
+            // packet (64-lane block bi = w + 4k of the group's packet stream, lane): member bi / (R/4), block bi % (R/4) = (tile, pair)
 #pragma unroll
-            for (int i = 0; i < PER; ++i) {
-                const int idx = tid + i * 256, r = idx / (H / 4), c4 = idx % (H / 4);
-                *reinterpret_cast<f32x4*>(&hs[r * LDH + 4 * c4]) = v[i];
+            for (int k = 0; k < NK; ++k) {
+                const int bi = w + 4 * k, mm = bi / (R / 4), blk = bi % (R / 4), pj = blk & 1, tw = blk >> 1;
+                const int prow_ = (R == 32 ? (tw >> 1) * 16 : 0) + 4 * kg + 2 * pj, pcol = mm * 32 + (tw & 1) * 16 + c16;
+                hs[prow_ * LDH + pcol] = v[k][0];
+                hs[(prow_ + 1) * LDH + pcol] = v[k][2];
             }
         }
         COOP_PHASE(6);
@@ -369,8 +422,11 @@ __global__ __launch_bounds__(256) COOP_ONE_WAVE_PER_SIMD void gru_coop_fwd_kerne
 template <int H, int R>
 static size_t coop_fwd_lds() { return (size_t)(96 * (H + 4) + R * (H + 4) + (R == 16 ? 2 * 12 * 64 : 0)) * 4; }
 
-// one flag word per (stream, 16-row half tile, member)
-extern "C" int64_t vame_gru_coop_flag_ints(int nstreams, int B, int H) { return (int64_t)nstreams * cdiv64(B, 32) * 2 * (H / 32) + 16; }
+// one flag word per (stream, 16-row half tile, member) in the first COOP_LL_OFF words (BPTT), then the forward kernel's tagged hand-off
+// packets: 2 step parities x 32 rows x H (value, tag) pairs per (stream, tile)
+extern "C" int64_t vame_gru_coop_flag_ints(int nstreams, int B, int H) {
+    return COOP_LL_OFF + (int64_t)nstreams * cdiv64(B, 32) * 2 * 32 * H * 2;
+}
 
 // 1 if (nstreams, B, H) can run cooperatively: every workgroup of the grid must be resident at once (one per CU)
 // compute units of the current device: every workgroup of a cooperative grid needs its own (LDS allows one per CU)
@@ -515,7 +571,7 @@ __global__ __launch_bounds__(256) COOP_ONE_WAVE_PER_SIMD void gru_coop_bwd_kerne
     const bool inject = max_polls < 0;
     if (inject) max_polls = COOP_DEFAULT_POLLS;
     const int sidx = g % P.nstreams, tile = g / P.nstreams + P.tile_off;
-    const GruBwdStream& S = P.s[sidx];
+    const GruBwdStream S = P.s[sidx];              // a copy, not a reference into the kernel arguments (see the forward kernel)
     const int B = P.B, T = (int)S.T;
     const int row0 = tile * 32 + half * R, col0 = 32 * m;
     const int nvalid = B - row0;

@@ -234,6 +234,13 @@ class CoopState:
         self._ev = [None, None]
         self._k = 0
 
+    def ensure_flags(self, ints):
+        """Flag words + the forward kernel's tagged hand-off packets (vame_gru_coop_flag_ints).  A larger buffer starts out as if a launch
+        a few epochs back had left it behind: older than anything the next launch waits for, equal to no tag it will look for."""
+        if self.flags.numel() < ints:
+            stale = (self.epoch - 8) & 0xffffffff
+            self.flags = torch.full((int(ints),), stale - (1 << 32) if stale >= (1 << 31) else stale, dtype=torch.int32, device=self.flags.device)
+
     def snapshot(self):
         """Enqueue a copy of the status word to the host (end of a step); never blocks."""
         if not self.dirty:
@@ -322,8 +329,7 @@ def gru_coop_fwd(streams, B, H, state: CoopState, rows=(0, 0), kernel=KERNEL_AUT
     groups always (the same bits either way)."""
     d = _desc_tensor(streams, GF["N"])
     d[0, GF["OPT"]] = gru_opt(kernel, -1, -1)
-    need = _lib.lib().vame_gru_coop_flag_ints(len(streams), rows[1] or B, H)
-    assert state.flags.numel() >= need, "cooperative flag buffer too small"
+    state.ensure_flags(_lib.lib().vame_gru_coop_flag_ints(len(streams), rows[1] or B, H))
     T = max(int(s[GF["T"]]) for s in streams)
     state.dirty = True
     rc = _lib.lib().vame_gru_coop_fwd_f32(d.data_ptr(), len(streams), B, H, rows[0], rows[1], _ptr(state.flags), state.next_base(T),
