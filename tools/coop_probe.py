@@ -1,6 +1,6 @@
 """Per-wave phase cycles of the cooperative GRU kernels (probe build: make probe; loads tools/libvame_hip_probe.so).
-forward phases per step: 0 acc init + MFMA loop, 1 K-half exchange (16-row groups), 2 gate math + publish issue, 3 drain, 4 barrier,
-5 flag + stash + poll + barrier, 6 tile read -> LDS, 7 barrier.   BPTT: 0 element-wise + A tile -> LDS, 1 barrier, 2 dG stores + stash
+forward phases per step: 0 acc init + MFMA loop, 1 K-half exchange (16-row groups), 2 gate math, 3 publish (packets, sequence, stash) issue,
+4 barrier (32-row groups), 5 packet poll, 6 LDS rebuild, 7 barrier.   BPTT: 0 element-wise + A tile -> LDS, 1 barrier, 2 dG stores + stash
 prefetch issue, 3 MFMA loop, 4 publish + drain, 5 barrier, 6 flag + poll + barrier, 7 reduce-scatter loads + sums."""
 import ctypes, os, sys
 R = os.environ.get("GRAFT_REPO_ROOT", "/root/repo")
@@ -16,7 +16,7 @@ L.vame_probe_set_coop(probe.data_ptr())
 state = ops.CoopState(torch.device("cuda"))
 orig, orig_b = ops.gru_seq_fwd, ops.gru_seq_bwd
 H, T = 256, 30
-FN = ["mfma", "k-xchg", "gates+pub", "drain", "barrier", "flag/poll", "tile read", "barrier"]
+FN = ["mfma", "k-xchg", "gates", "publish", "barrier", "packet poll", "lds rebuild", "barrier"]
 BN = ["elementwise", "barrier", "dG+prefetch", "mfma", "publish+drain", "barrier", "flag/poll", "reduce"]
 for (B, ns) in ((256, 2), (256, 4)):
     for name, kern in (("auto", ops.KERNEL_AUTO), ("32-row groups", ops.KERNEL_LOCKSTEP)):

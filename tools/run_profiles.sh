@@ -47,4 +47,6 @@ FWD_H=512,384 FWD_DELAYS=0 python -u tools/fwd_table.py 8192 60 2>&1 | grep -v a
 python -u tools/bwd_table.py 2>&1 | grep -v amdgpu > $O/bwd_table.txt
 python tools/step_ab.py 256 join=nuc_join_before_coop:1 nojoin=nuc_join_before_coop:0 inline=nuc_side:0 2>&1 | grep -v amdgpu > $O/b256_overlap.txt
 python tools/clock_check.py 2>&1 | grep -v amdgpu > $O/clock_check.txt
+python tools/coop_bench.py 2>&1 | grep -v amdgpu > $O/coop_bench.txt
+python tools/coop_probe.py 2>&1 | grep -v amdgpu > $O/coop_probe.txt
 ls -la $O
