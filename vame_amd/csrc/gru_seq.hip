@@ -260,8 +260,10 @@ __global__ __launch_bounds__(H / 32 * 64) void gru_seq_fwd_kernel(GruFwdParams P
     if (y_tile && S.pad) store_h(hs[0], S.reverse ? T : -1);
     const float bhn = S.bhn[col0 + li];
     const float bgr = XIN ? S.bgi[col0 + li] : 0.f, bgu = XIN ? S.bgi[H + col0 + li] : 0.f, bgn = XIN ? S.bgi[2 * H + col0 + li] : 0.f;
-    const float4* __restrict__ wpx = XIN ? reinterpret_cast<const float4*>(S.wpx) + (int64_t)w * 4 * 3 * 64 + lane : nullptr;
-    const float4* __restrict__ wp = reinterpret_cast<const float4*>(S.wp) + (int64_t)w * KC * 3 * 64 + lane;
+    // uniform ring bases (SGPR pairs) + one per-lane byte offset (RING_LOAD_U: no vector-ALU address arithmetic in the K loop)
+    const float4* __restrict__ wpx = XIN ? reinterpret_cast<const float4*>(S.wpx) + (int64_t)w * 4 * 3 * 64 : nullptr;
+    const float4* __restrict__ wp = reinterpret_cast<const float4*>(S.wp) + (int64_t)w * KC * 3 * 64;
+    const unsigned lane16 = (unsigned)lane * 16u;
     float4* stash = S.stash ? reinterpret_cast<float4*>(S.stash) : nullptr;
     int cur = 0;
     // gi of the first step; later steps are prefetched during the previous step's MFMA loop
@@ -299,7 +301,7 @@ __global__ __launch_bounds__(H / 32 * 64) void gru_seq_fwd_kernel(GruFwdParams P
     {
         const float4* w0 = XIN ? wpx : wp;
 #pragma unroll
-        for (int c = 0; c < PD; ++c) { RING_LOAD(wq[c][0], w0, (c * 3 + 0) * 64); RING_LOAD(wq[c][1], w0, (c * 3 + 1) * 64); RING_LOAD(wq[c][2], w0, (c * 3 + 2) * 64); }
+        for (int c = 0; c < PD; ++c) { RING_LOAD_U(wq[c][0], w0 + (c) * 3 * 64, lane16, 0); RING_LOAD_U(wq[c][1], w0 + (c) * 3 * 64, lane16, 1024); RING_LOAD_U(wq[c][2], w0 + (c) * 3 * 64, lane16, 2048); }
     }
     if (XIN) __syncthreads();
     GRU_PHASE_DECL();
@@ -326,7 +328,7 @@ __global__ __launch_bounds__(H / 32 * 64) void gru_seq_fwd_kernel(GruFwdParams P
                 ar = MFMA_32x32x2(a.w, b0[3], ar); au = MFMA_32x32x2(a.w, b1[3], au); ani = MFMA_32x32x2(a.w, b2[3], ani);
                 RING_FENCE();                  // refill only after the slot's last use: see the note at the main loop
                 const float4* nsrc = skip_first ? wpx : wp;      // no recurrent loop in a zero-state first step: keep the input chunks
-                RING_LOAD(wq[j][0], nsrc, (j * 3 + 0) * 64); RING_LOAD(wq[j][1], nsrc, (j * 3 + 1) * 64); RING_LOAD(wq[j][2], nsrc, (j * 3 + 2) * 64);
+                RING_LOAD_U(wq[j][0], nsrc + (j) * 3 * 64, lane16, 0); RING_LOAD_U(wq[j][1], nsrc + (j) * 3 * 64, lane16, 1024); RING_LOAD_U(wq[j][2], nsrc + (j) * 3 * 64, lane16, 2048);
             }
         } else {
             ar = gr; au = gu; ani = gn;
@@ -362,7 +364,7 @@ __global__ __launch_bounds__(H / 32 * 64) void gru_seq_fwd_kernel(GruFwdParams P
                 const bool wrap = c0 + PD == KC;
                 const float4* src = (XIN && wrap) ? wpx : wp;
                 const int cn = (ABL & 16) ? 0 : (wrap ? j : c + PD);
-                RING_LOAD(wq[j][0], src, (cn * 3 + 0) * 64); RING_LOAD(wq[j][1], src, (cn * 3 + 1) * 64); RING_LOAD(wq[j][2], src, (cn * 3 + 2) * 64);
+                RING_LOAD_U(wq[j][0], src + (cn) * 3 * 64, lane16, 0); RING_LOAD_U(wq[j][1], src + (cn) * 3 * 64, lane16, 1024); RING_LOAD_U(wq[j][2], src + (cn) * 3 * 64, lane16, 2048);
             }
         }
         GRU_PHASE_DYN(8 + c0 / PD);
@@ -521,8 +523,10 @@ __global__ __launch_bounds__(H / 32 * 64) void gru_skew_fwd_kernel(GruFwdParams 
     if (y_tile && S.pad) store_h(hs[0], S.reverse ? T : -1);
     const float bhn = S.bhn[col0 + li];
     const float bgr = XIN ? S.bgi[col0 + li] : 0.f, bgu = XIN ? S.bgi[H + col0 + li] : 0.f, bgn = XIN ? S.bgi[2 * H + col0 + li] : 0.f;
-    const float4* __restrict__ wpx = XIN ? reinterpret_cast<const float4*>(S.wpx) + (int64_t)w * 4 * 3 * 64 + lane : nullptr;
-    const float4* __restrict__ wp = reinterpret_cast<const float4*>(S.wp) + (int64_t)w * KC * 3 * 64 + lane;
+    // uniform ring bases (SGPR pairs) + one per-lane byte offset (RING_LOAD_U: no vector-ALU address arithmetic in the K loop)
+    const float4* __restrict__ wpx = XIN ? reinterpret_cast<const float4*>(S.wpx) + (int64_t)w * 4 * 3 * 64 : nullptr;
+    const float4* __restrict__ wp = reinterpret_cast<const float4*>(S.wp) + (int64_t)w * KC * 3 * 64;
+    const unsigned lane16 = (unsigned)lane * 16u;
     float4* stash = S.stash ? reinterpret_cast<float4*>(S.stash) : nullptr;
     f32x16 gr, gu, gn;                       // gi of the wave's next step (per-step gi streams: fetched behind part 1's K loop)
     auto load_gi = [&](int t) {
@@ -547,7 +551,7 @@ __global__ __launch_bounds__(H / 32 * 64) void gru_skew_fwd_kernel(GruFwdParams 
     {
         const float4* w0 = XIN ? wpx : wp;
 #pragma unroll
-        for (int c = 0; c < PD; ++c) { RING_LOAD(wq[c][0], w0, (c * 3 + 0) * 64); RING_LOAD(wq[c][1], w0, (c * 3 + 1) * 64); RING_LOAD(wq[c][2], w0, (c * 3 + 2) * 64); }
+        for (int c = 0; c < PD; ++c) { RING_LOAD_U(wq[c][0], w0 + (c) * 3 * 64, lane16, 0); RING_LOAD_U(wq[c][1], w0 + (c) * 3 * 64, lane16, 1024); RING_LOAD_U(wq[c][2], w0 + (c) * 3 * 64, lane16, 2048); }
     }
     // a zero initial state contributes nothing to step 0: its K loops are skipped (acc + 0 * w = acc), the ring keeps its first chunks
     const bool skip0 = S.h0 == nullptr;
@@ -586,7 +590,7 @@ __global__ __launch_bounds__(H / 32 * 64) void gru_skew_fwd_kernel(GruFwdParams 
                 ar = MFMA_32x32x2(a.w, b0[3], ar); au = MFMA_32x32x2(a.w, b1[3], au); ani = MFMA_32x32x2(a.w, b2[3], ani);
                 RING_FENCE();
                 const float4* nsrc = skip ? wpx : wp;          // no recurrent loop in a zero-state first step: keep the input chunks
-                RING_LOAD(wq[j][0], nsrc, (j * 3 + 0) * 64); RING_LOAD(wq[j][1], nsrc, (j * 3 + 1) * 64); RING_LOAD(wq[j][2], nsrc, (j * 3 + 2) * 64);
+                RING_LOAD_U(wq[j][0], nsrc + (j) * 3 * 64, lane16, 0); RING_LOAD_U(wq[j][1], nsrc + (j) * 3 * 64, lane16, 1024); RING_LOAD_U(wq[j][2], nsrc + (j) * 3 * 64, lane16, 2048);
             }
         } else {
             ar = gr; au = gu; ani = gn;
@@ -611,7 +615,7 @@ __global__ __launch_bounds__(H / 32 * 64) void gru_skew_fwd_kernel(GruFwdParams 
                     const bool wrap = c0 + PD == KC;
                     const float4* src = (XIN && wrap) ? wpx : wp;
                     const int cn = wrap ? j : c + PD;
-                    RING_LOAD(wq[j][0], src, (cn * 3 + 0) * 64); RING_LOAD(wq[j][1], src, (cn * 3 + 1) * 64); RING_LOAD(wq[j][2], src, (cn * 3 + 2) * 64);
+                    RING_LOAD_U(wq[j][0], src + (cn) * 3 * 64, lane16, 0); RING_LOAD_U(wq[j][1], src + (cn) * 3 * 64, lane16, 1024); RING_LOAD_U(wq[j][2], src + (cn) * 3 * 64, lane16, 2048);
                 }
             }
         };
@@ -712,7 +716,8 @@ __global__ __launch_bounds__(H / 32 * 64) void gru_seq_bwd_kernel(GruBwdParams P
         dh[r] = (S.dhn && grow < B) ? S.dhn[(int64_t)grow * S.dhn_row + col0 + li] : 0.0f;
     }
     float dbs0 = 0.f, dbs1 = 0.f, dbs2 = 0.f, dbs3 = 0.f;
-    const float4* __restrict__ wpt = reinterpret_cast<const float4*>(S.wpt) + (int64_t)w * KC * 64 + lane;
+    const float4* __restrict__ wpt = reinterpret_cast<const float4*>(S.wpt) + (int64_t)w * KC * 64;      // uniform ring base (RING_LOAD_U)
+    const unsigned lane16 = (unsigned)lane * 16u;
     const float4* stash = reinterpret_cast<const float4*>(S.stash);
     const float* grow_a = &gs[li * LDG + 4 * hh];
     // LDS is > 64 KiB: two lane bases keep every ds_write inside the 16-bit immediate offset range
@@ -746,7 +751,7 @@ __global__ __launch_bounds__(H / 32 * 64) void gru_seq_bwd_kernel(GruBwdParams P
     constexpr int PD = 3;                       // W_hh fragment prefetch distance in chunk pairs ((KC/2) % PD == 0 for H = 32..256; 4 measured slower)
     f32x4 wq[PD][2];
 #pragma unroll
-    for (int c = 0; c < PD; ++c) { RING_LOAD(wq[c][0], wpt, (2 * c) * 64); RING_LOAD(wq[c][1], wpt, (2 * c + 1) * 64); }
+    for (int c = 0; c < PD; ++c) { RING_LOAD_U(wq[c][0], wpt + (2 * c) * 64, lane16, 0); RING_LOAD_U(wq[c][1], wpt + (2 * c) * 64, lane16, 1024); }
     // dG[b][t][da_r | da_z | dgi_n | dgh_n] leaves through LDS: 16 coalesced 16-byte stores per thread
     auto dg_copy_out = [&](int t) {
         float* dgt = dg_copy + (int64_t)t * 4 * H;
@@ -834,7 +839,7 @@ __global__ __launch_bounds__(H / 32 * 64) void gru_seq_bwd_kernel(GruBwdParams P
             RING_FENCE();
             {   // refill after the slot's last use (see the forward kernel); wraps into the next step
                 const int cn = (ABL & 16) ? 0 : (c0 + j + PD == KC / 2 + j ? 2 * j : c + 2 * PD);
-                RING_LOAD(wq[j][0], wpt, cn * 64); RING_LOAD(wq[j][1], wpt, (cn + 1) * 64);
+                RING_LOAD_U(wq[j][0], wpt + cn * 64, lane16, 0); RING_LOAD_U(wq[j][1], wpt + cn * 64, lane16, 1024);
             }
             if (j == PD - 1) GRU_PHASE_DYN(8 + c0 / PD);
         }
@@ -909,15 +914,17 @@ __global__ __launch_bounds__(H / 32 * 64) void gru_ws_bwd_kernel(GruBwdParams P)
     if (w < MW) {
         // ================================================================ MFMA waves: columns [64 w, 64 w + 64)
         const int cbA = 2 * w, cbB = 2 * w + 1;
-        const float4* __restrict__ wpA = reinterpret_cast<const float4*>(S.wpt) + (int64_t)cbA * KC * 64 + lane;
-        const float4* __restrict__ wpB = wpA + (int64_t)KC * 64;
+        // uniform ring bases (SGPR pairs) + one per-lane byte offset: no vector-ALU address arithmetic in the contraction
+        const float4* __restrict__ uA = reinterpret_cast<const float4*>(S.wpt) + (int64_t)cbA * KC * 64;
+        const float4* __restrict__ uB = uA + (int64_t)KC * 64;
+        const unsigned lane16 = (unsigned)lane * 16u;
         const float* grow_a = &gs[li * LDG + 4 * hh];
         constexpr int PD = 3;                               // ring depth in chunk pairs ((KC / 2) % PD == 0 for every H % 64 == 0)
         f32x4 wq[PD][4];
 #pragma unroll
         for (int c = 0; c < PD; ++c) {
-            RING_LOAD(wq[c][0], wpA, (2 * c) * 64); RING_LOAD(wq[c][1], wpA, (2 * c + 1) * 64);
-            RING_LOAD(wq[c][2], wpB, (2 * c) * 64); RING_LOAD(wq[c][3], wpB, (2 * c + 1) * 64);
+            RING_LOAD_U(wq[c][0], uA + (2 * c) * 64, lane16, 0); RING_LOAD_U(wq[c][1], uA + (2 * c) * 64, lane16, 1024);
+            RING_LOAD_U(wq[c][2], uB + (2 * c) * 64, lane16, 0); RING_LOAD_U(wq[c][3], uB + (2 * c) * 64, lane16, 1024);
         }
         f32x16 a0, b0;
 #pragma unroll
@@ -960,8 +967,8 @@ __global__ __launch_bounds__(H / 32 * 64) void gru_ws_bwd_kernel(GruBwdParams P)
                 RING_FENCE();
                 {   // refill behind the slot's last use; wraps into the next step's first chunks
                     const int cn = (c0 + j + PD == KC / 2 + j) ? 2 * j : c + 2 * PD;
-                    RING_LOAD(wq[j][0], wpA, cn * 64); RING_LOAD(wq[j][1], wpA, (cn + 1) * 64);
-                    RING_LOAD(wq[j][2], wpB, cn * 64); RING_LOAD(wq[j][3], wpB, (cn + 1) * 64);
+                    RING_LOAD_U(wq[j][0], uA + cn * 64, lane16, 0); RING_LOAD_U(wq[j][1], uA + cn * 64, lane16, 1024);
+                    RING_LOAD_U(wq[j][2], uB + cn * 64, lane16, 0); RING_LOAD_U(wq[j][3], uB + cn * 64, lane16, 1024);
                 }
                 fa0 = na0; fa1 = na1;
             }

@@ -18,6 +18,7 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 #define SCHED_FENCE()
 #define RING_FENCE()
 #define RING_LOAD(dst, ptr, idx) (dst) = *reinterpret_cast<const f32x4*>((ptr) + (idx))
+#define RING_LOAD_U(dst, ubase, voff, imm) (dst) = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(ubase) + (voff) + (imm))
 #define RING_WAIT2(n, a, b)
 #define RING_WAIT3(n, a, b, c)
 #define RING_WAIT4(n, a, b, c, d)
@@ -59,6 +60,9 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));      /* pairs for the p
 // conservative (vmcnt counts in order), never unsafe.  The asm wait takes the slot registers as in/out operands so that no
 // consumer can be scheduled above it.  (ptr: float4 pointer, idx: float4 index; offsets stay < 4 KiB of a per-lane base.)
 #define RING_LOAD(dst, ptr, idx) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"((ptr) + (idx)))
+// the same with a UNIFORM base in an SGPR pair + a per-lane byte offset + an immediate: the address arithmetic stays on the scalar ALU
+// (a 64-bit VGPR address costs a v_lshl_add_u64 per load -- vector-ALU time the f32 MFMAs need)
+#define RING_LOAD_U(dst, ubase, voff, imm) asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(dst) : "v"(voff), "s"(ubase), "n"(imm))
 #define RING_WAIT2(n, a, b) asm volatile("s_waitcnt vmcnt(%2)" : "+v"(a), "+v"(b) : "n"(n))
 #define RING_WAIT3(n, a, b, c) asm volatile("s_waitcnt vmcnt(%3)" : "+v"(a), "+v"(b), "+v"(c) : "n"(n))
 #define RING_WAIT4(n, a, b, c, d) asm volatile("s_waitcnt vmcnt(%4)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "n"(n))
