@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """Stress the cross-workgroup hand-offs of the cooperative GRU kernels: many launches on the SAME buffers with fresh data each
-time (a stale L1 / L2 line would show), a second stream streaming memory in the background (uneven load), every word checked
-against the batch-tile-persistent kernels.  usage: python tools/coop_stress.py [iterations]"""
+time (a stale L1 / L2 line or a stale hand-off packet would show), a second stream streaming memory in the background (uneven load), every
+word checked: against the batch-tile-persistent kernels to summation-order rounding, and BIT FOR BIT between the two forms of the
+cooperative launch (16-row groups with tagged packets on twice the workgroups vs 32-row groups), which exchange different packets in a
+different order.  usage: python tools/coop_stress.py [iterations]"""
 import os
 import sys
 
@@ -12,7 +14,7 @@ import torch
 
 from vame_amd import ops
 from vame_amd.ops import GB, GF
-from kernel_cases import _gru_weights, _pack
+from kernel_cases import _gru_weights, _pack, _valid_stash_mask
 
 iters = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 dev = torch.device("cuda")
@@ -28,12 +30,14 @@ for B in (256, 100, 512):
     packs = [_pack("cuda", w[1], w[2], w[3], H) for w in W]
     gi = [torch.empty(B, T, 3 * H, device=dev) for _ in range(2)]
     h0 = torch.empty(B, H, device=dev)
-    Y = [torch.zeros(B, T + 2, 2 * H, device=dev) for _ in range(2)]
-    hN = [torch.zeros(B, 2 * H, device=dev) for _ in range(2)]
-    stash = [[torch.zeros(ops.gru_stash_floats(B, T, H), device=dev) for _ in range(2)] for _ in range(2)]
+    Y = [torch.zeros(B, T + 2, 2 * H, device=dev) for _ in range(3)]
+    hN = [torch.zeros(B, 2 * H, device=dev) for _ in range(3)]
+    stash = [[torch.zeros(ops.gru_stash_floats(B, T, H), device=dev) for _ in range(2)] for _ in range(3)]
     dY, dhN = torch.empty(B, T, 2 * H, device=dev), torch.empty(B, 2 * H, device=dev)
     outs = [[(torch.zeros(B, T, 4 * H, device=dev), torch.zeros(B, H, device=dev), torch.zeros(nt, 4 * H, device=dev)) for _ in range(2)]
-            for _ in range(2)]
+            for _ in range(3)]
+
+    smask = torch.from_numpy(_valid_stash_mask(B, T, H).copy()).to(dev)        # stash entries of rows past the batch are don't-cares
 
     def rows_f(k):
         return [{GF["GI"]: ops.addr(gi[d]), GF["GI_ROW"]: T * 3 * H, GF["GI_T"]: 3 * H, GF["WP"]: ops.addr(packs[d][0]),
@@ -60,14 +64,19 @@ for B in (256, 100, 512):
                 junk_b.copy_(junk_a)
         ops.gru_seq_fwd(rows_f(0), B, H)
         ops.gru_coop_fwd(rows_f(1), B, H, state)
+        ops.gru_coop_fwd(rows_f(2), B, H, state, kernel=ops.KERNEL_LOCKSTEP)
         ops.gru_seq_bwd(rows_b(0), B, H)
         ops.gru_coop_bwd(rows_b(1), B, H, state)
+        ops.gru_coop_bwd(rows_b(2), B, H, state, kernel=ops.KERNEL_LOCKSTEP)
         torch.cuda.synchronize()
-        ok = torch.equal(Y[0], Y[1]) and torch.equal(hN[0], hN[1])
+        ok = bool((Y[0] - Y[1]).abs().max() <= 2e-6) and bool((hN[0] - hN[1]).abs().max() <= 2e-6)
+        ok = ok and torch.equal(Y[1], Y[2]) and torch.equal(hN[1], hN[2])                   # the two cooperative forms: the same bits
         for d in range(2):
-            for a, b in zip(outs[0][d][:2], outs[1][d][:2]):
+            ok = ok and torch.equal(stash[1][d][smask], stash[2][d][smask])
+            for a, b, c in zip(outs[0][d][:2], outs[1][d][:2], outs[2][d][:2]):
                 tol = 2e-5 * max(1.0, float(a.abs().max()))
-                ok = ok and bool((a - b).abs().max() <= tol)
+                ok = ok and bool((a - b).abs().max() <= tol) and torch.equal(b, c)
+            ok = ok and torch.equal(outs[1][d][2], outs[2][d][2])                              # bias partials incl. the 16-row hand-over
         if not ok:
             bad += 1
             print(f"MISMATCH B={B} iteration {it}", flush=True)
