@@ -181,7 +181,7 @@ struct TileIO {
     // LDS image.  k-major [BK][BX+4] (default; fragment = ds_read_b32 of row k; a row-major (!KM) operand is transposed by
     // four ds_write_b32 per global float4), or for !KM operands with XM: x-major [BX][BK+4] -- the global float4 is stored
     // as-is with one ds_write_b128 and a lane reads float4 [x][8c + 4*(lane>>5)] = its operand for 4 MFMA steps (row
-    // stride 36 floats = 9 x 16 B: conflict-free b128).  Measured: XM wins for the NN form's A operand only.
+    // stride 36 floats = 9 x 16 B: conflict-free b128).  Measured: XM wins for the A operand (NN; NT since round 4), not for B.
     static constexpr bool XMAJ = !KM && XM;
     static constexpr int LD = XMAJ ? BK + 4 : BX + 4;
     static constexpr int LDS_FLOATS = XMAJ ? BX * (BK + 4) : BK * (BX + 4);
@@ -304,7 +304,10 @@ template <int BM, int BN, int WM, int WN, bool AKM, bool BKM, int VAR, int EPI>
 __global__ __launch_bounds__(WM * WN * 64, ((BM / WM) * (BN / WN) > 64 * 64 || (VAR & 8)) ? 2 : 3) void gemm_kernel(GemmParams p) {
     constexpr int BK = 32, NT = WM * WN * 64, TM = BM / WM / 32, TN = BN / WN / 32;
     constexpr bool PIPE = (VAR & 8) != 0;
-    typedef TileIO<BK, BM, NT, AKM, BKM> TA;      // x-major image only for the A operand of the NN form
+    // x-major image (global float4 stored as-is, b128 fragments) for a row-major A operand -- NN and, since round 4, NT: with the fetch's
+    // address arithmetic gone the transposing stores' own (53 v_add_u32 + 16 ds_write2_b32 per k-tile) showed: NT 109.3 -> 113.2 TF;
+    // the B operand keeps the transposing store (x-major B: 112.2, both: 111.4; tools/gemm_lib_ab.py)
+    typedef TileIO<BK, BM, NT, AKM, true> TA;
     typedef TileIO<BK, BN, NT, BKM, false> TB;
     __shared__ __attribute__((aligned(16))) float As[(PIPE ? 2 : 1) * TA::LDS_FLOATS];
     __shared__ __attribute__((aligned(16))) float Bs[(PIPE ? 2 : 1) * TB::LDS_FLOATS];
