@@ -172,6 +172,7 @@ class VAEEngine:
         # the future decoder's two dW_hh contractions beside the small-kernel chain that follows the decoders' BPTT launch (_early_wgrads)
         self.bwd_overlap = os.environ.get("VAME_AMD_BWD_OVERLAP", "1") != "0"
         self.skinny_side = os.environ.get("VAME_AMD_SKINNY_SIDE", "1") != "0"
+        self.wgrad_min_rounds = 0          # grouped weight gradients: whole rounds of 3 workgroups per CU, at least this many (0 = by K, see _group_wgrads)
         self._early_stream, self._early_pending = None, False
         self._nuc_stream = None
         self._nuc_pending = None          # arguments of a deferred cluster_terms()
@@ -287,8 +288,12 @@ class VAEEngine:
                 # whole rounds of 3 workgroups per CU: the smallest multiple of 8 with >= 2 rounds (dynamic balancing between
                 # rounds), capped so that a workgroup keeps >= 8 k-tiles
                 cands = [k for k in range(8, 129, 8) if k * 8 * 32 <= K]
-                full = [k for k in cands if tiles * k >= 2 * 768 and (tiles * k) % 768 == 0]
-                sk = full[0] if full else next((k for k in cands if tiles * k >= 2 * 768), cands[-1] if cands else 8)
+                # one whole round where the k-slabs stay short (K = batch x time < 2^18: +0.5 % at batch 4096, +1.7 % at 256 against two rounds --
+                # half the partial sums), two where a slab is long enough for the workgroups to drift apart (K = 491,520: one round -0.4 %);
+                # profiles/r04_wgrad_rounds.txt
+                rounds = self.wgrad_min_rounds or (1 if K < (1 << 18) else 2)
+                full = [k for k in cands if tiles * k >= rounds * 768 and (tiles * k) % 768 == 0]
+                sk = full[0] if full else next((k for k in cands if tiles * k >= rounds * 768), cands[-1] if cands else 8)
                 ws = self.ws.get(ws_name, len(part) * sk * M * N, self.dev)
                 ops.gemm_group(M, N, K, [m[3] for m in part], 1, [m[4] for m in part], 1, self.g, [self.table.off(m[5]) for m in part],
                                N, sk, ws, a_gap_at=key[9], a_gap=key[10])
