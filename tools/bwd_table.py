@@ -27,7 +27,10 @@ for H in SIZES:
     base = 2 * H * H // 65536, 8 * H * H // 65536
     variants = [("lock-step", ops.KERNEL_LOCKSTEP, -1, -1)]
     if ops.gru_seq_bwd_has_kernel(H, ops.KERNEL_WS):
-        variants += [(f"ws {cp}/{ld}", ops.KERNEL_WS, cp, ld) for cp, ld in sorted({base, (0, 0), (max(base[0] // 2, 0), max(base[1] // 2, 1)), (base[0] + 1, base[1] + 2)})]
+        pairs = sorted({base, (0, 0), (max(base[0] // 2, 0), max(base[1] // 2, 1)), (base[0] + 1, base[1] + 2)})
+        if os.environ.get("BWD_PACE"):                      # explicit sweep: BWD_PACE="1/8,2/6,2/7"
+            pairs = [tuple(int(v) for v in pr.split("/")) for pr in os.environ["BWD_PACE"].split(",")]
+        variants += [(f"ws {cp}/{ld}", ops.KERNEL_WS, cp, ld) for cp, ld in pairs]
     def run(k, cp, ld, n=3):
         ts = []
         for _ in range(n):

@@ -92,7 +92,7 @@ extern "C" int vame_probe_set_coop(long long* p) { return (int)hipMemcpyToSymbol
 #define COOP_PHASE(i) do { const long long t_ = (long long)__builtin_amdgcn_s_memtime(); pp_[i] += t_ - pa_; pa_ = t_; } while (0)
 #define COOP_PHASE_END()                                                                            \
     if ((threadIdx.x & 63) == 0 && g_coop_probe) {                                                   \
-        long long* o_ = g_coop_probe + ((long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * 8;         \
+        long long* o_ = g_coop_probe + ((long long)blockIdx.x * (COOP_NT / 64) + (threadIdx.x >> 6)) * 8;         \
         for (int i_ = 0; i_ < 8; ++i_) o_[i_] = pp_[i_];                                             \
     }
 #else
@@ -111,6 +111,7 @@ constexpr int COOP_DEFAULT_POLLS = 1 << 30;
 constexpr int COOP_DEFAULT_POLLS = 1 << 18;
 #endif
 static int g_coop_polls = COOP_DEFAULT_POLLS;
+constexpr int COOP_NT = 512;             // 8 waves, two per SIMD: an MFMA stream fed from LDS fragments issues every ~34.6 cycles with two waves, 38 with one (r04_mfma_issue_probe.txt)
 constexpr int COOP_LL_OFF = 4096;        // (the flag words of a launch: <= 256 workgroups)
 extern "C" int vame_gru_coop_set_poll_limit(int polls) {
     const int old = g_coop_polls;
@@ -140,21 +141,22 @@ __device__ __forceinline__ bool coop_map(int ngroups, int& g, int& m, int& half)
 
 // Forward.  A group is the R rows of a batch tile (R = 32, or 16 when twice the workgroups still fit one per CU: the launches with two
 // streams at batch 256) x the S members.  A member's step is R x 32 columns x 3 gates over K = H, as 16 x 16 tiles of
-// v_mfma_f32_16x16x4_f32: wave w owns the 16 x 16 tile (row half, column half) = (w >> 1, w & 1) at R = 32, or column half w & 1 and
-// K half w >> 1 at R = 16 (the halves meet through LDS).  All three gates of a tile sit in the same lanes -- lane l holds column l & 15,
+// v_mfma_f32_16x16x4_f32 on eight waves (two per SIMD): wave w owns the 16 x 16 tile (row half, column half) = ((w >> 1) & 1, w & 1) and
+// the K half w >> 2 (as two separate quarters) at R = 32, or column half w & 1 and K quarter w >> 1 at R = 16; the quarters meet through LDS
+// in the tile's first wave and are added as (q0 + q1) + (q2 + q3) in either form.  All three gates of a tile sit in the same lanes -- lane l holds column l & 15,
 // rows 4 (l >> 4) .. +3 -- so the gate math, the publish of h_t and the BPTT stash (one float4 per quantity and lane, the layout of the
 // batch-tile kernels) need no exchange between waves, and all four SIMDs share the contraction (192 / 96 MFMAs of 32 cycles per wave
-// and step against 128 of 64 cycles on three of four SIMDs in the 32 x 32 form of rounds 2-3).  Both K halves are summed separately
-// and then added in either form, so a launch gives the same bits whichever R its row range selects.
+// and step against 128 of 64 cycles on three of four SIMDs in the 32 x 32 form of rounds 2-3).  The four K quarters are summed
+// separately and then added in the same order in either form, so a launch gives the same bits whichever R its row range selects.
 template <int H, int R>
-__global__ __launch_bounds__(256) COOP_ONE_WAVE_PER_SIMD void gru_coop_fwd_kernel(GruFwdParams P, int* __restrict__ flags, int base, int* __restrict__ status,
+__global__ __launch_bounds__(COOP_NT) COOP_ONE_WAVE_PER_SIMD void gru_coop_fwd_kernel(GruFwdParams P, int* __restrict__ flags, int base, int* __restrict__ status,
                                                            int max_polls) {
-    constexpr int NM = H / 32, NH = 32 / R, LDW = H + 4, LDH = H + 4, NCH = H / 16, HALF = NCH / 2;
+    constexpr int NM = H / 32, NH = 32 / R, LDW = H + 4, LDH = H + 4, NCH = H / 16, QN = NCH / 4, PBF = R == 32 ? 4 * 24 * 64 : 2 * 3 * 12 * 64;
     static_assert(R == 32 || R == 16, "row tiles of 32 or 16");
     VAME_DYN_SMEM(smem_raw);
     float* wl = reinterpret_cast<float*>(smem_raw);                        // [3][32][LDW] this member's rows of W_hh, k contiguous
     float* hs = wl + 96 * LDW;                                             // [R][LDH] h_{t-1} (A operand)
-    float* pb = hs + R * LDH;                                              // R = 16: [2][12][64] partial sums of the upper K half
+    float* pb = hs + R * LDH;                                              // partial sums of the K quarters that are not the tile's first wave's: [tile][24][64] / [column half][3][12][64]
     int g, m, half;
     if (!coop_map<NM, NH>(P.nstreams * P.ntiles, g, m, half)) return;
     const bool inject = max_polls < 0;
@@ -168,9 +170,10 @@ __global__ __launch_bounds__(256) COOP_ONE_WAVE_PER_SIMD void gru_coop_fwd_kerne
     const int nvalid = B - row0;
     const int tid = threadIdx.x, lane = tid & 63, c16 = lane & 15, kg = lane >> 4;
     const int w = UNIFORM(tid >> 6);
-    const int ch = w & 1, rh = R == 32 ? (w >> 1) : 0, kh = R == 32 ? 0 : (w >> 1);
+    const int ch = w & 1, rh = R == 32 ? ((w >> 1) & 1) : 0;
+    const int q0 = R == 32 ? 2 * (w >> 2) : (w >> 1);                       // first (R = 16: only) K quarter of this wave
     const int lrow = rh * 16 + 4 * kg, lcol = ch * 16 + c16;               // this lane: rows lrow .. lrow + 3, column lcol of the slice
-    const bool owner = R == 32 || kh == 0;                                 // lanes that finish the sums and do the gate math
+    const bool owner = q0 == 0;                                            // the tile's first wave: finishes the sums, does the gate math, publishes
     const int gidx = g * NH + half;
     float* ll = reinterpret_cast<float*>(flags + COOP_LL_OFF);             // tagged hand-off packets, behind the flag words
     float4* stash = S.stash ? reinterpret_cast<float4*>(S.stash) : nullptr;
@@ -188,12 +191,12 @@ __global__ __launch_bounds__(256) COOP_ONE_WAVE_PER_SIMD void gru_coop_fwd_kerne
     // ---- prologue: W slice -> LDS (the 32 x 32 x 2 fragment pack un-permuted: fragment (c, gate, lane) = 4 consecutive k of one row)
     {
         const f32x4* src = reinterpret_cast<const f32x4*>(S.wp) + (int64_t)m * (H / 8) * 3 * 64;
-        for (int i = tid; i < (H / 8) * 3 * 64; i += 256) {
+        for (int i = tid; i < (H / 8) * 3 * 64; i += COOP_NT) {
             const int c = i / 192, gt = (i % 192) / 64, l = i % 64;
             *reinterpret_cast<f32x4*>(&wl[(gt * 32 + (l & 31)) * LDW + 8 * c + 4 * (l >> 5)]) = src[i];
         }
     }
-    for (int i = tid; i < R * (H / 4); i += 256) {
+    for (int i = tid; i < R * (H / 4); i += COOP_NT) {
         const int r = i / (H / 4), c4 = i % (H / 4);
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (S.h0 && r < nvalid) v = *reinterpret_cast<const float4*>(S.h0 + (int64_t)(row0 + r) * S.h0_row + 4 * c4);
@@ -241,7 +244,7 @@ __global__ __launch_bounds__(256) COOP_ONE_WAVE_PER_SIMD void gru_coop_fwd_kerne
     COOP_PHASE_DECL();
     for (int step = 0; step < T; ++step) {
         const int t = S.reverse ? T - 1 - step : step;
-        f32x4 lo[3], hi[3];
+        f32x4 lo[3], hi[3];                       // this wave's quarter q0 (and, at R = 32, q0 + 1)
 #pragma unroll
         for (int gt = 0; gt < 3; ++gt)
 #pragma unroll
@@ -254,17 +257,19 @@ __global__ __launch_bounds__(256) COOP_ONE_WAVE_PER_SIMD void gru_coop_fwd_kerne
             // itself hipcc issues every chunk's ds_reads right in front of their first use and the LDS latency is exposed once per chunk
             // (probe: 51 cycles per 32-cycle MFMA).  Element-major issue order: consecutive MFMAs go to different accumulators.
             auto ldf = [](const float* p_) { return *reinterpret_cast<const f32x4*>(p_); };
+            const float* ar = arow + 4 * q0 * QN;
+            const float* br = brow + 4 * q0 * QN;
             if (R == 32) {
-                f32x4 a0 = ldf(arow), a1 = ldf(arow + 4 * HALF), b0[3], b1[3];
+                f32x4 a0 = ldf(ar), a1 = ldf(ar + 4 * QN), b0[3], b1[3];
 #pragma unroll
-                for (int gt = 0; gt < 3; ++gt) { b0[gt] = ldf(brow + gt * 32 * LDW); b1[gt] = ldf(brow + gt * 32 * LDW + 4 * HALF); }
+                for (int gt = 0; gt < 3; ++gt) { b0[gt] = ldf(br + gt * 32 * LDW); b1[gt] = ldf(br + gt * 32 * LDW + 4 * QN); }
 #pragma unroll 2
-                for (int c = 0; c < HALF; ++c) {
-                    const int cn = c + 1 < HALF ? c + 1 : c;
-                    const f32x4 na0 = ldf(arow + 4 * cn), na1 = ldf(arow + 4 * (cn + HALF));
+                for (int c = 0; c < QN; ++c) {
+                    const int cn = c + 1 < QN ? c + 1 : c;
+                    const f32x4 na0 = ldf(ar + 4 * cn), na1 = ldf(ar + 4 * (cn + QN));
                     f32x4 nb0[3], nb1[3];
 #pragma unroll
-                    for (int gt = 0; gt < 3; ++gt) { nb0[gt] = ldf(brow + gt * 32 * LDW + 4 * cn); nb1[gt] = ldf(brow + gt * 32 * LDW + 4 * (cn + HALF)); }
+                    for (int gt = 0; gt < 3; ++gt) { nb0[gt] = ldf(br + gt * 32 * LDW + 4 * cn); nb1[gt] = ldf(br + gt * 32 * LDW + 4 * (cn + QN)); }
                     SCHED_FENCE();
 #pragma unroll
                     for (int e = 0; e < 4; ++e)
@@ -279,14 +284,12 @@ __global__ __launch_bounds__(256) COOP_ONE_WAVE_PER_SIMD void gru_coop_fwd_kerne
                     for (int gt = 0; gt < 3; ++gt) { b0[gt] = nb0[gt]; b1[gt] = nb1[gt]; }
                 }
             } else {
-                const float* ar = arow + 4 * kh * HALF;
-                const float* br = brow + 4 * kh * HALF;
                 f32x4 a0 = ldf(ar), b0[3];
 #pragma unroll
                 for (int gt = 0; gt < 3; ++gt) b0[gt] = ldf(br + gt * 32 * LDW);
 #pragma unroll 2
-                for (int c = 0; c < HALF; ++c) {
-                    const int cn = c + 1 < HALF ? c + 1 : c;
+                for (int c = 0; c < QN; ++c) {
+                    const int cn = c + 1 < QN ? c + 1 : c;
                     const f32x4 na0 = ldf(ar + 4 * cn);
                     f32x4 nb0[3];
 #pragma unroll
@@ -304,19 +307,40 @@ __global__ __launch_bounds__(256) COOP_ONE_WAVE_PER_SIMD void gru_coop_fwd_kerne
             }
         }
         COOP_PHASE(0);
-        if (R == 16) {                                                     // the upper K half of each tile crosses to the lower half's wave
-            if (kh == 1) {
+        // ---- the quarters of a tile meet in its first wave: (q0 + q1) + (q2 + q3)
+        f32x4 sum[3];
+        {
+            if (R == 32) {
+                float* pw = pb + ((w & 3) * 24) * 64 + lane;
+                if (!owner) {
 #pragma unroll
-                for (int gt = 0; gt < 3; ++gt)
+                    for (int gt = 0; gt < 3; ++gt)
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) pb[(ch * 12 + gt * 4 + i) * 64 + lane] = lo[gt][i];
-            }
-            __syncthreads();
-            if (kh == 0) {
+                        for (int i = 0; i < 4; ++i) { pw[(gt * 4 + i) * 64] = lo[gt][i]; pw[(12 + gt * 4 + i) * 64] = hi[gt][i]; }
+                }
+                __syncthreads();
+                if (owner) {
 #pragma unroll
-                for (int gt = 0; gt < 3; ++gt)
+                    for (int gt = 0; gt < 3; ++gt)
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) hi[gt][i] = pb[(ch * 12 + gt * 4 + i) * 64 + lane];
+                        for (int i = 0; i < 4; ++i) sum[gt][i] = (lo[gt][i] + hi[gt][i]) + (pw[(gt * 4 + i) * 64] + pw[(12 + gt * 4 + i) * 64]);
+                }
+            } else {
+                float* pw = pb + (ch * 3 * 12) * 64 + lane;
+                if (!owner) {
+#pragma unroll
+                    for (int gt = 0; gt < 3; ++gt)
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) pw[((q0 - 1) * 12 + gt * 4 + i) * 64] = lo[gt][i];
+                }
+                __syncthreads();
+                if (owner) {
+#pragma unroll
+                    for (int gt = 0; gt < 3; ++gt)
+#pragma unroll
+                        for (int i = 0; i < 4; ++i)
+                            sum[gt][i] = (lo[gt][i] + pw[(gt * 4 + i) * 64]) + (pw[(12 + gt * 4 + i) * 64] + pw[(24 + gt * 4 + i) * 64]);
+                }
             }
         }
         COOP_PHASE(1);
@@ -325,8 +349,8 @@ __global__ __launch_bounds__(256) COOP_ONE_WAVE_PER_SIMD void gru_coop_fwd_kerne
 #pragma clang fp contract(off)      // the two instantiations (R = 32 / 16) must round alike: no fma formed here in one and not the other
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const float rr = fast_sigmoid(lo[0][i] + hi[0][i]), uu = fast_sigmoid(lo[1][i] + hi[1][i]);
-                an[i] = lo[2][i] + hi[2][i];
+                const float rr = fast_sigmoid(sum[0][i]), uu = fast_sigmoid(sum[1][i]);
+                an[i] = sum[2][i];
                 const float nn = fast_tanh(gcur[2][i] + rr * an[i]);
                 const float hp = hprev[i];
                 const float hv = nn + uu * (hp - nn);
@@ -369,12 +393,12 @@ __global__ __launch_bounds__(256) COOP_ONE_WAVE_PER_SIMD void gru_coop_fwd_kerne
         }
         COOP_PHASE(3);
         if (step + 1 == T) break;
-        if (R == 32) __syncthreads();              // every wave is done reading h_{t-1} (at R = 16 the K-half exchange barrier says so)
+        // (every wave is done reading h_{t-1}: the barrier of the quarter exchange says so)
         COOP_PHASE(4);
         // ---- every thread polls its share of the S members' packets until all tags are this step's, then rebuilds the R x H tile in LDS
         {
-            constexpr int NK = R * NM / 16;                                // 16-byte packets per thread: R * 16 per member, 256 threads
-            static_assert(NK == 8 || NK == 16 || NK == 4, "packet poll is written for H = 128 / 256");
+            constexpr int NK = R * NM * 16 / COOP_NT;                      // 16-byte packets per thread: R * 16 per member, COOP_NT threads
+            static_assert(NK == 8 || NK == 4 || NK == 2, "packet poll is written for H = 128 / 256");
             f32x4 v[16];
 #pragma unroll
             for (int k = NK; k < 16; ++k) v[k] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -385,8 +409,8 @@ __global__ __launch_bounds__(256) COOP_ONE_WAVE_PER_SIMD void gru_coop_fwd_kerne
             while (true) {
 #pragma unroll
                 for (int k = 0; k < NK; ++k)
-                    if (need >> k & 1u) COOP_LOAD16_LL(v[k], xr + (int64_t)k * 1024);
-                if (NK > 8) COOP_WAIT_LL16(v); else COOP_WAIT_LL8(v);
+                    if (need >> k & 1u) COOP_LOAD16_LL(v[k], xr + (int64_t)k * (COOP_NT * 4));
+                COOP_WAIT_LL8(v);
 #pragma unroll
                 for (int k = 0; k < NK; ++k)
                     if ((need >> k & 1u) && COOP_TAG(v[k][1]) == tag && COOP_TAG(v[k][3]) == tag) need &= ~(1u << k);
@@ -397,10 +421,10 @@ __global__ __launch_bounds__(256) COOP_ONE_WAVE_PER_SIMD void gru_coop_fwd_kerne
                 if (polls > max_polls || (polls == 64 && !inject && COOP_FLAG_LOAD(status) != 0)) { atomicAdd(status, 1); break; }
             }
             COOP_PHASE(5);
-            // packet (64-lane block bi = w + 4k of the group's packet stream, lane): member bi / (R/4), block bi % (R/4) = (tile, pair)
+            // packet (64-lane block bi = w + 8k of the group's packet stream, lane): member bi / (R/4), block bi % (R/4) = (tile, pair)
 #pragma unroll
             for (int k = 0; k < NK; ++k) {
-                const int bi = w + 4 * k, mm = bi / (R / 4), blk = bi % (R / 4), pj = blk & 1, tw = blk >> 1;
+                const int bi = w + (COOP_NT / 64) * k, mm = bi / (R / 4), blk = bi % (R / 4), pj = blk & 1, tw = blk >> 1;
                 const int prow_ = (R == 32 ? (tw >> 1) * 16 : 0) + 4 * kg + 2 * pj, pcol = mm * 32 + (tw & 1) * 16 + c16;
                 hs[prow_ * LDH + pcol] = v[k][0];
                 hs[(prow_ + 1) * LDH + pcol] = v[k][2];
@@ -427,7 +451,7 @@ __global__ __launch_bounds__(256) COOP_ONE_WAVE_PER_SIMD void gru_coop_fwd_kerne
 #endif
 
 template <int H, int R>
-static size_t coop_fwd_lds() { return (size_t)(96 * (H + 4) + R * (H + 4) + (R == 16 ? 2 * 12 * 64 : 0)) * 4; }
+static size_t coop_fwd_lds() { return (size_t)(96 * (H + 4) + R * (H + 4) + (R == 32 ? 4 * 24 * 64 : 2 * 3 * 12 * 64)) * 4; }
 
 // one flag word per (stream, 16-row half tile, member) in the first COOP_LL_OFF words (BPTT), then the forward kernel's tagged hand-off
 // packets: 2 step parities x 32 rows x H (value, tag) pairs per (stream, tile)
@@ -454,7 +478,7 @@ static int coop_cu_count() {
 }
 
 template <int H, int R> static size_t coop_bwd_lds();
-template <int H, int R> __global__ __launch_bounds__(256) COOP_ONE_WAVE_PER_SIMD void gru_coop_bwd_kernel(GruBwdParams, float*, int*, int, int*, int);
+template <int H, int R> __global__ __launch_bounds__(COOP_NT) COOP_ONE_WAVE_PER_SIMD void gru_coop_bwd_kernel(GruBwdParams, float*, int*, int, int*, int);
 // The runtime's own answer to "how many of these workgroups does one CU hold" (registers, LDS, waves): every cooperative kernel
 // must get >= 1, and the grid is then limited to ONE workgroup per CU (their LDS footprints exclude a second one anyway).
 static int coop_kernels_resident(int H) {
@@ -468,17 +492,17 @@ static int coop_kernels_resident(int H) {
         hipError_t e1, e2;
         if (H == 256) {
             int n16 = 0;
-            e1 = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nf, gru_coop_fwd_kernel<256, 32>, 256, coop_fwd_lds<256, 32>());
-            if (e1 == hipSuccess) e1 = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n16, gru_coop_fwd_kernel<256, 16>, 256, coop_fwd_lds<256, 16>());
-            e2 = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, gru_coop_bwd_kernel<256, 32>, 256, coop_bwd_lds<256, 32>());
-            if (e2 == hipSuccess) e2 = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n16, gru_coop_bwd_kernel<256, 16>, 256, coop_bwd_lds<256, 16>());
+            e1 = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nf, gru_coop_fwd_kernel<256, 32>, COOP_NT, coop_fwd_lds<256, 32>());
+            if (e1 == hipSuccess) e1 = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n16, gru_coop_fwd_kernel<256, 16>, COOP_NT, coop_fwd_lds<256, 16>());
+            e2 = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, gru_coop_bwd_kernel<256, 32>, COOP_NT, coop_bwd_lds<256, 32>());
+            if (e2 == hipSuccess) e2 = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n16, gru_coop_bwd_kernel<256, 16>, COOP_NT, coop_bwd_lds<256, 16>());
             nf = nf < n16 ? nf : n16;
         } else {
             int n16 = 0;
-            e1 = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nf, gru_coop_fwd_kernel<128, 32>, 256, coop_fwd_lds<128, 32>());
-            if (e1 == hipSuccess) e1 = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n16, gru_coop_fwd_kernel<128, 16>, 256, coop_fwd_lds<128, 16>());
-            e2 = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, gru_coop_bwd_kernel<128, 32>, 256, coop_bwd_lds<128, 32>());
-            if (e2 == hipSuccess) e2 = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n16, gru_coop_bwd_kernel<128, 16>, 256, coop_bwd_lds<128, 16>());
+            e1 = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nf, gru_coop_fwd_kernel<128, 32>, COOP_NT, coop_fwd_lds<128, 32>());
+            if (e1 == hipSuccess) e1 = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n16, gru_coop_fwd_kernel<128, 16>, COOP_NT, coop_fwd_lds<128, 16>());
+            e2 = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, gru_coop_bwd_kernel<128, 32>, COOP_NT, coop_bwd_lds<128, 32>());
+            if (e2 == hipSuccess) e2 = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n16, gru_coop_bwd_kernel<128, 16>, COOP_NT, coop_bwd_lds<128, 16>());
             nf = nf < n16 ? nf : n16;
         }
         r = (e1 == hipSuccess && e2 == hipSuccess && nf >= 1 && nb >= 1) ? 1 : 0;
@@ -538,7 +562,7 @@ extern "C" int vame_gru_coop_fwd_f32(const int64_t* desc, int nstreams, int B, i
         const size_t lds_ = coop_fwd_lds<HH, RR>();                                                                              \
         const int grid_ = coop_grid<HH / 32>(ngroups) * (32 / RR);                                                               \
         COOP_ALLOW_LDS((gru_coop_fwd_kernel<HH, RR>), lds_);                                                                     \
-        hipLaunchKernelGGL((gru_coop_fwd_kernel<HH, RR>), dim3(grid_), dim3(256), lds_, st, P, flags, epoch_base, status, g_coop_polls); \
+        hipLaunchKernelGGL((gru_coop_fwd_kernel<HH, RR>), dim3(grid_), dim3(COOP_NT), lds_, st, P, flags, epoch_base, status, g_coop_polls); \
     } while (0)
     if (H == 256) { if (r16) COOP_FWD_LAUNCH(256, 16); else COOP_FWD_LAUNCH(256, 32); }
     else          { if (r16) COOP_FWD_LAUNCH(128, 16); else COOP_FWD_LAUNCH(128, 32); }
@@ -566,9 +590,9 @@ extern "C" int vame_gru_coop_fwd_f32(const int64_t* desc, int nstreams, int B, i
 // partial tile nor the carry passes through LDS.  The two 16-row groups of a tile add their bias partials in a fixed order
 // (the upper one hands its sums to the lower one at the end of the launch), and the 32-row form sums in the same order.
 template <int H, int R>
-__global__ __launch_bounds__(256) COOP_ONE_WAVE_PER_SIMD void gru_coop_bwd_kernel(GruBwdParams P, float* __restrict__ xbuf, int* __restrict__ flags, int base,
+__global__ __launch_bounds__(COOP_NT) COOP_ONE_WAVE_PER_SIMD void gru_coop_bwd_kernel(GruBwdParams P, float* __restrict__ xbuf, int* __restrict__ flags, int base,
                                                            int* __restrict__ status, int max_polls) {
-    constexpr int NM = H / 32, NH = 32 / R, LDK = 100, LDG = 132, NCT = H / 16, TPW = NCT * (R / 16) / 4, RG = R / 4;
+    constexpr int NM = H / 32, NH = 32 / R, LDK = 100, LDG = 132, NCT = H / 16, NWV = COOP_NT / 64, TPW = NCT * (R / 16) / NWV, RG = R / 4;
     static_assert((NM == 8 || NM == 4) && (R == 32 || R == 16), "written for H = 128 / 256, 32- or 16-row groups");
     VAME_DYN_SMEM(smem_raw);
     float* wl = reinterpret_cast<float*>(smem_raw);                    // [H][LDK]  W_hh[gate*H + C_m][n] as wl[n][gate*32 + j]
@@ -595,7 +619,7 @@ __global__ __launch_bounds__(256) COOP_ONE_WAVE_PER_SIMD void gru_coop_bwd_kerne
 
     {   // W_hh rows {gate*H + C_m} x all columns, from the backward pack: wp_bwd[((ct*(3H/8) + c)*64 + l)*4 + e] = W[8c + 4(l>>5) + e][32ct + (l&31)]
         const f32x4* src = reinterpret_cast<const f32x4*>(S.wpt);
-        for (int i = tid; i < NM * 12 * 64; i += 256) {
+        for (int i = tid; i < NM * 12 * 64; i += COOP_NT) {
             const int ct = i / (12 * 64), rem = i % (12 * 64), gg = rem / 256, c64 = rem % 256, cc = c64 / 64, l = c64 % 64;
             *reinterpret_cast<f32x4*>(&wl[(32 * ct + (l & 31)) * LDK + gg * 32 + 8 * cc + 4 * (l >> 5)]) =
                 src[((int64_t)ct * (3 * H / 8) + (gg * H + 32 * m) / 8) * 64 + c64];
@@ -638,7 +662,7 @@ __global__ __launch_bounds__(256) COOP_ONE_WAVE_PER_SIMD void gru_coop_bwd_kerne
     load_step(0);
     float dbs0 = 0.f, dbs1 = 0.f, dbs2 = 0.f, dbs3 = 0.f;
     // MFMA phase: wave w owns the 16-row half rh and TPW column tiles from ct0 on
-    const int rh = R == 32 ? (w >> 1) : 0, ct0 = R == 32 ? (w & 1) * TPW : w * TPW;
+    const int rh = R == 32 ? w / (NWV / 2) : 0, ct0 = R == 32 ? (w % (NWV / 2)) * TPW : w * TPW;
     const float* arow = &gs[(rh * 16 + c16) * LDG + 4 * kg];
     const float* brow = &wl[(ct0 * 16 + c16) * LDK + 4 * kg];
     __syncthreads();
@@ -828,7 +852,7 @@ extern "C" int vame_gru_coop_bwd_f32(const int64_t* desc, int nstreams, int B, i
         const size_t lds_ = coop_bwd_lds<HH, RR>();                                                                              \
         const int grid_ = coop_grid<HH / 32>(ngroups) * (32 / RR);                                                               \
         COOP_ALLOW_LDS((gru_coop_bwd_kernel<HH, RR>), lds_);                                                                     \
-        hipLaunchKernelGGL((gru_coop_bwd_kernel<HH, RR>), dim3(grid_), dim3(256), lds_, st, P, xbuf, flags, epoch_base, status, g_coop_polls); \
+        hipLaunchKernelGGL((gru_coop_bwd_kernel<HH, RR>), dim3(grid_), dim3(COOP_NT), lds_, st, P, xbuf, flags, epoch_base, status, g_coop_polls); \
     } while (0)
     if (H == 256) { if (r16) COOP_BWD_LAUNCH(256, 16); else COOP_BWD_LAUNCH(256, 32); }
     else          { if (r16) COOP_BWD_LAUNCH(128, 16); else COOP_BWD_LAUNCH(128, 32); }
