@@ -1,15 +1,16 @@
 // Column-split ("cooperative") GRU sequence kernels for SMALL batches.
 //
 // gru_seq.hip gives one workgroup a whole 32-row batch tile: at batch 256 that is 8 tiles x 2 directions = 16 workgroups on a
-// 256-CU chip, and a time step costs what one CU needs for 32 x 3H x H MACs (~29 us at H = 256) no matter how idle the rest
-// is.  Here a tile is shared by S = H/32 workgroups (a "group", all on one XCD): member s owns hidden columns
-// [32s, 32s+32) of all three gates, keeps ITS 3 x 32 x H slice of W_hh in LDS for the whole sequence (98 KB at H = 256,
-// nothing is re-streamed), and after every step the members exchange their 32 x 32 slices of h_t through the output
-// sequence tensor itself (it has to be written anyway): write-through (sc1) 16-byte stores -> drained -> one relaxed agent-scope
-// flag per member; consumers poll the S flags, then read the 32 x H tile with sc1 loads (the R1 hand-off form of
-// MI355X_MICROARCH.md: no fences, L1 bypassed, L2-served inside the XCD).  I/O contract (descriptor table, stash layout, padded
-// sequence layout) is identical to vame_gru_seq_fwd_f32, and so are the results, bit for bit: same MFMA k-order, same gate
-// arithmetic.
+// 256-CU chip, and a time step costs what one CU needs for 32 x 3H x H MACs (~26 us at H = 256) no matter how idle the rest
+// is.  Here the R rows of a tile (R = 32, or 16 where twice the workgroups still get a CU each) are shared by S = H/32 workgroups
+// (a "group", all on one XCD): member s owns hidden columns [32s, 32s+32) of all three gates and keeps ITS slice of W_hh in LDS for
+// the whole sequence (98-102 KB at H = 256, nothing is re-streamed).  The contraction runs on 16 x 16 x 4 MFMA tiles over eight waves
+// (two per SIMD), which makes gate math, publish and the BPTT stash lane-local.  After every step the members hand each other their
+// slices of h_t as self-validating (value, tag) pairs (forward: every consumer thread polls the data itself, no flag, no drain) or
+// reduce-scatter their partial dh through a double-buffered scratch behind a drained flag (BPTT); loads and stores of the hand-off carry
+// sc1 (L1 bypassed, L2-served inside the XCD: MI355X_MICROARCH.md, hand-off price list).  I/O contract (descriptor table, stash layout,
+// padded sequence layout) is identical to vame_gru_seq_fwd_f32 / _bwd_f32; results agree to summation-order rounding (K is summed in
+// quarters / by member) and are the same bits for every form of a launch (16- / 32-row groups, row-range launches).
 //
 // Residency: the spin wait needs every member of a group running.  The launcher refuses grids above one workgroup per CU
 // (<= 256 workgroups, LDS forces 1 per CU), every poll loop is bounded and reports through `status` instead of hanging.
@@ -45,7 +46,7 @@ static inline unsigned emu_tag(float x) { unsigned u; __builtin_memcpy(&u, &x, 4
 #define COOP_TAG(x) emu_tag(x)
 #define COOP_WAIT_LOADS8(a, b, c, d, e, f, g, h)
 #define COOP_DRAIN()
-#define COOP_ONE_WAVE_PER_SIMD
+#define COOP_WAVES_PER_SIMD
 #define COOP_MFMA_SETTLE()
 #define COOP_FLAG_STORE(p, v) __atomic_store_n((p), (v), __ATOMIC_RELEASE)
 #define COOP_FLAG_LOAD(p) __atomic_load_n((p), __ATOMIC_ACQUIRE)
@@ -75,8 +76,8 @@ static inline unsigned emu_tag(float x) { unsigned u; __builtin_memcpy(&u, &x, 4
     } while (0)
 #define COOP_TAG(x) __float_as_uint(x)
 #define COOP_DRAIN() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
-// LDS allows one workgroup per CU = one wave per SIMD: the register allocator may use the whole file instead of spilling at 128
-#define COOP_ONE_WAVE_PER_SIMD __attribute__((amdgpu_waves_per_eu(1, 2)))
+// LDS allows one workgroup per CU = two waves per SIMD: the register allocator may use 256 registers per wave instead of spilling at 128
+#define COOP_WAVES_PER_SIMD __attribute__((amdgpu_waves_per_eu(1, 2)))
 // MFMA results read by an asm store: the hazard recognizer does not look inside inline asm, so the wait states an 8-pass MFMA needs
 // before a VMEM instruction may read its destination (11) are spelled out
 #define COOP_MFMA_SETTLE() asm volatile("s_nop 15\n s_nop 3" ::: "memory")
@@ -149,7 +150,7 @@ __device__ __forceinline__ bool coop_map(int ngroups, int& g, int& m, int& half)
 // and step against 128 of 64 cycles on three of four SIMDs in the 32 x 32 form of rounds 2-3).  The four K quarters are summed
 // separately and then added in the same order in either form, so a launch gives the same bits whichever R its row range selects.
 template <int H, int R>
-__global__ __launch_bounds__(COOP_NT) COOP_ONE_WAVE_PER_SIMD void gru_coop_fwd_kernel(GruFwdParams P, int* __restrict__ flags, int base, int* __restrict__ status,
+__global__ __launch_bounds__(COOP_NT) COOP_WAVES_PER_SIMD void gru_coop_fwd_kernel(GruFwdParams P, int* __restrict__ flags, int base, int* __restrict__ status,
                                                            int max_polls) {
     constexpr int NM = H / 32, NH = 32 / R, LDW = H + 4, LDH = H + 4, NCH = H / 16, QN = NCH / 4, PBF = R == 32 ? 4 * 24 * 64 : 2 * 3 * 12 * 64;
     static_assert(R == 32 || R == 16, "row tiles of 32 or 16");
@@ -478,7 +479,7 @@ static int coop_cu_count() {
 }
 
 template <int H, int R> static size_t coop_bwd_lds();
-template <int H, int R> __global__ __launch_bounds__(COOP_NT) COOP_ONE_WAVE_PER_SIMD void gru_coop_bwd_kernel(GruBwdParams, float*, int*, int, int*, int);
+template <int H, int R> __global__ __launch_bounds__(COOP_NT) COOP_WAVES_PER_SIMD void gru_coop_bwd_kernel(GruBwdParams, float*, int*, int, int*, int);
 // The runtime's own answer to "how many of these workgroups does one CU hold" (registers, LDS, waves): every cooperative kernel
 // must get >= 1, and the grid is then limited to ONE workgroup per CU (their LDS footprints exclude a second one anyway).
 static int coop_kernels_resident(int H) {
@@ -590,7 +591,7 @@ extern "C" int vame_gru_coop_fwd_f32(const int64_t* desc, int nstreams, int B, i
 // partial tile nor the carry passes through LDS.  The two 16-row groups of a tile add their bias partials in a fixed order
 // (the upper one hands its sums to the lower one at the end of the launch), and the 32-row form sums in the same order.
 template <int H, int R>
-__global__ __launch_bounds__(COOP_NT) COOP_ONE_WAVE_PER_SIMD void gru_coop_bwd_kernel(GruBwdParams P, float* __restrict__ xbuf, int* __restrict__ flags, int base,
+__global__ __launch_bounds__(COOP_NT) COOP_WAVES_PER_SIMD void gru_coop_bwd_kernel(GruBwdParams P, float* __restrict__ xbuf, int* __restrict__ flags, int base,
                                                            int* __restrict__ status, int max_polls) {
     constexpr int NM = H / 32, NH = 32 / R, LDK = 100, LDG = 132, NCT = H / 16, NWV = COOP_NT / 64, TPW = NCT * (R / 16) / NWV, RG = R / 4;
     static_assert((NM == 8 || NM == 4) && (R == 32 || R == 16), "written for H = 128 / 256, 32- or 16-row groups");
