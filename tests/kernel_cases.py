@@ -517,6 +517,14 @@ def check_gru_kernel_option_is_an_argument(dev):
         BWD_KERNEL = 7
         with pytest.raises(_lib.VameHipError, match="unknown kernel option"):
             _run_gru_bwd(dev, H, B, T, st, Y, dYt, dhNt)
+        # the cooperative launches know AUTO and LOCKSTEP (= 32-row groups) only
+        state = ops.CoopState(torch.device(dev))
+        x2, st2, Y2, hN2 = run_gru_fwd(dev, 128, 8, 2, seed=1)
+        with pytest.raises(_lib.VameHipError, match="kernel option"):
+            run_gru_fwd(dev, 128, 8, 2, seed=1, coop=state, coop_kernel=ops.KERNEL_SKEWED)
+        with pytest.raises(_lib.VameHipError, match="kernel option"):
+            _run_gru_bwd(dev, 128, 8, 2, st2, Y2, torch.zeros(8, 2, 256, device=dev), torch.zeros(8, 256, device=dev), coop=state, coop_kernel=ops.KERNEL_WS)
+        assert int(state.status.item()) == 0
     finally:
         BWD_KERNEL = ops.KERNEL_AUTO
 
