@@ -93,12 +93,12 @@ def test_prep_fill_rules(emu):
     check_prep_fill_rules("cpu")
 
 
-@pytest.mark.parametrize("H,B,T", [(128, 40, 3), (256, 37, 4)])
+@pytest.mark.parametrize("H,B,T", [(128, 40, 3), (256, 37, 4), (128, 17, 1), (256, 49, 2)])
 def test_gru_coop_fwd(emu, H, B, T):
     check_gru_coop_fwd("cpu", H, B, T)
 
 
-@pytest.mark.parametrize("H,B,T", [(128, 40, 3), (256, 37, 4)])
+@pytest.mark.parametrize("H,B,T", [(128, 40, 3), (256, 37, 4), (128, 17, 1), (256, 49, 2)])
 def test_gru_coop_bwd(emu, H, B, T):
     check_gru_coop_bwd("cpu", H, B, T)
 

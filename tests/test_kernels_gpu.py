@@ -85,12 +85,12 @@ def test_prep_fill_rules(hip):
     check_prep_fill_rules(DEV)
 
 
-@pytest.mark.parametrize("H,B,T", [(128, 40, 3), (256, 37, 4), (256, 256, 30), (256, 500, 30), (128, 1000, 7)])
+@pytest.mark.parametrize("H,B,T", [(128, 40, 3), (256, 37, 4), (128, 17, 1), (256, 49, 2), (256, 256, 30), (256, 500, 30), (128, 1000, 7)])
 def test_gru_coop_fwd(hip, H, B, T):
     check_gru_coop_fwd(DEV, H, B, T)
 
 
-@pytest.mark.parametrize("H,B,T", [(128, 40, 3), (256, 37, 4), (256, 256, 30), (256, 500, 30), (128, 1000, 7)])
+@pytest.mark.parametrize("H,B,T", [(128, 40, 3), (256, 37, 4), (128, 17, 1), (256, 49, 2), (256, 256, 30), (256, 500, 30), (128, 1000, 7)])
 def test_gru_coop_bwd(hip, H, B, T):
     check_gru_coop_bwd(DEV, H, B, T)
 
