@@ -385,12 +385,20 @@ class RNN_VAE(nn.Module):
                 if self._pad is not None:
                     self._pad.pull_grads(self._flat_g)
             eng.join_cluster()
-            out = losses[:4].clone()
-            out[2] = out[2] * (-0.5 / (B * s.Z))
-            if mse_red != "sum":
-                out[0] = out[0] / (B * s.T * F)
-            if s.future and mse_pred != "sum":
-                out[1] = out[1] / (B * s.FS * F)
+            # [rec, fut, kl, kmeans] in the reference's units: one multiply by a cached scale vector (every small torch op here is
+            # enqueue time of a step that is nearly host-bound at the stock batch)
+            with_fut = bool(training and s.future)
+            key = (B, mse_red, mse_pred, with_fut, str(eng.dev))
+            scale = self._loss_scale.get(key) if hasattr(self, "_loss_scale") else None
+            if scale is None:
+                if not hasattr(self, "_loss_scale"):
+                    self._loss_scale = {}
+                scale = self._loss_scale[key] = torch.tensor(
+                    [1.0 if mse_red == "sum" else 1.0 / (B * s.T * F), 1.0 if (not s.future or mse_pred == "sum") else 1.0 / (B * s.FS * F),
+                     -0.5 / (B * s.Z), 1.0], device=eng.dev, dtype=torch.float32)
+            out = losses[:4] * scale
+            if not with_fut:
+                out[1] = 0.0                    # (no future term in this pass: the slot may hold anything)
         eng.snapshot_async_errors()
         return out
 

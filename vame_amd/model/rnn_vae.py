@@ -185,6 +185,10 @@ def train(train_loader, epoch, model, optimizer, anneal_function, BETA, kl_start
     keep = seq_len_half + (future_steps if future_decoder else 0)
     kl_weight = kl_annealing(epoch, kl_start, annealtime, anneal_function)
     acc = torch.zeros(5, device=dev, dtype=torch.float64)     # total, rec, fut, kl, kmeans (summed over batches)
+    # total = rec + fut + BETA * kl_weight * kl + kl_weight * kmeans as ONE weighted sum per step (the stock batch is nearly host-bound:
+    # every small torch op in this loop is ~8 us of enqueue time)
+    wts = torch.tensor([1.0, 1.0, BETA * kl_weight, kl_weight], device=dev, dtype=torch.float32)
+    acc_total, acc_terms = acc[:1], acc[1:]
     last = None
     idx = -1
     for idx, data_item in enumerate(train_loader):
@@ -194,8 +198,9 @@ def train(train_loader, epoch, model, optimizer, anneal_function, BETA, kl_start
                                 mse_pred=mse_pred, enc_in=enc_in)
         gscale = allreduce_gradients(model)
         optimizer.step(gscale=gscale) if isinstance(optimizer, FusedAdamAMSGrad) else optimizer.step()
-        total = terms[0] + terms[1] + BETA * kl_weight * terms[2] + kl_weight * terms[3]
-        acc += torch.stack([total, terms[0], terms[1], terms[2], terms[3]]).to(torch.float64)
+        total = torch.dot(terms, wts)
+        acc_total += total
+        acc_terms += terms
         last = total
     if idx < 1:
         raise ValueError("train(): need at least 2 batches per epoch (the reference divides by the last batch index, "
@@ -218,15 +223,18 @@ def test(test_loader, epoch, model, optimizer, BETA, kl_weight, seq_len, mse_red
     model.eval()
     dev = model.flat_parameters()[0].device
     seq_len_half = int(seq_len / 2)
-    acc = torch.zeros(4, device=dev, dtype=torch.float64)
+    acc5 = torch.zeros(5, device=dev, dtype=torch.float64)    # total, rec, (fut: not part of the test loss), kl, kmeans
+    wts = torch.tensor([1.0, 0.0, BETA * kl_weight, kl_weight], device=dev, dtype=torch.float32)
+    acc_total, acc_terms = acc5[:1], acc5[1:]
     idx = -1
     with torch.no_grad():
         for idx, data_item in enumerate(test_loader):
             win = _to_windows(data_item, seq_len_half, dev)
             terms = model.loss_step(win, kl_weight, beta=BETA, kloss=kloss, klmbda=klmbda, bsize=bsize, mse_red=mse_red,
                                     backward=False)
-            total = terms[0] + BETA * kl_weight * terms[2] + kl_weight * terms[3]
-            acc += torch.stack([total, terms[0], terms[2], terms[3]]).to(torch.float64)
+            acc_total += torch.dot(terms, wts)
+            acc_terms += terms
+    acc = acc5[[0, 1, 3, 4]]
     if idx < 1:
         raise ValueError("test(): need at least 2 test batches of batch_size/4 (rnn_vae.py:207-210 divides by the last index)")
     test_loss, mse_loss, kullback_loss, kmeans_losses = [float(v) for v in _rank_mean(acc).cpu()]
