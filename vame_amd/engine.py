@@ -172,6 +172,7 @@ class VAEEngine:
         # the future decoder's two dW_hh contractions beside the small-kernel chain that follows the decoders' BPTT launch (_early_wgrads)
         self.bwd_overlap = os.environ.get("VAME_AMD_BWD_OVERLAP", "1") != "0"
         self.skinny_side = os.environ.get("VAME_AMD_SKINNY_SIDE", "1") != "0"
+        self._wgrad_plans = {}
         self.wgrad_min_rounds = 0          # grouped weight gradients: whole rounds of 3 workgroups per CU, at least this many (0 = by K, see _group_wgrads)
         self._early_stream, self._early_pending = None, False
         self._nuc_stream = None
@@ -256,8 +257,25 @@ class VAEEngine:
         them and each problem needs fewer partial sums for the same occupancy.  Returns the jobs left for single launches."""
         if not self.group_wgrads:
             return jobs
+        # the grouping depends on shapes and layouts only: planned once per job signature (a quarter of backward()'s host time otherwise)
+        sig = (ws_name, self.wgrad_min_rounds, tuple((j[0], j[1], j[2], j[3].ld, j[3].seg, j[3].seg_stride, j[4].ld, j[4].seg, j[4].seg_stride,
+                                                      j[5], j[6], j[7], j[8]) for j in jobs))
+        plan = self._wgrad_plans.get(sig)
+        if plan is None:
+            plan = self._wgrad_plans[sig] = self._plan_wgrads(jobs)
+        launches, rest_idx = plan
+        for grp, idx, M, N, K, sk, gap_at, gap, c_offs in launches:
+            if grp == 1 and after_first is not None:
+                after_first()
+                after_first = None
+            ws = self.ws.get(ws_name, len(idx) * sk * M * N, self.dev)
+            ops.gemm_group(M, N, K, [jobs[i][3] for i in idx], 1, [jobs[i][4] for i in idx], 1, self.g, c_offs, N, sk, ws, a_gap_at=gap_at, a_gap=gap)
+        return [jobs[i] for i in rest_idx]
+
+    def _plan_wgrads(self, jobs):
+        """([(group ordinal, job indices, M, N, K, split-K, gap_at, gap, output offsets)] in launch order, indices of the jobs left over)."""
         groups, rest = {}, []
-        for j in jobs:
+        for i, j in enumerate(jobs):
             M, N, K, A, Bop, gname, row_off, gap_at, gap = j
             # large K: (M <= 32: the 24/30-row heads keep their own skinny-M tile).  Small K (K = batch <= 2048: the contractions
             # over the batch alone -- decoders' dW_ih, latent_to_hidden, Lambda): every such launch is a chain of <= 8 dependent k-tiles
@@ -265,28 +283,25 @@ class VAEEngine:
             # of single-k-tile workgroups + one reduction, any M
             if row_off == 0 and ((M > 32 and K >= 8 * 256) or (256 <= K < 8 * 256 and _slabs(K, 8) >= 8)):
                 key = (M, N, K, A.ld, A.seg, A.seg_stride, Bop.ld, Bop.seg, Bop.seg_stride, gap_at, gap)
-                groups.setdefault(key, []).append(j)
+                groups.setdefault(key, []).append(i)
             else:
-                rest.append(j)
-        launched = 0
+                rest.append(i)
+        launches, launched = [], 0
         # largest group first (the six T-step dW_hh contractions: the step's dominant launch); `after_first` runs behind it
         for key, members in sorted(groups.items(), key=lambda kv: -kv[0][0] * kv[0][1] * kv[0][2] * len(kv[1])):
             if len(members) < 2:
                 rest += members
                 continue
-            if launched == 1 and after_first is not None:
-                after_first()
-                after_first = None
+            grp = launched
             launched += 1
             M, N, K = key[:3]
-            for i in range(0, len(members), 8):
-                part = members[i:i + 8]
+            for i0 in range(0, len(members), 8):
+                part = members[i0:i0 + 8]
                 if len(part) < 2:
                     rest += part
                     continue
                 tiles = ((M + 127) // 128) * ((N + 127) // 128 if N > 64 else 1) * len(part)
-                # whole rounds of 3 workgroups per CU: the smallest multiple of 8 with >= 2 rounds (dynamic balancing between
-                # rounds), capped so that a workgroup keeps >= 8 k-tiles
+                # whole rounds of 3 workgroups per CU: the smallest multiple of 8 with enough rounds, capped so that a workgroup keeps >= 8 k-tiles
                 cands = [k for k in range(8, 129, 8) if k * 8 * 32 <= K]
                 # one whole round where the k-slabs stay short (K = batch x time < 2^18: +0.5 % at batch 4096, +1.7 % at 256 against two rounds --
                 # half the partial sums), two where a slab is long enough for the workgroups to drift apart (K = 491,520: one round -0.4 %);
@@ -294,10 +309,8 @@ class VAEEngine:
                 rounds = self.wgrad_min_rounds or (1 if K < (1 << 18) else 2)
                 full = [k for k in cands if tiles * k >= rounds * 768 and (tiles * k) % 768 == 0]
                 sk = full[0] if full else next((k for k in cands if tiles * k >= rounds * 768), cands[-1] if cands else 8)
-                ws = self.ws.get(ws_name, len(part) * sk * M * N, self.dev)
-                ops.gemm_group(M, N, K, [m[3] for m in part], 1, [m[4] for m in part], 1, self.g, [self.table.off(m[5]) for m in part],
-                               N, sk, ws, a_gap_at=key[9], a_gap=key[10])
-        return rest
+                launches.append((grp, part, M, N, K, sk, key[9], key[10], [self.table.off(jobs[i][5]) for i in part]))
+        return launches, rest
 
     def _sum_into(self, C, M, N, jobs):
         """C (M,N) = sum of A_j (M,K_j) @ B_j (K_j,N).  Products of one K go out as one grouped launch whose partial sums are reduced
