@@ -173,6 +173,7 @@ class VAEEngine:
         self.bwd_overlap = os.environ.get("VAME_AMD_BWD_OVERLAP", "1") != "0"
         self.skinny_side = os.environ.get("VAME_AMD_SKINNY_SIDE", "1") != "0"
         self._wgrad_plans = {}
+        self._coop_covers = {}
         self.wgrad_min_rounds = 0          # grouped weight gradients: whole rounds of 3 workgroups per CU, at least this many (0 = by K, see _group_wgrads)
         self._early_stream, self._early_pending = None, False
         self._nuc_stream = None
@@ -496,17 +497,27 @@ class VAEEngine:
         if self._stepwise(H) or not self.coop:
             return []
         steps = lambda r: int(r[tkey]) if (r and tkey is not None) else 1                    # noqa: E731
-        options = [([rows], ops.coop_row_chunks(len(rows), B, H))]
-        if len(rows) > 2 and len(rows) % 2 == 0:                       # decoder + future decoder: one pair of directions each
-            options.append(([rows[i:i + 2] for i in range(0, len(rows), 2)], ops.coop_row_chunks(2, B, H)))
-        options = [(sets, ch) for sets, ch in options if ch]
-        if not options:
+        # the cover depends on (stream count, their lengths, batch, hidden size) only: decided once per signature
+        sig = (len(rows), tuple(steps(r) for r in rows), B, H)
+        cover = self._coop_covers.get(sig)
+        if cover is None:
+            idx = list(range(len(rows)))
+            options = [([idx], ops.coop_row_chunks(len(rows), B, H))]
+            if len(rows) > 2 and len(rows) % 2 == 0:                   # decoder + future decoder: one pair of directions each
+                options.append(([idx[i:i + 2] for i in range(0, len(rows), 2)], ops.coop_row_chunks(2, B, H)))
+            options = [(sets, ch) for sets, ch in options if ch]
+            if options:
+                # every launch lasts as long as its longest sequence: pick the cover with the fewest (launch x step) slots
+                sets, chunks = min(options, key=lambda o: len(o[1]) * sum(max(steps(rows[i]) for i in st) for st in o[0]))
+                cover = [(st, ch) for st in sets for ch in chunks]
+            else:
+                cover = []
+            self._coop_covers[sig] = cover
+        if not cover:
             return []
-        # every launch lasts as long as its longest sequence: pick the cover with the fewest (launch x step) slots
-        sets, chunks = min(options, key=lambda o: len(o[1]) * sum(max(steps(r) for r in st) for st in o[0]))
         if self._coop_state is None:
             self._coop_state = ops.CoopState(self.dev)
-        return [(st, ch) for st in sets for ch in chunks]
+        return [([rows[i] for i in st], ch) for st, ch in cover]
 
     def _gru_fwd(self, rows, B):
         """One launch for streams of one hidden size; streams of different sizes (hidden_size_rec != hidden_size_pred) go out
