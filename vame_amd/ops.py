@@ -224,7 +224,7 @@ class CoopState:
     exception: the optimizer takes the dropped launches out of its bias-correction step count there."""
 
     def __init__(self, dev, ints=1 << 16):
-        self.flags = torch.zeros(ints, dtype=torch.int32, device=dev)
+        self.flags = torch.full((ints,), -7, dtype=torch.int32, device=dev)      # older than the first epoch, equal to no tag the first launches look for
         self.status = torch.zeros(1, dtype=torch.int32, device=dev)
         self.shared = None
         self.on_error = []
