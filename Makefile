@@ -37,7 +37,7 @@ tests/emu/libvame_emu.so: $(foreach n,$(NAMES),build/emu/$(n).o) build/emu/hip_e
 
 # tuning build with all GEMM variants selectable through VAME_GEMM_VAR / VAME_GEMM_EPI and the GRU ablation masks
 # (tools/microbench.py gemm_ab / gemm_epi / gemm_sk / ablate)
-build/ab/%.o: vame_amd/csrc/%.hip $(HDR)
+build/ab/%.o: vame_amd/csrc/%.hip $(HDR) tools/gemm_split_variants.inc
 	@mkdir -p build/ab
 	$(HIPCC) $(HIPFLAGS) -DVAME_GEMM_AB -DVAME_TUNING_BUILD -c -o $@ $<
 

@@ -16,8 +16,8 @@ The series is already resident in HBM when the timed region starts.
 Prints ONE JSON line (rank 0): metric/value/unit + roofline (dominant kernel, measured with HIP
 events on the launch stream; HBM-bound kernels of the step next to it) + cpu_baseline
 (reference-equivalent torch-CPU model, oracle/torch_ref.py) + `repeat_spread` (two more timed regions
-of the same length) + `also` (N = 1: BASELINE configs[3] shape and a configs[4]-shape embedding pass,
-each with its own roofline) + `distributed` (N > 1: proof of the RCCL path and a same-run 1-rank leg).
+of the same length) + `also` (N = 1: BASELINE configs[3] shape, a configs[4]-shape embedding pass with its CPU baseline, the stock batch
+256, each with its own roofline, and `split_gemm`: the opt-in split-bf16 weight-gradient contraction) + `distributed` (N > 1: proof of the RCCL path and a same-run 1-rank leg).
 """
 import argparse
 import json
@@ -150,13 +150,21 @@ def profile_kernels(model, loader, B, steps=3):
             return (f"gru_coop_{tag}_kernel<{Hh}> x{len(streams)} streams", sum(2.0 * 3 * Hh * Hh * nrows * int(s[key_t]) for s in streams))
         return f
 
+    # contractions with a dimension <= 32 (K = 24 / 30 projections of the features / of z, the 24- / 30-wide heads and their weight gradients)
+    # stream their large operand once at HBM speed with the matrix pipes nearly idle (MFMA busy 0.05-0.31): they are rows of the HBM table
+    # (algorithmic bytes = A, B read once + C written once), not of an MFMA class
     def gemm_flops(M, N, K, A, akm, Bm, bkm, *a, **k):
         kind = "NT" if (not akm and not bkm) else ("NN" if not akm else "TN")
+        if min(M, N, K) <= 32:
+            return (f"hbm gemm_kernel {kind} narrow (a dimension <= 32)", 4.0 * (M * K + K * N + M * N))
         return (f"gemm_kernel {kind} M={M} N={N} K={K}", 2.0 * M * N * K)
 
     def group_flops(M, N, K, As, akm, Bs, bkm, *a, **k):
         kind = "NT" if (not akm and not bkm) else ("NN" if not akm else "TN")
-        return (f"gemm_kernel {kind} M={M} N={N} K={K} x{len(As)} grouped", 2.0 * M * N * K * len(As))
+        if min(M, N, K) <= 32:
+            return (f"hbm gemm_kernel {kind} narrow (a dimension <= 32)", 4.0 * (M * K + K * N + M * N) * len(As))
+        sp = k.get("split")
+        return (f"gemm_kernel {kind} M={M} N={N} K={K} x{len(As)} grouped" + ("" if sp is None else f" bf16x6 opt={sp}"), 2.0 * M * N * K * len(As))
 
     # HBM-bound kernels: algorithmic bytes = every element read once + every element written once
     def gather_bytes(X, N, F_, starts, start0, B_, L, out):
@@ -241,9 +249,12 @@ def roofline_block(agg, value_per_gpu, mflop_per_window, ms_per_step, dump=False
                 step_frac=round(step_frac, 4),
                 clock_mhz_timed_region=round(region_mhz, 0) if region_mhz else None, step_frac_at_clock=at_clock(step_frac, region_mhz),
                 by_class=by_class, timed_kernel_ms_per_step=round(sum(d["ms"] for d in agg.values()), 3),
-                mfma_kernel_ms_per_step=round(mfma_ms, 3), non_mfma_ms_per_step=round(ms_per_step - mfma_ms, 3),
-                note="per-kernel times: 3 separate steps with the side-stream overlaps off (serial); ms_per_step: timed region with them on, "
-                     "so ms_per_step - mfma_kernel_ms_per_step understates the non-MFMA time by what the overlaps hide")
+                mfma_kernel_ms_per_step=round(mfma_ms, 3), non_mfma_ms_per_step=round(max(0.0, ms_per_step - mfma_ms), 3),
+                # serial sum of every timed kernel minus the step time of the timed region: what the side-stream overlaps hide (positive) or what
+                # the host adds between launches (negative: a host-bound step)
+                hidden_by_overlaps_ms_per_step=round(sum(d["ms"] for d in agg.values()) - ms_per_step, 3),
+                note="per-kernel times: 3 separate steps with the side-stream overlaps off (serial); ms_per_step: timed region with them on; "
+                     "non_mfma_ms_per_step = max(0, ms_per_step - mfma_kernel_ms_per_step) understates the non-MFMA time by what the overlaps hide")
 
 
 def lib_source_id():
@@ -396,7 +407,7 @@ def release_leg(on_gpu):
         torch.cuda.empty_cache()
 
 
-def train_leg(dev, H, T, B, steps, warmup, rank, world, repeats=1, profile=True, dump=False, one_rank_leg=False):
+def train_leg(dev, H, T, B, steps, warmup, rank, world, repeats=1, profile=True, dump=False, one_rank_leg=False, engine_options=None):
     """Build the model at (H, T), run `warmup` untimed + `repeats` timed regions of `steps` steps.  Returns a dict with the region
     times, the last loss terms, the roofline block (GPU only) and -- several ranks -- the collective's own numbers."""
     from vame_amd.model.dataloader import DeviceWindowLoader
@@ -406,6 +417,7 @@ def train_leg(dev, H, T, B, steps, warmup, rank, world, repeats=1, profile=True,
     sync = torch.cuda.synchronize if on_gpu else (lambda: None)
     torch.manual_seed(19)
     model = RNN_VAE(2 * T, Z, F, 1, FS, H, H, H, H, 0, 0, 0, False).to(dev).train()
+    model.engine_options = dict(engine_options or {})
     opt = FusedAdamAMSGrad(model, lr=5e-4)
     loader = DeviceWindowLoader(_SynthDataset(T), B, T + FS, dev, rank=0, world=1)
     np.random.seed(1000 + rank)
@@ -433,6 +445,7 @@ def train_leg(dev, H, T, B, steps, warmup, rank, world, repeats=1, profile=True,
         res["distributed"] = collective_block(model, step, steps, rank, world, sync, dev, dts[0], one_rank_leg)
     if profile and on_gpu and rank == 0:
         agg = profile_kernels(model, loader, B)
+        res["agg"] = agg
         res["roofline"] = roofline_block(agg, B * steps / dts[0], res["mflop"], dts[0] / steps * 1e3, dump, region_mhz=res["mhz"])
     del model, opt, loader
     release_leg(on_gpu)
@@ -532,6 +545,40 @@ def embed_leg(dev, n_win_per_rank, rank, world, H=256, T=30):
                               traffic=pmc_traffic("gru_seq_fwd_kernel<256> x2 streams gi T=30 embed") if dev.type == "cuda" else None))
 
 
+PEAK_BF16_MFMA_TFLOPS = 2500.0             # MI355X_MICROARCH.md: dense bf16 MFMA peak
+
+
+def split_gemm_block(dev, steps, warmup, default_res):
+    """OPT-IN leg (not the headline): the same configs[1] train step with the large weight gradients (the six dW_hh, the two layer-1 dW_ih,
+    the future decoder's two dW_hh: two k-major operands, K = batch x time) on the error-compensated split-bf16 contraction
+    (vame_gemm_group_bf16x6_f32, engine option split_wgrad) instead of the f32-input matrix cores; everything else unchanged.  fp32-equivalent
+    flops against the bf16 dense peak / 6 plane products."""
+    out = dict(arith="large weight gradients: bf16x6 split operands (three exact bf16 planes per fp32 value, six plane products), f32 accumulate; "
+                     "everything else: f32-input MFMA as in the headline",
+               peak=round(PEAK_BF16_MFMA_TFLOPS / 6, 1), unit="TFLOP/s (fp32-equivalent)", peak_note="bf16 dense peak 2500 TF / 6 plane products",
+               default_ms_per_step=round(default_res["dts"][0] / steps * 1e3, 3),
+               error_table="profiles/r05_split_gemm_error_table.txt (max error vs float64: 0.4x the f32-input kernel's with two accumulators per output, "
+                           "1.0x with one); parity: tests/test_model_gpu.py::test_headline_batch_4096_all_gradients... at the unchanged tolerance, both ways")
+    dom = "gemm_kernel TN M=768 N=256 K=122880 x6 grouped"
+    base = (default_res.get("agg") or {}).get(dom)
+    if base:
+        out["default_launch"] = dict(kernel=dom, launch_ms=round(base["ms"] / base["launches"], 4),
+                                     tflops=round(base["work"] / base["launches"] / (base["ms"] / base["launches"] * 1e-3) / 1e12, 1))
+    for name, optw in (("one_accumulator", 1), ("two_accumulators", 0)):
+        r = train_leg(dev, 256, 30, 4096, steps, warmup, 0, 1, engine_options=dict(split_wgrad=optw))
+        line = dict(engine_option=f"split_wgrad={optw}", value=round(4096 * steps / r["dts"][0], 1), unit="windows/s",
+                    ms_per_step=round(r["dts"][0] / steps * 1e3, 3), clock_mhz_timed_region=round(r["mhz"], 0) if r["mhz"] else None)
+        launches = {}
+        for k, d in (r.get("agg") or {}).items():
+            if " bf16x6 " in k:
+                tf = d["work"] / d["launches"] / (d["ms"] / d["launches"] * 1e-3) / 1e12
+                launches[k] = dict(launch_ms=round(d["ms"] / d["launches"], 4), tflops=round(tf, 1), frac=round(tf / (PEAK_BF16_MFMA_TFLOPS / 6), 4),
+                                   clock_mhz=round(d["mhz"], 0) if d.get("mhz") else None)
+        line["launches"] = launches
+        out[name] = line
+    return out
+
+
 def workload_name(H, T, B, world):
     if world > 1:
         head = f"BASELINE.json configs[2] shape on {world} GPUs (data-parallel)"
@@ -609,7 +656,11 @@ def main():
             b256_line = dict(metric="temporal windows/sec (train) T=30,F=24,h=256", value=round(256 * 30 / b256["dts"][0], 1), unit="windows/s",
                              steps=30, warmup=10, ms_per_step=round(b256["dts"][0] / 30 * 1e3, 3),
                              config=dict(workload=workload_name(256, 30, 256, 1)), roofline=b256["roofline"])
-            also = dict(configs3_h512_t60_b8192=c4_line, configs4_embed_1gpu=embed_leg(dev, 2_000_000, 0, 1), batch256=b256_line)
+            emb_line = embed_leg(dev, 2_000_000, 0, 1)
+            if not args.no_cpu_baseline:              # the reference's batch-1 loop as written and a batch-256 variant, beside the embedding number
+                emb_line["cpu_baseline"] = cpu_baseline_embed()
+            also = dict(configs3_h512_t60_b8192=c4_line, configs4_embed_1gpu=emb_line, batch256=b256_line,
+                        split_gemm=split_gemm_block(dev, args.steps, args.warmup, res))
         out = None
         if rank == 0:
             dt = res["dts"][0]

@@ -63,6 +63,18 @@ int vame_gemm_group_f32(int count, int M, int N, int K, const float* const* A, i
                         int64_t a_seg_stride, const float* const* B, int64_t ldb, int b_kmajor, int64_t b_seg, int64_t b_seg_stride,
                         float* const* C, int64_t ldc, int accumulate, int splitk, float* ws, int a_gap_at, int a_gap, void* stream);
 
+/* vame_gemm_group_f32 for two k-major operands (C[g] (+)= A[g]^T B[g]: the weight gradients of vame/model/rnn_vae.py:141-143,
+ * loss.backward() -> dW_hh / dW_ih over K = batch x time), evaluated on the bf16 matrix cores with an ERROR-COMPENSATED SPLIT: every
+ * fp32 operand value is split exactly into three bf16 planes (x = x1 + x2 + x3) and the six plane products (1,1) (1,2) (2,1) (2,2)
+ * (1,3) (3,1) are accumulated in fp32 -- fp32-grade results at 6/16 of the f32-input matrix cores' time.  OPT-IN: the default path of
+ * the library stays on true fp32 matrix instructions.  Same arguments and semantics as vame_gemm_group_f32 (both operands k-major);
+ * additional requirements: M, N, lda, ldb, the segment strides, a_gap_at and a_gap even, operands 8-byte aligned, a slab of K / splitk
+ * rows spans < 1 GiB.  Inf / NaN inputs give NaN.  opt: bits 0-1 = accumulators per output (0 = default 2: the leading product on its
+ * own accumulator; 1 = one for all six products), bit 4 = MFMA waves at raised priority. */
+int vame_gemm_group_bf16x6_f32(int count, int M, int N, int K, const float* const* A, int64_t lda, int64_t a_seg, int64_t a_seg_stride,
+                               const float* const* B, int64_t ldb, int64_t b_seg, int64_t b_seg_stride, float* const* C, int64_t ldc,
+                               int accumulate, int splitk, float* ws, int a_gap_at, int a_gap, int opt, void* stream);
+
 /* Pack one GRU layer-direction's recurrent weights for the sequence kernels.
  *   W_hh (3H,H), b_ih/b_hh (3H) -> wp_fwd (3H*H, MFMA B-fragment order for h W_hh^T),
  *   wp_bwd (3H*H, fragment order for dgh W_hh), bias_gi (3H) = b_ih + [b_hr, b_hz, 0], b_hn (H). */

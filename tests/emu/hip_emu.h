@@ -46,7 +46,7 @@ enum { hipMemcpyDeviceToDevice = 3 };
 namespace emu {
 constexpr int WAVE = 64;
 struct Fiber { void* sp; char* stack; bool done; };
-struct WaveState { int count = 0; int gen = 0; float buf[4][WAVE]; unsigned long long ubuf[WAVE]; };
+struct WaveState { int count = 0; int gen = 0; float buf[4][WAVE]; unsigned long long ubuf[WAVE]; unsigned mbuf[2][WAVE][4]; };
 struct BlockCtx {
     std::vector<Fiber> fibers;
     std::vector<WaveState> waves;
@@ -136,6 +136,32 @@ static inline f32x4_emu emu_mfma_16x16x4(float a, float b, f32x4_emu c) {
         float acc = c[r];
         for (int k = 0; k < 4; ++k) acc = fmaf(w.buf[0][k * 16 + row], w.buf[1][k * 16 + col], acc);
         c[r] = acc;
+    }
+    emu::wave_sync();
+    return c;
+}
+// v_mfma_f32_32x32x16_bf16: lane l supplies 8 bf16 (four dwords, low half first) of A row / B column (l & 31) for k = 8 * (l >> 5) .. + 7;
+// C/D layout as the other 32x32 forms.  Products of two bf16 are exact in fp32; the 16 of a row-column pair are summed exactly here
+// (double) and rounded once into the fp32 accumulator -- the device's internal order is not documented, the tests compare with a tolerance.
+typedef unsigned u32x4_emu __attribute__((ext_vector_type(4)));
+static inline float emu_bf16_at(const unsigned (&w)[4], int e) {
+    const unsigned u = (e & 1) ? (w[e >> 1] & 0xffff0000u) : (w[e >> 1] << 16);
+    float f;
+    memcpy(&f, &u, 4);
+    return f;
+}
+static inline f32x16_emu emu_mfma_32x32x16_bf16(u32x4_emu a, u32x4_emu b, f32x16_emu c) {
+    emu::WaveState& w = emu::wave();
+    int l = emu::lane_id();
+    for (int d = 0; d < 4; ++d) { w.mbuf[0][l][d] = a[d]; w.mbuf[1][l][d] = b[d]; }
+    emu::wave_sync();
+    int col = l & 31;
+    for (int r = 0; r < 16; ++r) {
+        int row = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
+        double s = 0.0;
+        for (int h = 0; h < 2; ++h)
+            for (int e = 0; e < 8; ++e) s += (double)emu_bf16_at(w.mbuf[0][h * 32 + row], e) * (double)emu_bf16_at(w.mbuf[1][h * 32 + col], e);
+        c[r] = (float)((double)c[r] + s);
     }
     emu::wave_sync();
     return c;

@@ -45,6 +45,93 @@ def check_gemm_group(dev, small=True):
         np.testing.assert_allclose(N_(Cg)[0], ref, atol=2e-4 * np.sqrt(K))
 
 
+def split_planes(x):
+    """The three bf16 planes of fp32 values by truncation (x = x1 + x2 + x3 exactly), as float64 -- what gemm_split_kernel's producer
+    waves compute (vame_amd/csrc/gemm.hip: prod_split)."""
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    hi = lambda v: (v.view(np.uint32) & np.uint32(0xffff0000)).view(np.float32)        # noqa: E731
+    x1 = hi(x)
+    r1 = x - x1
+    x2 = hi(r1)
+    x3 = r1 - x2
+    assert np.array_equal(x1.astype(np.float64) + x2.astype(np.float64) + x3.astype(np.float64), x.astype(np.float64))
+    assert np.array_equal(hi(x3), x3)
+    return [v.astype(np.float64) for v in (x1, x2, x3)]
+
+
+def split_reference(a, b):
+    """sum over the six plane products (1,1) (1,2) (2,1) (2,2) (1,3) (3,1) of a^T b in float64: what the split contraction evaluates
+    (up to fp32 accumulation rounding)."""
+    pa, pb = split_planes(a), split_planes(b)
+    return sum(pa[i].T @ pb[j] for i, j in ((0, 0), (0, 1), (1, 0), (1, 1), (0, 2), (2, 0)))
+
+
+def check_gemm_split(dev, small=True):
+    """vame_gemm_group_bf16x6_f32 (error-compensated split-bf16 contraction of two k-major operands) against float64: ragged and partial
+    tiles, partial last k-tile, two-level (batch, time) rows with short and long segments, the dW_hh column gap, accumulation, a shared
+    output, both accumulator options.  Tolerances: against the six-plane-product sum the only error is fp32 accumulation (tight);
+    against the exact product additionally the dropped plane products (< 2^-21 |a||b| each)."""
+    rng = np.random.default_rng(11)
+    cases = [  # M, N, K(rows), n, sk, seg_a, seg_b, gap, acc, opt (0 = two accumulators per output, 1 = one)
+        (96, 136, 8 * 32, 3, 8, 0, 0, 0, False, 0), (70, 72, 8 * 64 - 2, 2, 8, 0, 6, 0, True, 1), (64, 100, 16 * 30, 2, 8, 30, 30, 32, False, 0),
+        (130, 30, 16 * 15, 2, 8, 15, 15, 0, False, 1), (128, 128, 8 * 32 + 1, 1, 9, 0, 0, 0, False, 2), (300, 136, 8 * 32 + 6, 2, 9, 0, 0, 0, False, 0),
+    ]
+    if not small:
+        cases += [(768, 256, 64 * 30 * 4, 6, 32, 0, 30, 256, False, 0), (768, 512, 48 * 30 * 2, 2, 16, 0, 30, 0, False, 1), (200, 264, 4095, 3, 24, 7, 0, 0, True, 0),
+                  (768, 256, 64 * 30 * 4, 6, 32, 0, 30, 256, False, 1)]
+    for (M, Nn, K, n, sk, sega, segb, gap, acc, opt) in cases:
+        Mw = M + gap
+        gap_at = (M // 2) // 4 * 4 if gap else 0
+
+        def mk(width, seg):
+            """(dense values (K, width), stored tensor, Operand fields): seg != 0 stores rows as (K / seg, seg + 2, width + 6) with the
+            view starting at slot 1 -- the (B, T + 2, 2H) sequence layout of the engine."""
+            v = (rng.standard_normal((K, width)) * np.exp(rng.uniform(-6, 6, (K, 1)))).astype(np.float32)
+            if not seg:
+                return v, v, dict(ld=width)
+            assert K % seg == 0
+            st = rng.standard_normal((K // seg, seg + 2, width + 6)).astype(np.float32)
+            st[:, 1:seg + 1, 2:2 + width] = v.reshape(K // seg, seg, width)
+            return v, st, dict(ld=width + 6, seg=seg, seg_stride=(seg + 2) * (width + 6), off=(width + 6) + 2)
+        As, Bs = [mk(Mw, sega) for _ in range(n)], [mk(Nn, segb) for _ in range(n)]
+        C0 = rng.standard_normal((n, M, Nn)).astype(np.float32)
+        At, Bt, C = [T_(a[1], dev) for a in As], [T_(b[1], dev) for b in Bs], T_(C0, dev)
+        ws = torch.zeros(n * sk * M * Nn, device=dev)
+        opA = [Operand(t, **a[2]) for t, a in zip(At, As)]
+        opB = [Operand(t, **b[2]) for t, b in zip(Bt, Bs)]
+        assert ops.gemm_split_ok(M, Nn, K, opA, opB, sk, gap_at, gap)
+        ops.gemm_group(M, Nn, K, opA, 1, opB, 1, C, [g * M * Nn for g in range(n)], Nn, sk, ws, accumulate=acc, a_gap_at=gap_at, a_gap=gap, split=opt)
+        out = N_(C)
+        cols = np.r_[0:gap_at, gap_at + gap:Mw] if gap else np.arange(M)
+        for g in range(n):
+            a, b = As[g][0][:, cols], Bs[g][0]
+            base = C0[g].astype(np.float64) if acc else 0.0
+            mag = np.abs(a).astype(np.float64).T @ np.abs(b).astype(np.float64)           # sum |a||b| per output
+            six = split_reference(a, b) + base
+            exact = a.astype(np.float64).T @ b.astype(np.float64) + base
+            tag = str((M, Nn, K, n, sk, sega, segb, gap, acc, opt, g))
+            # fp32 accumulation of the leading product alone (two accumulators: measured <= 2.2e-7 of sum |a||b| on the MI355X) or of all six
+            # products (one: <= 3.6e-7, the f32-input MFMA kernel's own level); the dropped plane products add < 2^-21
+            tol = 2.0 ** -21 if (opt & 3) != 1 else 2.0 ** -20
+            assert np.all(np.abs(out[g] - six) <= tol * (mag + np.abs(base)) + 1e-30), tag + f" vs six planes: {np.max(np.abs(out[g] - six) / (mag + 1e-30)):.3e}"
+            assert np.all(np.abs(out[g] - exact) <= 1.5 * tol * (mag + np.abs(base)) + 1e-30), tag + f" vs exact: {np.max(np.abs(out[g] - exact) / (mag + 1e-30)):.3e}"
+    # every problem naming one C: the partial sums of all problems are one stack
+    M, Nn, K, n, sk = 64, 66, 8 * 32, 3, 8
+    As = [rng.standard_normal((K, M)).astype(np.float32) for _ in range(n)]
+    Bs = [rng.standard_normal((K, Nn)).astype(np.float32) for _ in range(n)]
+    C = torch.zeros(M, Nn, device=dev)
+    ws = torch.zeros(n * sk * M * Nn, device=dev)
+    ops.gemm_group(M, Nn, K, [Operand(T_(a, dev), M) for a in As], 1, [Operand(T_(b, dev), Nn) for b in Bs], 1, C, [0] * n, Nn, sk, ws, split=0)
+    ref = sum(a.astype(np.float64).T @ b.astype(np.float64) for a, b in zip(As, Bs))
+    np.testing.assert_allclose(N_(C), ref, atol=1e-5 * np.sqrt(K * n))
+    # what it refuses: odd pitches / misaligned operands (8-byte loads), fewer than 8 slabs
+    a, b = torch.zeros(K, 65, device=dev), torch.zeros(K, 64, device=dev)
+    assert not ops.gemm_split_ok(64, 64, K, [Operand(a, 65)], [Operand(b, 64)], 8)
+    assert not ops.gemm_split_ok(64, 64, K, [Operand(a, 64, off=1)], [Operand(b, 64)], 8)
+    with pytest.raises(Exception):
+        ops.gemm_group(64, 64, K, [Operand(a, 65)], 1, [Operand(b, 64)], 1, C, [0], 64, 8, ws, split=0)
+
+
 def check_gemm_group_shared_output(dev):
     """All problems of a group naming one C: C (+)= sum_g A_g B_g (dz of the decoders), against float64."""
     rng = np.random.default_rng(4)

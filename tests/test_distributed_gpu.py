@@ -76,3 +76,14 @@ def test_bench_line_contract(hip):
     b256 = also["batch256"]
     assert b256["value"] > 30_000 and b256["steps"] == 30 and "batch=256" in b256["config"]["workload"]
     assert {"gru_coop_fwd_kernel<256>", "gru_coop_bwd_kernel<256>"} <= set(b256["roofline"]["by_class"])
+    # round 5: narrow contractions (a dimension <= 32) are rows of the HBM table; no negative times; the opt-in split-bf16 weight-gradient
+    # contraction is an `also` leg with both step times, its launches priced against bf16 dense / 6, and the headline stays on f32-input MFMA
+    assert any(k.startswith("gemm_kernel") and "narrow" in k and v["bound"] == "hbm" for k, v in roof["by_class"].items())
+    assert roof["non_mfma_ms_per_step"] >= 0 and "hidden_by_overlaps_ms_per_step" in roof
+    assert not any("bf16x6" in k for k in roof["by_class"]) and "bf16x6" not in roof["kernel"]
+    sg = also["split_gemm"]
+    assert abs(sg["peak"] - 2500.0 / 6) < 0.1 and sg["default_ms_per_step"] == j["ms_per_step"]
+    for name in ("one_accumulator", "two_accumulators"):
+        leg = sg[name]
+        assert leg["value"] > 50_000 and len(leg["launches"]) == 3, leg
+        assert all(0 < v["frac"] <= 1 and v["tflops"] > 60 for v in leg["launches"].values()), leg["launches"]

@@ -135,13 +135,15 @@ def test_hidden_sizes_above_1024_run_the_stepwise_path(hip):
 
 
 def test_cfg4_shape_h512_t60_vs_oracle(hip):
-    """BASELINE config 4 shape (hidden=512, T=60, 2-layer bi-GRU encoder): per-step MFMA gate-GEMM path vs the numpy oracle."""
+    """BASELINE config 4 shape (hidden=512, T=60, 2-layer bi-GRU encoder): the two-blocks-per-wave persistent kernels (gru_wide.hip: forward and
+    BPTT) vs the numpy oracle."""
     T, F, Z, H, FS, B = 60, 24, 30, 512, 15, 48
     torch.manual_seed(19)
     model = RNN_VAE(2 * T, Z, F, 1, FS, H, H, H, H, 0, 0, 0, False)
     p = {k: v.numpy().copy() for k, v in model.state_dict().items()}
     model = model.cuda().train()
-    assert model._ensure_engine().stepwise
+    eng = model._ensure_engine()
+    assert eng._wide(H) and eng.wide_bwd          # (hidden sizes the wide kernels do not cover take the per-step GEMM path: test_hidden_sizes_above_1024...)
     rng = np.random.default_rng(4)
     win = rng.standard_normal((B, T + FS, F)).astype(np.float32)
     eps = rng.standard_normal((B, Z)).astype(np.float32)
@@ -205,20 +207,35 @@ def test_headline_batch_4096_all_gradients_vs_torch_cpu_reference(hip):
     loss, terms = reference_loss(out_ref, win[:, :T], win[:, T:], 1.0)
     loss.backward()
     model = model.cuda().train()
-    out = model.loss_step(win.cuda(), 1.0, beta=1.0, kloss=Z, klmbda=0.1, bsize=B, eps=eps.cuda()).cpu().numpy()
-    for i, (k, v) in enumerate(zip(["rec", "fut", "kl", "kmeans"], terms)):
-        assert_loss_close(out[i], v.item(), name=k)
-    eng = model._engine
-    mu = eng.buf("mu", B, Z)[:B * Z].view(B, Z).cpu().numpy()
-    assert np.abs(mu - out_ref[3].detach().numpy()).max() < 1e-4          # BASELINE.json: latent max-abs-diff < 1e-4
     rg = ref.reference_named_grads()
     assert len(rg) == 44
-    worst = {}
-    for k, prm in model.named_parameters():
-        r = rg[k].numpy()
-        worst[k] = np.abs(prm.grad.cpu().numpy() - r).max() / np.abs(r).max()          # relative to the tensor's own scale
-    bad = {k: v for k, v in worst.items() if v > BIG_REL}
-    assert not bad, bad
+    from vame_amd import ops
+    # the default step (f32-input matrix cores everywhere), then the same step with the large weight gradients on the opt-in split-bf16
+    # contraction (engine option split_wgrad: two accumulators per output / one) -- the SAME tolerance for all three
+    for split in (None, 0, 1):
+        eng = model._ensure_engine()
+        eng.split_wgrad = split
+        calls, orig = [], ops.gemm_group
+        ops.gemm_group = lambda *a, **k: (calls.append((a[0], a[1], a[2], k.get("split"))), orig(*a, **k))[1]
+        try:
+            out = model.loss_step(win.cuda(), 1.0, beta=1.0, kloss=Z, klmbda=0.1, bsize=B, eps=eps.cuda()).cpu().numpy()
+        finally:
+            ops.gemm_group = orig
+        on_split = [c for c in calls if c[3] is not None]
+        if split is None:
+            assert not on_split
+        else:           # the six dW_hh (768 x 256 x 122,880), the two layer-1 dW_ih (768 x 512), the future decoder's two dW_hh (K = 61,440)
+            assert sorted(c[:3] for c in on_split) == [(768, 256, 61440), (768, 256, 122880), (768, 512, 122880)] and all(c[3] == split for c in on_split)
+        for i, (k, v) in enumerate(zip(["rec", "fut", "kl", "kmeans"], terms)):
+            assert_loss_close(out[i], v.item(), name=k)
+        mu = eng.buf("mu", B, Z)[:B * Z].view(B, Z).cpu().numpy()
+        assert np.abs(mu - out_ref[3].detach().numpy()).max() < 1e-4          # BASELINE.json: latent max-abs-diff < 1e-4
+        worst = {}
+        for k, prm in model.named_parameters():
+            r = rg[k].numpy()
+            worst[k] = np.abs(prm.grad.cpu().numpy() - r).max() / np.abs(r).max()          # relative to the tensor's own scale
+        bad = {k: v for k, v in worst.items() if v > BIG_REL}
+        assert not bad, (split, bad)
 
 
 def test_three_step_adam_trajectory_matches_reference(hip):

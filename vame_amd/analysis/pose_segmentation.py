@@ -34,6 +34,7 @@ def load_model(cfg, model_name, fixed):
     model = RNN_VAE(cfg['time_window'] * 2, cfg['zdims'], NUM_FEATURES, cfg['prediction_decoder'], cfg['prediction_steps'],
                     cfg['hidden_size_layer_1'], cfg['hidden_size_layer_2'], cfg['hidden_size_rec'], cfg['hidden_size_pred'],
                     cfg['dropout_encoder'], cfg['dropout_rec'], cfg['dropout_pred'], cfg['softplus'])
+    model.engine_options = dict(cfg.get('vame_amd_engine') or {})
     dev = _device()
     path = os.path.join(cfg['project_path'], 'model', 'best_model', model_name + '_' + cfg['Project'] + '.pkl')
     model.load_state_dict(torch.load(path, map_location="cpu"))

@@ -765,3 +765,369 @@ extern "C" int vame_gemm_group_f32(int count, int M, int N, int K, const float* 
     VAME_LAUNCH_CHECK("gemm_group reduce");
     return VAME_OK;
 }
+
+// =====================================================================================================================================
+// Error-compensated SPLIT-bf16 form of the grouped k-major x k-major contraction (weight gradients: C_g = A_g^T B_g over K = batch x time).
+// Opt-in (vame_gemm_group_bf16x6_f32); the default path above stays on the f32-input matrix cores.
+//
+// Why: v_mfma_f32_32x32x2_f32 issues at the vector-ALU rate (157 TF) and occupies the SIMD's VALU lanes, v_mfma_f32_32x32x16_bf16 runs
+// 16x faster on its own pipe.  Every fp32 operand value is split EXACTLY into three bf16 planes by truncation, x = x1 + x2 + x3 (8 + 8 + 8
+// significand bits, fp32's exponent range, so no scaling: x1 = the upper 16 bits of x, x2 = the upper 16 bits of the exact remainder
+// x - x1, x3 = what is left), and the contraction is evaluated as the six plane products (1,1) (1,2) (2,1) (2,2) (1,3) (3,1) with fp32
+// accumulation: the dropped products (2,3) (3,2) (3,3) are below 2^-21 of |x||y| and a bf16 x bf16 product is exact in fp32.  With the
+// leading product on its own accumulator (NACC = 2) the low-order terms (<= 2^-7 of it) add no rounding of their own: measured error 0.4x
+// the f32-input kernel's (one rounding per K = 16 block instead of sixteen); with one accumulator for all six products (NACC = 1) it is
+// the f32-input kernel's level.  6/16 of the f32-input MFMA's pipe time per flop.
+//
+// Mapping (the fastest of four that were built and measured, see below): 128 x 128 output tile, BK = 32, 256-thread workgroups of FOUR
+// SYMMETRIC waves, two (NACC = 2) or three (NACC = 1) workgroups per CU.  Per k-tile every wave
+//   1. splits its share of the tile -- operand wave >> 1, rows [16 (wave & 1), + 16), a lane owns two adjacent columns: 16
+//      buffer_load_dwordx2 of wave-uniform rows (the two-level (batch, time) row offsets are computed once per k-tile on 16 lanes and handed
+//      out with v_readlane as the loads' scalar offsets), ~9 VALU per four values (v_and / v_pk_add_f32 / v_perm_b32), 12 ds_write_b128;
+//   2. issues the loads of the next k-tile (in flight during the MFMAs), LDS-only barrier;
+//   3. contracts its 64 x 64 quarter: 24 ds_read_b128 + 48 MFMAs; LDS-only barrier.
+// The workgroups of a CU fill each other's split / barrier phases with MFMAs (the scheme of gemm_kernel's plain loop).
+// LDS image (48 KB): [plane][operand][k-octet][column] in 16-byte units (8 bf16 of one column = one MFMA operand of a lane); columns are
+// stored even | odd, the odd half rotated by 8 slots, so the 16-byte stores and the fragment reads are both conflict-free.  The k order
+// inside a k-tile is a permutation (an octet = eight consecutive rows), identical for A and B.
+//
+// What bounds it (tools/split_abl.py on the dominant launch, 6 x 768 x 256 x 122,880, profiles/r05_split_abl.txt; tools/
+// mfma_valu_overlap_probe.hip, profiles/r05_mfma_valu_overlap_probe.txt): the MFMAs alone take 0.75-0.8 ms, but (a) with 128 x 128 tiles the
+// operand panels pass through the L1s 9.06 GB per launch (A twice, B six times) and that stream alone takes 0.85 ms whatever the load width
+// or the number of waves in flight (~10.6 TB/s L2 -> L1); (b) the split is 576 VALU wave-instructions per CU and k-tile; one wave issues
+// them at 7-8 cycles each and at 14 beside another wave's MFMAs (v_pk_add_f32 15.5), so they need every wave of the CU; (c) the planes are
+// 48 KB of ds_write_b128 per k-tile at ~73 B/clk; (d) with MFMAs, L2 traffic and VALU all active the shader clock falls to 1.9-2.1 GHz
+// (f32-input kernel: 2.2).  Three other mappings measured 12-19 % slower and live in tools/gemm_split_variants.inc (tuning build only):
+// wave-specialised 4 MFMA + 4 split waves with three LDS images (2.0 ms: one split wave per SIMD is VALU-issue-bound), 256 x 128 tiles with
+// eight waves and two images (1.85 ms: 6.8 GB through the L1s, but the phases of a wave's in-order stream do not overlap), 4 MFMA + 8 split
+// waves (1.89 ms: the MFMA stream alone runs at 0.77 ms = 34 cycles per MFMA with one fragment read between the MFMAs, the producers need 1.06).
+// =====================================================================================================================================
+namespace split6 {
+constexpr int BK = 32, TILE = 128;
+constexpr int REGION = 2048;               // one (plane, operand, k-octet): 128 columns x 8 bf16
+constexpr int PLANE = 8 * REGION;          // [operand A | B][octet 0..3]
+constexpr int BUF = 3 * PLANE;             // three planes of one k-tile
+constexpr int NBUF = 3;
+constexpr unsigned HI16 = 0xffff0000u;
+
+__device__ __forceinline__ int xslot(int x) { return ((x & 1) << 10) + (((x >> 1) ^ ((x & 1) << 3)) << 4); }
+__device__ __forceinline__ unsigned fbits(float f) { return __builtin_bit_cast(unsigned, f); }
+__device__ __forceinline__ float ufloat(unsigned u) { return __builtin_bit_cast(float, u); }
+// the bf16 (upper) halves of two fp32 values in one dword: lo in bits 0..15
+__device__ __forceinline__ unsigned pack_hi16(float lo, float hi) {
+#ifdef VAME_EMU
+    return (fbits(lo) >> 16) | (fbits(hi) & HI16);
+#else
+    return __builtin_amdgcn_perm(fbits(hi), fbits(lo), 0x07060302u);
+#endif
+}
+__device__ __forceinline__ int uniform(int v) {
+#ifdef VAME_EMU
+    return v;
+#else
+    return __builtin_amdgcn_readfirstlane(v);
+#endif
+}
+
+// A producer wave's position in a k-major operand: the first of its 16 rows of the k-tile it loads next.  Wave-uniform (scalar
+// registers).  Two-level rows: row g = (b, t) = (g / seg, g % seg) sits at b * seg_stride + t * ld.  Offsets are bytes relative to the
+// slab's first row (the buffer range's base), < 2^30 (checked on the host).  The cursor never moves past the slab's last row: tiles
+// behind the end of the slab re-read its last rows (they are prefetched unconditionally so that every interval issues the same loads)
+// and rows >= ke of the last tile are zeroed by the caller.
+struct RowCursor {
+    unsigned off0, ld4, wrap4;
+    int g0, t0, seg, ke;
+    __device__ __forceinline__ void init(const GemmOperand& o, int kb, int g, int ke_) {
+        ke = ke_;
+        ld4 = (unsigned)(o.ld * 4);
+        g0 = g < ke ? g : ke - 1;
+        if (o.seg) {
+            seg = (int)o.seg; wrap4 = (unsigned)((o.seg_stride - o.seg * o.ld) * 4);
+            t0 = g0 % seg;
+        } else { seg = 0x7fffffff; wrap4 = 0; t0 = 0; }
+        off0 = (unsigned)((op_row(o, g0) - op_row(o, kb)) * 4);
+    }
+    // byte offsets of rows g0 + min(j, rows left) for j = lane & 15 (one row per lane, computed on the vector ALU once per k-tile)
+    __device__ __forceinline__ unsigned lane_off(int lane) const {
+        const int j = lane & 15, left = ke - 1 - g0, jc = j < left ? j : left, tt = t0 + jc;
+        const unsigned nb = seg >= 16 ? (tt >= seg ? 1u : 0u) : (unsigned)(tt / seg);
+        return off0 + (unsigned)jc * ld4 + nb * wrap4;
+    }
+    __device__ __forceinline__ void advance() {       // to the same rows of the next k-tile
+        if (g0 + BK < ke) {
+            g0 += BK; t0 += BK; off0 += BK * ld4;
+            while (t0 >= seg) { t0 -= seg; off0 += wrap4; }
+        }
+    }
+};
+__device__ __forceinline__ unsigned lane_bcast(unsigned v, int j) {
+#ifdef VAME_EMU
+    return __shfl(v, j);
+#else
+    return (unsigned)__builtin_amdgcn_readlane((int)v, j);
+#endif
+}
+
+struct TileRegs { f32x2 r[16]; };          // a producer lane's share of one k-tile: 16 rows x 2 adjacent columns
+
+// rows gt .. gt+15 of the operand (gt = the true first row: rows >= ke read as zero), then the cursor moves on to the next k-tile.
+// voff: the lane's column offset in bytes, poisoned (out of the buffer range: reads 0) for columns outside the matrix.
+__device__ __forceinline__ void prod_load(TileRegs& R, RowCursor& c, BufRange rng, unsigned voff, int lane, int gt) {
+    const unsigned lo = c.lane_off(lane);
+#pragma unroll
+    for (int j = 0; j < 16; ++j) R.r[j] = buf_load_f32x2(rng, voff, lane_bcast(lo, j));
+    c.advance();
+    if (gt + 16 > c.ke) {                   // the slab's last, partial k-tile (wave-uniform, once per workgroup at most)
+#pragma unroll
+        for (int j = 0; j < 16; ++j)
+            if (gt + j >= c.ke) R.r[j] = f32x2{0.f, 0.f};
+    }
+}
+
+__device__ __forceinline__ f32x2 hi16_of(f32x2 v) { return f32x2{ufloat(fbits(v[0]) & HI16), ufloat(fbits(v[1]) & HI16)}; }
+
+// split the 32 values into their three bf16 planes and store them as MFMA operands: dst = this wave's first octet region of the image
+__device__ __forceinline__ void prod_split(const TileRegs& R, char* dst, int slot_e, int slot_o, bool nostore = false) {
+#pragma unroll
+    for (int oc = 0; oc < 2; ++oc) {
+        u32x4 p1[2], p2[2], p3[2];
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            const f32x2 a = R.r[8 * oc + 2 * d], b = R.r[8 * oc + 2 * d + 1];      // rows 2d, 2d+1 of the octet; [0], [1] = the lane's two columns
+            const f32x2 ra = a - hi16_of(a), rb = b - hi16_of(b);                  // exact
+            const f32x2 sa = ra - hi16_of(ra), sb = rb - hi16_of(rb);              // exact, <= 8 significant bits
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                p1[e][d] = pack_hi16(a[e], b[e]);
+                p2[e][d] = pack_hi16(ra[e], rb[e]);
+                p3[e][d] = pack_hi16(sa[e], sb[e]);
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            char* q = dst + (e ? slot_o : slot_e) + oc * REGION;
+#if defined(VAME_TUNING_BUILD) && !defined(VAME_EMU)
+            if (nostore) { asm volatile("" ::"v"(p1[e]), "v"(p2[e]), "v"(p3[e])); continue; }
+#endif
+            *reinterpret_cast<u32x4*>(q) = p1[e];
+            *reinterpret_cast<u32x4*>(q + PLANE) = p2[e];
+            *reinterpret_cast<u32x4*>(q + 2 * PLANE) = p3[e];
+        }
+    }
+}
+
+struct Frags { u32x4 a[3][2], b[3][2]; };   // [plane][MFMA tile] operands of one K = 16 step
+
+__device__ __forceinline__ void cons_read(Frags& f, const char* img, int step, const int (&oa)[2], const int (&ob)[2]) {
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            f.a[pl][i] = *reinterpret_cast<const u32x4*>(img + pl * PLANE + 2 * step * REGION + oa[i]);
+            f.b[pl][i] = *reinterpret_cast<const u32x4*>(img + pl * PLANE + 2 * step * REGION + ob[i]);
+        }
+}
+
+// the six plane products of one K = 16 step on the wave's 2 x 2 tiles; consecutive MFMAs go to different accumulators
+template <int NACC>
+__device__ __forceinline__ void cons_mfma(const Frags& f, f32x16 (&acc)[NACC][2][2]) {
+    constexpr int LO = NACC - 1;
+    constexpr int PA[6] = {0, 0, 2, 1, 0, 1}, PB[6] = {0, 2, 0, 1, 1, 0};      // (1,1) | (1,3) (3,1) (2,2) (1,2) (2,1)
+#pragma unroll
+    for (int q = 0; q < 6; ++q)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                f32x16& c = acc[q == 0 ? 0 : LO][i][j];
+                c = MFMA_BF16_32x32x16(f.a[PA[q]][i], f.b[PB[q]][j], c);
+            }
+}
+}  // namespace split6
+
+#ifdef VAME_TUNING_BUILD      // timing-only ablations (tools/split_abl.py; results are garbage): opt bits 8.. = 1 no fragment reads / MFMAs, 2 fragment
+#define SPLIT_ABL_MASK 0x3f00      // reads but no MFMAs, 4 no split / LDS stores, 8 no global loads, 16 split but no LDS stores, 32 the loads as dwordx4
+#define SPLIT_ABL(opt) (((opt) & SPLIT_ABL_MASK) >> 8)
+#define SPLIT_VARIANT_MASK 0x8c   // bits 2, 3, 7: the other mappings (tools/gemm_split_variants.inc)
+#else
+#define SPLIT_ABL_MASK 0
+#define SPLIT_ABL(opt) 0
+#define SPLIT_VARIANT_MASK 0
+#endif
+// opt: see vame_gemm_group_bf16x6_f32.  OCC = workgroups per CU the register budget is set for (3 with one accumulator set, 2 with two).
+template <int NACC, int OCC>
+__global__ __launch_bounds__(256, OCC) void gemm_split_kernel(GemmParams p, int opt) {
+    using namespace split6;
+    __shared__ __attribute__((aligned(16))) char smem[BUF];
+    int tm_, tn_, z, g;
+    if (!map_tile(p, tm_, tn_, z, g)) return;
+    GemmOperand opA = p.A, opB = p.B;
+    float* ws = p.ws;
+    if (p.group > 1) { opA.p = p.gA[g]; opB.p = p.gB[g]; ws += (int64_t)g * p.splitk * p.M * p.N; }
+    const int tid = threadIdx.x, lane = tid & 63, wv = uniform(tid >> 6);
+    const int m0 = tm_ * TILE, n0 = tn_ * TILE;
+    const int kb = z * p.kper, ke = (kb + p.kper < p.K) ? kb + p.kper : p.K;
+    const int nt = (ke - kb + BK - 1) / BK;
+    // producer role
+    const int op = wv >> 1, h = wv & 1;
+    const GemmOperand& o = op ? opB : opA;
+    const int x0 = op ? n0 : m0, X = op ? p.N : p.M;
+    const int x = x0 + 2 * lane;
+    const unsigned voff = x < X ? (unsigned)(x + (x >= o.gap_at ? o.gap : 0)) * 4u : 0xC0000000u;
+    const BufRange rng = buf_range(o.p + op_row(o, kb), (uint64_t)(op_row(o, ke - 1) - op_row(o, kb) + o.ld) * 4);
+    RowCursor c;
+    c.init(o, kb, kb + 16 * h, ke);
+    int gt = kb + 16 * h;
+    char* dst = smem + (op * 4 + 2 * h) * REGION;
+    const int se = lane * 16, so = 1024 + ((lane ^ 8) * 16);
+    // consumer role
+    const int li = lane & 31, hh = lane >> 5, wm = wv >> 1, wn = wv & 1;
+    int oa[2], ob[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        oa[i] = hh * REGION + xslot(wm * 64 + i * 32 + li);
+        ob[i] = (4 + hh) * REGION + xslot(wn * 64 + i * 32 + li);
+    }
+    f32x16 acc[NACC][2][2];
+#pragma unroll
+    for (int a = 0; a < NACC; ++a)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[a][i][j][r] = 0.f;
+    TileRegs R;
+    const int abl = SPLIT_ABL(opt);
+    auto LD = [&]() {
+#if defined(VAME_TUNING_BUILD) && !defined(VAME_EMU)
+        if (abl & 32) {      // load-rate experiment: the same bytes as 8 x dwordx4 (garbage layout)
+            const unsigned lo = c.lane_off(lane), v4 = (unsigned)((x0 + 4 * (lane & 31)) * 4);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float4 q = buf_load_f32x4(rng, v4, lane_bcast(lo, 2 * j) + (lane >> 5) * c.ld4);
+                R.r[2 * j] = f32x2{q.x, q.y}; R.r[2 * j + 1] = f32x2{q.z, q.w};
+            }
+            c.advance();
+            gt += BK;
+            return;
+        }
+#endif
+        if (!(abl & 8)) prod_load(R, c, rng, voff, lane, gt);
+        gt += BK;
+    };
+    LD();
+    for (int it = 0; it < nt; ++it) {
+        if (!(abl & 4)) prod_split(R, dst, se, so, (abl & 16) != 0);
+        LD();                                           // tile it+1 (behind the slab's end: its last rows again, never used)
+        LDS_BARRIER();
+        if (!(abl & 1)) {
+            Frags f;
+            cons_read(f, smem, 0, oa, ob);
+            if (!(abl & 2)) cons_mfma<NACC>(f, acc);
+#if defined(VAME_TUNING_BUILD) && !defined(VAME_EMU)
+            else asm volatile("" ::"v"(f.a[0][0]), "v"(f.b[2][1]), "v"(f.a[2][1]), "v"(f.b[0][0]));
+#endif
+            cons_read(f, smem, 1, oa, ob);
+            if (!(abl & 2)) cons_mfma<NACC>(f, acc);
+#if defined(VAME_TUNING_BUILD) && !defined(VAME_EMU)
+            else asm volatile("" ::"v"(f.a[0][0]), "v"(f.b[2][1]), "v"(f.a[2][1]), "v"(f.b[0][0]));
+#endif
+        }
+        LDS_BARRIER();
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int col = n0 + wn * 64 + j * 32 + li;
+            if (col >= p.N) continue;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wm * 64 + i * 32 + frag_row(r, lane);
+                if (row >= p.M) continue;
+                float v = acc[0][i][j][r];
+                if (NACC > 1) v += acc[NACC - 1][i][j][r];
+                ws[((int64_t)z * p.M + row) * p.N + col] = v;
+            }
+        }
+}
+
+#ifdef VAME_TUNING_BUILD
+#include "../../tools/gemm_split_variants.inc"
+#endif
+
+// vame_gemm_group_f32's contract for two k-major operands, evaluated by gemm_split_kernel.  opt: bits 0-1 = accumulators per output (0 = default:
+// 2 -- the leading plane product on its own, two workgroups per CU; 1 = one accumulator for all six products, three workgroups per CU).
+// (Tuning build only: bits 2 / 3 / 7 = the mappings of tools/gemm_split_variants.inc, bits 8-13 = timing ablations.)
+extern "C" int vame_gemm_group_bf16x6_f32(int count, int M, int N, int K, const float* const* A, int64_t lda, int64_t a_seg, int64_t a_seg_stride,
+                                          const float* const* B, int64_t ldb, int64_t b_seg, int64_t b_seg_stride, float* const* C, int64_t ldc,
+                                          int accumulate, int splitk, float* ws, int a_gap_at, int a_gap, int opt, void* stream) {
+    VAME_CHECK_ARG(count >= 1 && count <= 8 && A && B && C && ws, VAME_E_BADARG, "gemm_group_bf16x6: count=%d (1..8) / null table", count);
+    VAME_CHECK_ARG(M >= 2 && N >= 2 && K >= 1 && M % 2 == 0 && N % 2 == 0, VAME_E_SHAPE, "gemm_group_bf16x6: M=%d N=%d K=%d (M, N even)", M, N, K);
+    VAME_CHECK_ARG(lda % 2 == 0 && ldb % 2 == 0 && a_seg_stride % 2 == 0 && b_seg_stride % 2 == 0 && a_gap % 2 == 0 && a_gap_at % 2 == 0 &&
+                   a_seg >= 0 && b_seg >= 0 && a_seg < (1ll << 31) && b_seg < (1ll << 31),
+                   VAME_E_BADARG, "gemm_group_bf16x6: row pitches, segment strides and the column gap must be even (8-byte operand loads)");
+    const int nacc = (opt & 3) == 0 ? 2 : (opt & 3);
+    VAME_CHECK_ARG((nacc == 1 || nacc == 2) && (opt & ~(3 | SPLIT_VARIANT_MASK | SPLIT_ABL_MASK)) == 0, VAME_E_BADARG, "gemm_group_bf16x6: opt=%d", opt);
+    GemmParams p;
+    for (int g = 0; g < count; ++g) {
+        VAME_CHECK_ARG(A[g] && B[g] && C[g], VAME_E_BADARG, "gemm_group_bf16x6: problem %d has a null operand", g);
+        VAME_CHECK_ARG((uintptr_t)A[g] % 8 == 0 && (uintptr_t)B[g] % 8 == 0, VAME_E_BADARG, "gemm_group_bf16x6: operands must be 8-byte aligned");
+        p.gA[g] = A[g]; p.gB[g] = B[g];
+    }
+    for (int g = count; g < 8; ++g) { p.gA[g] = A[0]; p.gB[g] = B[0]; }
+    p.A = {A[0], lda, a_seg, a_seg_stride, 1, a_gap ? a_gap_at : 0x7fffffff, a_gap};
+    p.B = {B[0], ldb, b_seg, b_seg_stride, 1, 0x7fffffff, 0};
+    p.bias = nullptr; p.C = C[0]; p.ldc = ldc; p.ws = ws;
+    p.M = M; p.N = N; p.K = K; p.accumulate = accumulate; p.group = count;
+    p.kper = (int)(cdiv64(cdiv64(K, splitk), 32) * 32);
+    p.splitk = (int)cdiv64(K, p.kper);
+    VAME_CHECK_ARG(p.splitk >= 8, VAME_E_SHAPE, "gemm_group_bf16x6: split-K %d < 8 (grouping is for large-K contractions)", p.splitk);
+    for (const GemmOperand* o : {&p.A, &p.B}) {      // a slab's rows are addressed with 32-bit byte offsets from its first row, lanes outside the matrix at 3 GiB
+        const int64_t wrap = o->seg ? o->seg_stride - o->seg * o->ld : 0, rows = p.kper + 64;
+        VAME_CHECK_ARG(o->ld > 0 && wrap >= 0 && (rows * o->ld + (o->seg ? rows / o->seg + 2 : 0) * wrap) * 4 < (1ll << 30), VAME_E_UNSUPPORTED,
+                       "gemm_group_bf16x6: a k-slab must span < 1 GiB with non-negative strides (raise splitk)");
+    }
+    p.tiles_m = (int)cdiv64(M, split6::TILE); p.tiles_n = (int)cdiv64(N, split6::TILE);
+    p.by_z = 1; p.cvec = 0; p.wsvec = 0;
+    const int64_t per_unit = (int64_t)p.tiles_m * p.tiles_n, nunits = (int64_t)p.splitk * p.group;
+    dim3 grid((unsigned)(cdiv64(nunits, 8) * per_unit * 8)), block(256);
+    hipStream_t st = (hipStream_t)stream;
+#ifdef VAME_TUNING_BUILD
+    if (opt & SPLIT_VARIANT_MASK) {
+        if (opt & 4) hipLaunchKernelGGL(gemm_split12_kernel, grid, dim3(768), 0, st, p, opt);
+        else if (opt & 128) {
+            p.tiles_m = (int)cdiv64(M, 2 * split6::TILE);
+            grid = dim3((unsigned)(cdiv64(nunits, 8) * p.tiles_m * p.tiles_n * 8));
+            if (nacc == 2) hipLaunchKernelGGL(gemm_split_wide_kernel<2>, grid, dim3(512), 0, st, p, opt);
+            else hipLaunchKernelGGL(gemm_split_wide_kernel<1>, grid, dim3(512), 0, st, p, opt);
+        } else if (nacc == 2) hipLaunchKernelGGL(gemm_split8_kernel<2>, grid, dim3(512), 0, st, p, opt);
+        else hipLaunchKernelGGL(gemm_split8_kernel<1>, grid, dim3(512), 0, st, p, opt);
+    } else
+#endif
+    if (nacc == 2) hipLaunchKernelGGL((gemm_split_kernel<2, 2>), grid, block, 0, st, p, opt);
+    else hipLaunchKernelGGL((gemm_split_kernel<1, 3>), grid, block, 0, st, p, opt);
+    VAME_LAUNCH_CHECK("gemm_group_bf16x6");
+    GemmGroupOut out;
+    bool one_c = count > 1;
+    for (int g = 0; g < 8; ++g) { out.C[g] = C[g < count ? g : 0]; one_c = one_c && out.C[g] == C[0]; }
+    const int64_t n = (int64_t)M * N;
+    if (one_c) {
+        const int slabs = count * p.splitk;
+        if (reduce_spread(n, slabs))
+            hipLaunchKernelGGL(splitk_reduce_kernel<true>, dim3(reduce_blocks(n, true)), dim3(256), 0, st, (const float*)ws, slabs, M, N,
+                               (const float*)nullptr, C[0], ldc, accumulate);
+        else
+            hipLaunchKernelGGL(splitk_reduce_kernel<false>, dim3(reduce_blocks(n, false)), dim3(256), 0, st, (const float*)ws, slabs, M, N,
+                               (const float*)nullptr, C[0], ldc, accumulate);
+    } else if (reduce_spread(n, p.splitk)) {
+        hipLaunchKernelGGL(splitk_reduce_group_kernel<true>, dim3(reduce_blocks(n, true), count), dim3(256), 0, st, (const float*)ws, p.splitk, M, N,
+                           out, ldc, accumulate);
+    } else {
+        hipLaunchKernelGGL(splitk_reduce_group_kernel<false>, dim3(reduce_blocks(n, false), count), dim3(256), 0, st, (const float*)ws, p.splitk, M, N,
+                           out, ldc, accumulate);
+    }
+    VAME_LAUNCH_CHECK("gemm_group_bf16x6 reduce");
+    return VAME_OK;
+}

@@ -24,6 +24,8 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 #define RING_WAIT4(n, a, b, c, d)
 #define VAME_EXPF(x) expf(x)
 #define VAME_RCP(x) (1.0f / (x))
+typedef u32x4_emu u32x4;
+#define MFMA_BF16_32x32x16(a, b, c) emu_mfma_32x32x16_bf16((a), (b), (c))
 #else
 #include <hip/hip_runtime.h>
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -68,6 +70,12 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));      /* pairs for the p
 #define RING_WAIT4(n, a, b, c, d) asm volatile("s_waitcnt vmcnt(%4)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "n"(n))
 #define VAME_EXPF(x) __expf(x)
 #define VAME_RCP(x) __builtin_amdgcn_rcpf(x)   /* v_rcp_f32, 1 ulp */
+// bf16-input matrix FMA (fp32 accumulate, 16x the f32-input rate): a lane supplies 8 bf16 = four dwords of A row / B column (lane & 31),
+// k = 8 * (lane >> 5) .. + 7; used by the error-compensated split contraction of gemm.hip only
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 vame_bf16x8 __attribute__((ext_vector_type(8)));
+#define MFMA_BF16_32x32x16(a, b, c) \
+    __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(vame_bf16x8, (a)), __builtin_bit_cast(vame_bf16x8, (b)), (c), 0, 0, 0)
 #endif
 #include <stdint.h>
 
@@ -91,6 +99,10 @@ static inline float4 buf_load_f32x4(BufRange r, uint32_t voff, uint32_t soff) {
     const uint64_t o = (uint64_t)voff + soff;
     return o + 16 <= r.bytes ? *reinterpret_cast<const float4*>(r.base + o) : float4{0.f, 0.f, 0.f, 0.f};
 }
+static inline f32x2 buf_load_f32x2(BufRange r, uint32_t voff, uint32_t soff) {
+    const uint64_t o = (uint64_t)voff + soff;
+    return o + 8 <= r.bytes ? *reinterpret_cast<const f32x2*>(r.base + o) : f32x2{0.f, 0.f};
+}
 static inline void buf_store_f32(BufRange r, uint32_t voff, uint32_t soff, float v) {
     const uint64_t o = (uint64_t)voff + soff;
     if (o + 4 <= r.bytes) *reinterpret_cast<float*>(const_cast<char*>(r.base) + o) = v;
@@ -111,6 +123,9 @@ __device__ __forceinline__ float buf_load_f32(BufRange r, uint32_t voff, uint32_
 }
 __device__ __forceinline__ float4 buf_load_f32x4(BufRange r, uint32_t voff, uint32_t soff) {
     return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 0));
+}
+__device__ __forceinline__ f32x2 buf_load_f32x2(BufRange r, uint32_t voff, uint32_t soff) {
+    return __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(r, (int)voff, (int)soff, 0));
 }
 __device__ __forceinline__ void buf_store_f32(BufRange r, uint32_t voff, uint32_t soff, float v) {
     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, (int)voff, (int)soff, 0);

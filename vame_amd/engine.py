@@ -14,7 +14,6 @@ All buffers are fp32 and live in a per-batch-size workspace (no allocation insid
 Sequences are stored as (B, T+2, 2H): slot 0 / T+1 hold the initial state of the forward /
 reverse direction so h_{t-1} is a plain strided view for the BPTT kernels and the dW_hh GEMMs.
 """
-import os
 from dataclasses import dataclass
 from types import SimpleNamespace
 
@@ -107,9 +106,36 @@ class Workspace:
         return t
 
 
+# Scheduling / kernel-choice options of an engine: CONSTRUCTOR ARGUMENTS (VAEEngine(..., options={...}); RNN_VAE(...).engine_options;
+# the optional `vame_amd_engine:` mapping of config.yaml, vame_amd/model/rnn_vae.py) -- never the process environment.  The defaults are
+# the measured best; the A/B tools translate their VAME_AMD_* variables with tools/engine_env.py.
+ENGINE_DEFAULTS = dict(
+    group_wgrads=True,     # same-shape weight-gradient contractions leave as grouped launches (_group_wgrads)
+    fuse_heads=False,      # output Linear + MSE + their backward per decoder in ONE kernel (vame_head_fused_f32): measured 159 us against
+                           # 149 us for the three launches it replaces at batch 4096 (tools/head_bench.py) and +-0 on the whole step
+    small_streams=3,       # HIP streams for the independent small GEMMs before the decoders' launch
+    wgrad_streams=0,       # 0 = auto: 4 streams up to batch 1024, ONE above (two give +1.5 % at batch 4096, but two large GEMMs sharing the
+                           # chip each take twice as long, which makes per-kernel durations unreadable); 1 = caller's stream only
+    coop=True,             # column-split GRU kernels for batches that leave most CUs idle (_coop_parts); False keeps the persistent ones
+    wide=True,             # 256 < H <= 512: persistent two-blocks-per-wave kernels (gru_wide.hip) instead of the per-step GEMM path
+    wide_bwd=True,         # ... for BPTT too (False: step by step: per-step GEMM + gate kernel)
+    nuc_side=True,         # nuclear-norm solve on a side stream next to the output heads
+    bwd_overlap=True,      # the future decoder's two dW_hh contractions beside the small-kernel chain behind the decoders' BPTT launch
+    skinny_side=True,      # narrow weight gradients (an output dimension <= 32) on a side stream beside the wide ones
+    split_wgrad=None,      # None = the f32-input matrix cores (default).  An int = the `opt` word of vame_gemm_group_bf16x6_f32 (0 = its
+                           # defaults): the large grouped weight gradients (two k-major operands, N > 64, K >= 8192) run as the
+                           # error-compensated split-bf16 contraction (bf16x6 planes, fp32 accumulate).  OPT-IN.
+)
+
+
 class VAEEngine:
-    def __init__(self, spec: Spec, table: ParamTable, flat_p: torch.Tensor, flat_g: torch.Tensor):
+    def __init__(self, spec: Spec, table: ParamTable, flat_p: torch.Tensor, flat_g: torch.Tensor, options=None):
         self.spec, self.table, self.p, self.g = spec, table, flat_p, flat_g
+        opt = dict(ENGINE_DEFAULTS)
+        unknown = set(options or ()) - set(opt)
+        if unknown:
+            raise ValueError(f"unknown engine option(s) {sorted(unknown)}; known: {sorted(opt)}")
+        opt.update(options or {})
         self.dev = flat_p.device
         H, F, Z, Hd, Hf = spec.H, spec.F, spec.Z, spec.Hd, spec.Hf
         for hh in (H, Hd, Hf):
@@ -135,23 +161,17 @@ class VAEEngine:
                      GruDir("decoder_future.rnn_pred", "_l0_reverse", Hf, Z, self.dev)] if spec.future else [])
         self.ws = Workspace()
         self._wgrad_queue = None
-        self.group_wgrads = os.environ.get("VAME_AMD_GROUP_WGRADS", "1") != "0"
-        # training step: output Linear + MSE + their backward per decoder in ONE kernel (vame_head_fused_f32).  Off by default: measured
-        # 159 us against 149 us for the three launches it replaces at batch 4096 (tools/head_bench.py; both stream their 2 x 252 MB at
-        # 3.3-4 TB/s) and +-0 on the whole step; the parity tests run it both ways.
-        self.fuse_heads = os.environ.get("VAME_AMD_FUSE_HEADS", "0") != "0"
+        self.group_wgrads = bool(opt["group_wgrads"])
+        self.fuse_heads = bool(opt["fuse_heads"])          # (the parity tests run the step both ways)
         self._heads_deferred = False
         self._B_bwd = None
         self._side_streams = []
-        self.small_streams = int(os.environ.get("VAME_AMD_SMALL_STREAMS", "3"))   # independent small GEMMs before the decoder launch
-        # 0 = auto: 4 streams up to batch 1024, ONE above (two streams give +1.5 % at batch 4096, but two large GEMMs sharing the
-        # chip each take twice as long, which makes per-kernel durations -- bench.py's roofline block, rocprofv3 --stats --
-        # unreadable; set 2 to take that 1.5 %); 1 = caller's stream only
-        self.wgrad_streams = int(os.environ.get("VAME_AMD_WGRAD_STREAMS", "0"))
-        # column-split GRU kernels for batches that leave most CUs idle (see _coop_parts); VAME_AMD_COOP=0 keeps the persistent ones
-        self.coop = os.environ.get("VAME_AMD_COOP", "1") != "0"
-        self.wide = os.environ.get("VAME_AMD_WIDE", "1") != "0"
-        self.wide_bwd = os.environ.get("VAME_AMD_WIDE_BWD", "1") != "0"      # 0: BPTT step by step (per-step GEMM + gate kernel)
+        self.small_streams = int(opt["small_streams"])
+        self.wgrad_streams = int(opt["wgrad_streams"])
+        self.coop = bool(opt["coop"])
+        self.wide = bool(opt["wide"])
+        self.wide_bwd = bool(opt["wide_bwd"])
+        self.split_wgrad = None if opt["split_wgrad"] is None else int(opt["split_wgrad"])
         # BPTT / forward kernel choice of the persistent H <= 256 launches (ops.KERNEL_*): an argument of every launch (descriptor field),
         # AUTO = the library's measured default per hidden size; the A/B tests set these attributes
         self.gru_bwd_kernel = ops.KERNEL_AUTO
@@ -162,7 +182,7 @@ class VAEEngine:
         # when the decoders' GRU launch has finished and runs beside the HBM-bound head / MSE / dY kernels, which leave most of a
         # CU's registers and LDS free -- unlike the GRU launches, which need whole CUs (a solve beside them was measured to cost
         # as much as it saves).  Joined before dz reads Minv and before the loss terms are handed out.
-        self.nuc_side = os.environ.get("VAME_AMD_NUC_SIDE", "1") != "0"
+        self.nuc_side = bool(opt["nuc_side"])
         # Small batches: the decoders' BPTT launch is the cooperative column-split kernel, one workgroup on EVERY CU, and the solve's single
         # workgroup still holds a CU when it starts (their LDS footprints exclude each other: 153 KB + 98 KB), so one 8-member group of the
         # launch starts late.  Measured at batch 256 (tools/step_ab.py, profiles/r04_b256_overlap.txt): joining the solve in front of that
@@ -170,8 +190,8 @@ class VAEEngine:
         # serialisation, and its members' waits are bounded polls of 0.3 s against a 0.2 ms solve.  True = join (diagnostics).
         self.nuc_join_before_coop = False
         # the future decoder's two dW_hh contractions beside the small-kernel chain that follows the decoders' BPTT launch (_early_wgrads)
-        self.bwd_overlap = os.environ.get("VAME_AMD_BWD_OVERLAP", "1") != "0"
-        self.skinny_side = os.environ.get("VAME_AMD_SKINNY_SIDE", "1") != "0"
+        self.bwd_overlap = bool(opt["bwd_overlap"])
+        self.skinny_side = bool(opt["skinny_side"])
         self._wgrad_plans = {}
         self._coop_covers = {}
         self.wgrad_min_rounds = 0          # grouped weight gradients: whole rounds of 3 workgroups per CU, at least this many (0 = by K, see _group_wgrads)
@@ -199,8 +219,8 @@ class VAEEngine:
         return self.force_stepwise or H > 256
 
     def _wide(self, H):
-        """256 < H <= 512: the forward recurrence runs in the two-blocks-per-wave persistent kernel (gru_wide.hip, fragment-order
-        stash); BPTT stays step by step (per-step GEMM + gate kernel reading that stash)."""
+        """256 < H <= 512: forward recurrence and (unless wide_bwd is off) BPTT run in the two-blocks-per-wave persistent kernels of
+        gru_wide.hip (fragment-order stash); wide_bwd = False: BPTT step by step (per-step GEMM + gate kernel reading that stash)."""
         return self.wide and not self.force_stepwise and H > 256 and ops.gru_wide_supported(H)
 
     def _all_dirs(self):
@@ -270,7 +290,10 @@ class VAEEngine:
                 after_first()
                 after_first = None
             ws = self.ws.get(ws_name, len(idx) * sk * M * N, self.dev)
-            ops.gemm_group(M, N, K, [jobs[i][3] for i in idx], 1, [jobs[i][4] for i in idx], 1, self.g, c_offs, N, sk, ws, a_gap_at=gap_at, a_gap=gap)
+            As, Bs = [jobs[i][3] for i in idx], [jobs[i][4] for i in idx]
+            split = self.split_wgrad if (self.split_wgrad is not None and N > 64 and M >= 128 and K >= 8192
+                                         and ops.gemm_split_ok(M, N, K, As, Bs, sk, gap_at, gap)) else None
+            ops.gemm_group(M, N, K, As, 1, Bs, 1, self.g, c_offs, N, sk, ws, a_gap_at=gap_at, a_gap=gap, split=split)
         return [jobs[i] for i in rest_idx]
 
     def _plan_wgrads(self, jobs):

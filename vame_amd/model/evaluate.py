@@ -124,6 +124,7 @@ def eval_temporal(cfg, use_gpu, model_name, fixed, snapshot=None, suffix=None):
     model = RNN_VAE(T2, cfg['zdims'], F, cfg['prediction_decoder'], FS, cfg['hidden_size_layer_1'],
                     cfg['hidden_size_layer_2'], cfg['hidden_size_rec'], cfg['hidden_size_pred'], cfg['dropout_encoder'],
                     cfg['dropout_rec'], cfg['dropout_pred'], cfg['softplus'])
+    model.engine_options = dict(cfg.get('vame_amd_engine') or {})
     weights = snapshot or os.path.join(filepath, 'best_model', model_name + '_' + cfg['Project'] + '.pkl')
     model.load_state_dict(torch.load(weights, map_location='cpu'))
     model = model.to(dev)

@@ -225,6 +225,9 @@ class RNN_VAE(nn.Module):
         self._engine = None
         self._pad = None
         self._bucket_check = None
+        # options of the engine built on first use (vame_amd.engine.ENGINE_DEFAULTS: kernel choice / scheduling; optional, the defaults are
+        # the measured best).  train_model() fills it from the optional `vame_amd_engine:` mapping of config.yaml.  Set before the first call.
+        self.engine_options = {}
         self._register_state_dict_hook(_clone_state_dict)
 
     def _build_modules(self, ZDIMS, NUM_FEATURES, FUTURE_DECODER, FUTURE_STEPS, h1, h2, h_rec, h_pred, d_enc, d_rec, d_pred, softplus):
@@ -279,10 +282,10 @@ class RNN_VAE(nn.Module):
                 # a hidden size that is not a multiple of 32 (torch.nn.GRU takes any): the kernels run on a zero-padded image of
                 # the parameters; the model, its state_dict, the optimizer and the all-reduce keep the reference's shapes
                 self._pad = PadMap(self.spec, self._table, [(n, tuple(p.shape)) for n, p in plist], dev)
-                self._engine = VAEEngine(self._pad.spec, self._pad.table, self._pad.p, self._pad.g)
+                self._engine = VAEEngine(self._pad.spec, self._pad.table, self._pad.p, self._pad.g, options=self.engine_options)
             else:
                 self._pad = None
-                self._engine = VAEEngine(self.spec, self._table, flat_p, flat_g)
+                self._engine = VAEEngine(self.spec, self._table, flat_p, flat_g, options=self.engine_options)
         if touch or not ok:
             if self._pad is not None:
                 self._pad.push_params(self._flat_p)

@@ -327,6 +327,8 @@ def train_model(config):
     model = RNN(TEMPORAL_WINDOW, ZDIMS, NUM_FEATURES, FUTURE_DECODER, FUTURE_STEPS, cfg['hidden_size_layer_1'],
                     cfg['hidden_size_layer_2'], cfg['hidden_size_rec'], cfg['hidden_size_pred'], cfg['dropout_encoder'],
                     cfg['dropout_rec'], cfg['dropout_pred'], cfg['softplus']).to(dev)
+    # optional key, absent from the reference's config.yaml: kernel-choice / scheduling options of this build (vame_amd.engine.ENGINE_DEFAULTS)
+    model.engine_options = dict(cfg.get('vame_amd_engine') or {})
     if world > 1:
         # identical weights on every rank (same seed above), but independent draws afterwards: eps of the reparameterisation,
         # input noise and dropout masks must not repeat across the ranks' batches

@@ -75,10 +75,10 @@ def gemm(M, N, K, A, a_kmajor, B, b_kmajor, C, ldc, c_off=0, bias=None, accumula
     _lib.check(rc, "vame_gemm_f32")
 
 
-def gemm_group(M, N, K, As, a_kmajor, Bs, b_kmajor, C, c_offs, ldc, splitk, ws, accumulate=False, a_gap_at=0, a_gap=0):
+def gemm_group(M, N, K, As, a_kmajor, Bs, b_kmajor, C, c_offs, ldc, splitk, ws, accumulate=False, a_gap_at=0, a_gap=0, split=None):
     """len(As) problems of one shape / layout in one launch: C[c_offs[g] ...] (+)= op(As[g]) op(Bs[g]) (vame_gemm_group_f32).
-    As / Bs: Operands that differ only in their base (tensor + offset)."""
-    import ctypes
+    As / Bs: Operands that differ only in their base (tensor + offset).  split = an `opt` word (0 = defaults): the contraction runs
+    as the error-compensated split-bf16 form (vame_gemm_group_bf16x6_f32; both operands k-major, see gemm_split_ok)."""
     n = len(As)
     a0, b0 = As[0], Bs[0]
     assert all((o.ld, o.seg, o.seg_stride) == (a0.ld, a0.seg, a0.seg_stride) for o in As)
@@ -88,9 +88,28 @@ def gemm_group(M, N, K, As, a_kmajor, Bs, b_kmajor, C, c_offs, ldc, splitk, ws, 
     pa = arr(*[_ptr(o.t, o.off) for o in As])
     pb = arr(*[_ptr(o.t, o.off) for o in Bs])
     pc = arr(*[_ptr(C, off) for off in c_offs])
+    if split is not None:
+        assert a_kmajor and b_kmajor, "the split-bf16 contraction takes two k-major operands"
+        rc = _lib.lib().vame_gemm_group_bf16x6_f32(n, M, N, K, pa, a0.ld, a0.seg, a0.seg_stride, pb, b0.ld, b0.seg, b0.seg_stride, pc, ldc,
+                                                   int(accumulate), splitk, _ptr(ws), a_gap_at, a_gap, int(split), _stream())
+        _lib.check(rc, "vame_gemm_group_bf16x6_f32")
+        return
     rc = _lib.lib().vame_gemm_group_f32(n, M, N, K, pa, a0.ld, int(a_kmajor), a0.seg, a0.seg_stride, pb, b0.ld, int(b_kmajor), b0.seg,
                                         b0.seg_stride, pc, ldc, int(accumulate), splitk, _ptr(ws), a_gap_at, a_gap, _stream())
     _lib.check(rc, "vame_gemm_group_f32")
+
+
+def gemm_split_ok(M, N, K, As, Bs, splitk, a_gap_at=0, a_gap=0):
+    """Whether vame_gemm_group_bf16x6_f32 takes this group (its alignment rules; shapes it is worth using for are the caller's choice)."""
+    a0, b0 = As[0], Bs[0]
+    even = (M, N, a0.ld, b0.ld, a0.seg_stride, b0.seg_stride, a_gap_at, a_gap)
+    if any(v % 2 for v in even):
+        return False
+    if any(_ptr(o.t, o.off) % 8 for o in list(As) + list(Bs)):
+        return False
+    kper = -(-(-(-K // splitk)) // 32) * 32
+    span = max(a0.ld, b0.ld, (a0.seg_stride // a0.seg) if a0.seg else 0, (b0.seg_stride // b0.seg) if b0.seg else 0) * 4 * (kper + 64)
+    return -(-K // kper) >= 8 and span < (1 << 30)
 
 
 class ClockProbe:
