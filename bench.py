@@ -407,7 +407,7 @@ def release_leg(on_gpu):
         torch.cuda.empty_cache()
 
 
-def train_leg(dev, H, T, B, steps, warmup, rank, world, repeats=1, profile=True, dump=False, one_rank_leg=False, engine_options=None):
+def train_leg(dev, H, T, B, steps, warmup, rank, world, repeats=1, profile=True, dump=False, one_rank_leg=False, engine_options=None, graph=False):
     """Build the model at (H, T), run `warmup` untimed + `repeats` timed regions of `steps` steps.  Returns a dict with the region
     times, the last loss terms, the roofline block (GPU only) and -- several ranks -- the collective's own numbers."""
     from vame_amd.model.dataloader import DeviceWindowLoader
@@ -428,6 +428,14 @@ def train_leg(dev, H, T, B, steps, warmup, rank, world, repeats=1, profile=True,
         gs = allreduce_gradients(model) if reduce else 1.0
         opt.step(gscale=gs)
         return terms
+
+    if graph and on_gpu and world == 1:       # the same step as ONE replayed hipGraph (what train() does up to batch 1024: rnn_vae.GraphedTrainStep)
+        from vame_amd.model.rnn_vae import GraphedTrainStep
+        gstep = GraphedTrainStep(model, opt, loader, torch.zeros(6, device=dev, dtype=torch.float64), kl_weight=1.0, beta=1.0, kloss=Z, klmbda=0.1, bsize=B)
+        eager_step = step
+
+        def step(reduce=True):                # noqa: F811
+            return gstep(loader.draw_starts())
 
     for _ in range(warmup):
         terms = step()
@@ -604,6 +612,7 @@ def main():
                          "where nothing else is measured (the CPU test-suite's emulator harness)")
     ap.add_argument("--no-also", action="store_true", help="skip the configs[3] / configs[4] legs and the two extra timed regions")
     ap.add_argument("--batch", type=int, default=4096)
+    ap.add_argument("--graph", action="store_true", help="run the step as one replayed hipGraph (single GPU; train() does this up to batch 1024)")
     ap.add_argument("--dump-kernels", action="store_true", help="per-launch-group table on stderr")
     ap.add_argument("--mode", choices=["train", "embed"], default="train",
                     help="train = the headline metric; embed = encoder-only embedd_latent_vectors sweep (BASELINE config 5)")
@@ -643,7 +652,7 @@ def main():
         headline = (H, T, B) == (256, 30, 4096)
         extras = headline and not args.no_also
         res = train_leg(dev, H, T, B, args.steps, args.warmup, rank, world, repeats=3 if extras else 1,
-                        dump=args.dump_kernels, one_rank_leg=True)
+                        dump=args.dump_kernels, one_rank_leg=True, graph=args.graph)
         also = None
         if extras and world == 1 and on_gpu:
             # the other two single-GPU configurations of BASELINE.json under the same clock, each with its own roofline, and the batch
@@ -652,9 +661,13 @@ def main():
             c4_line = dict(metric="temporal windows/sec (train) T=60,F=24,h=512", value=round(8192 * 5 / c4["dts"][0], 1), unit="windows/s",
                            steps=5, warmup=2, ms_per_step=round(c4["dts"][0] / 5 * 1e3, 3), config=dict(workload=workload_name(512, 60, 8192, 1)),
                            roofline=c4["roofline"])
-            b256 = train_leg(dev, 256, 30, 256, 30, 10, 0, 1)
+            b256 = train_leg(dev, 256, 30, 256, 30, 10, 0, 1, graph=True)
+            b256e = train_leg(dev, 256, 30, 256, 30, 10, 0, 1, profile=False)
             b256_line = dict(metric="temporal windows/sec (train) T=30,F=24,h=256", value=round(256 * 30 / b256["dts"][0], 1), unit="windows/s",
                              steps=30, warmup=10, ms_per_step=round(b256["dts"][0] / 30 * 1e3, 3),
+                             execution="one hipGraph replay per step (rnn_vae.GraphedTrainStep: what train() does up to batch 1024)",
+                             eager=dict(value=round(256 * 30 / b256e["dts"][0], 1), ms_per_step=round(b256e["dts"][0] / 30 * 1e3, 3),
+                                        execution="the same step enqueued launch by launch"),
                              config=dict(workload=workload_name(256, 30, 256, 1)), roofline=b256["roofline"])
             emb_line = embed_leg(dev, 2_000_000, 0, 1)
             if not args.no_cpu_baseline:              # the reference's batch-1 loop as written and a batch-256 variant, beside the embedding number

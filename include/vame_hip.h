@@ -157,11 +157,18 @@ int vame_gru_cell_bwd_f32(const float* stash, int64_t st_row, float* dh, const f
 
 /* Lambda reparameterisation + KL partials (vame/model/rnn_model.py:63-76, vame/model/rnn_vae.py:53-60).
  *   mu, lv_raw (B,Z) -> logvar (softplus optional), z = eps*exp(0.5*logvar)+mu (training) or mu;
- *   kl_out[0] += sum(1 + logvar - mu^2 - exp(logvar))   (caller zeroes kl_out). */
-int vame_latent_fwd_f32(const float* mu, const float* lv_raw, const float* eps, int B, int Z, int softplus,
-                        int training, float* logvar, float* z, float* kl_out, void* stream);
-/* Backward of the above plus the KL term: dmu = dz + ckl*mu ; dlv = dz*eps*0.5*std + 0.5*ckl*(exp(lv)-1)
- * (times sigmoid(lv_raw) under softplus), ckl = beta*kl_weight/(B*Z). */
+ *   kl_out[0] += sum(1 + logvar - mu^2 - exp(logvar))   (the caller's buffer is zero before the step: vame_loss_finish_f32 leaves it so).
+ *   rng == NULL: eps (B,Z) is an INPUT (parity tests inject the reference's draw).  rng != NULL (device, 4 x uint64: {seed, step, ticket = 0,
+ *   unused}) in training mode: eps is an OUTPUT -- N(0,1) from Philox4x32-10 keyed by seed, counter = (element, step), Box-Muller -- and the
+ *   launch advances `step` by one on the device (the reference's `torch.randn_like`, rnn_model.py:71-74, with no host op and no argument
+ *   that changes between launches). */
+int vame_latent_fwd_f32(const float* mu, const float* lv_raw, float* eps, int B, int Z, int softplus,
+                        int training, float* logvar, float* z, float* kl_out, uint64_t* rng, void* stream);
+/* Loss bookkeeping of one step (vame/model/rnn_vae.py:129-150) in one launch: raw (device, 8 floats: the sums left by the loss kernels in slots
+ * 0..3 = rec, fut, KL sum, kmeans) -> out (device, 5 floats) = the four terms x scale[i] (fut = 0 unless with_fut) and their weighted total
+ * sum_i weights[i] term[i]; acc (device, 6 doubles, may be NULL): += total, rec, fut, kl, kmeans; acc[5] = this step's total.  raw is
+ * zeroed.  scale / weights: HOST arrays of 4 floats. */
+int vame_loss_finish_f32(float* raw, const float* scale, const float* weights, int with_fut, float* out, double* acc, void* stream);
 int vame_latent_bwd_f32(const float* dz, const float* mu, const float* logvar, const float* lv_raw,
                         const float* eps, int B, int Z, int softplus, float ckl, float* dmu, float* dlv, void* stream);
 
@@ -217,10 +224,13 @@ int vame_colsum_batch_f32(const int64_t* desc, int njobs, void* stream);
  * whose gradients are undefined never reaches the weights (the host raises when it next reads the word).  Any non-zero 32-bit
  * pattern aborts, so the word may also be a float that an all-reduce SUM left > 0 (the multi-rank case: one rank's failure drops
  * the step on every rank).  dropped (optional device counter) is incremented by each launch that was aborted, so the host can
- * keep its bias-correction step count equal to the number of updates actually applied. */
+ * keep its bias-correction step count equal to the number of updates actually applied.
+ * state (optional, device, 4 x int32 = {learning rate as a float, updates applied so far, 0, unused}): when given, `lr` and `step` are ignored --
+ * the launch reads both from the device, and counts itself there unless it was aborted: no argument changes from step to step (a captured
+ * hipGraph replays the launch; an LR scheduler writes state[0]). */
 int vame_adam_amsgrad_f32(float* p, const float* g, float* m, float* v, float* vmax, int64_t n, float lr,
                           float beta1, float beta2, float eps, int step, float gscale, const int* abort_flag, int* dropped,
-                          void* stream);
+                          int* state, void* stream);
 
 /* dst[dst_idx[i]] = src[src_idx[i]], i < n (element indices, no duplicates in dst_idx).  torch.nn.GRU accepts any hidden_size
  * (rnn_model.py:34,91,125) while the GRU kernels tile hidden units by 32: for other sizes the model keeps its parameters in the
@@ -243,24 +253,25 @@ int vame_axpy_f32(const float* x, float a, float* y, int64_t n, void* stream);
  * shared by H/32 workgroups that keep their slice of W_hh in LDS and hand their 32 columns of h_t to each other every step as
  * self-validating (value, tag) pairs (needs GF_Y, a precomputed gi, H = 128 or 256, and a grid that fits one workgroup per CU:
  * vame_gru_coop_supported).  GF_OPT / GB_OPT kernel: AUTO, or LOCKSTEP = 32-row groups even where 16-row groups fit.
- * flags: vame_gru_coop_flag_ints() ints (flag words + the hand-off packets), initialised ONCE by the caller to a value older than
- * the first epoch_base (zero for a fresh epoch counter) and then only passed back; epoch_base: a value that grows by at least T + 2
- * between launches sharing `flags`; *status is incremented if a bounded poll ever expires (results are then undefined, the launch
- * still terminates). */
+ * flags: flag_ints >= vame_gru_coop_flag_ints() ints (flag words + the hand-off packets; the launch checks the size), initialised ONCE by the
+ * caller to a value OLDER than the first epoch (e.g. epoch - 8: equal to no tag a launch will look for) and then only passed back.
+ * epoch: device int[2] = {launch epoch, 0}, shared by every launch that shares `flags`: a launch reads its tag base from epoch[0] and its last
+ * workgroup advances it by (steps + 2), so consecutive launches -- also replays of a captured hipGraph, whose arguments are frozen -- never see
+ * each other's words.  *status is incremented if a bounded poll ever expires (results are then undefined, the launch still terminates). */
 int64_t vame_gru_coop_flag_ints(int nstreams, int B, int H);
 int vame_gru_coop_supported(int nstreams, int B, int H);   /* grid <= CUs and the runtime's occupancy query admits each kernel */
 /* Poll budget of one hand-off wait (0 = default, about 0.3 s on the device); returns the previous value.  Process-wide;
  * for diagnostics.  polls < 0 = fault injection: every cooperative launch reports one timeout through *status although its
  * hand-offs complete (tests of the failure path: optimizer step dropped on the device, host exception). */
 int vame_gru_coop_set_poll_limit(int polls);
-int vame_gru_coop_fwd_f32(const int64_t* desc, int nstreams, int B, int H, int row0, int nrows, int* flags, int epoch_base, int* status,
-                          void* stream);   /* rows [row0, row0+nrows) of the batch, row0 % 32 == 0; nrows = 0: all rows */
+int vame_gru_coop_fwd_f32(const int64_t* desc, int nstreams, int B, int H, int row0, int nrows, int* flags, int64_t flag_ints, int* epoch,
+                          int* status, void* stream);   /* rows [row0, row0+nrows) of the batch, row0 % 32 == 0; nrows = 0: all rows */
 /* BPTT counterpart (contract of vame_gru_seq_bwd_f32; results equal up to the summation order of the K = 3H contraction, which is
  * split by member; the same bits in 32- and 16-row groups): xbuf = vame_gru_coop_xbuf_floats() floats of scratch for the per-step
  * reduce-scatter of the dh partials (and, at the end of a launch in 16-row groups, the hand-over of the upper group's bias sums). */
 int64_t vame_gru_coop_xbuf_floats(int nstreams, int B, int H);
-int vame_gru_coop_bwd_f32(const int64_t* desc, int nstreams, int B, int H, int row0, int nrows, float* xbuf, int* flags, int epoch_base,
-                          int* status, void* stream);
+int vame_gru_coop_bwd_f32(const int64_t* desc, int nstreams, int B, int H, int row0, int nrows, float* xbuf, int* flags, int64_t flag_ints,
+                          int* epoch, int* status, void* stream);
 
 /* ---- wide hidden sizes, 256 < H <= 512 (H % 64 == 0; vame_amd/csrc/gru_wide.hip): batch-tile-persistent forward with two 32-column
  * blocks per wave; descriptor table, sequence layout and fragment-order stash (NB = H/32 blocks) as vame_gru_seq_fwd_f32, no fused input

@@ -321,7 +321,7 @@ def check_gru_coop_fwd(dev, H, B, T, launches=3):
     repeated launches that reuse the flag words (epoch logic)."""
     assert ops.gru_coop_supported(2, B, H) and not ops.gru_coop_supported(2, 8192, H)
     state = ops.CoopState(torch.device(dev))
-    state.epoch = (1 << 32) - T - 3                       # the second launch crosses the 2^32 wrap of the flag epoch
+    state.epoch[0] = -T - 3                               # (= 2^32 - T - 3 as unsigned) the second launch crosses the 2^32 wrap of the flag epoch
     state.flags.fill_(-T - 4)                             # ... as left behind by a launch just before it
     x, st0, Y0, hN0 = run_gru_fwd(dev, H, B, T)
     forms = [(None, ops.KERNEL_AUTO), (None, ops.KERNEL_LOCKSTEP)]
@@ -683,6 +683,98 @@ def check_latent(dev):
         np.testing.assert_allclose(N_(dlv), ref, atol=1e-5)
 
 
+def philox4x32_10(ctr, key):
+    """numpy Philox4x32-10 (Salmon et al., Random123): ctr (n, 4) uint32, key (2,) uint32 -> (n, 4) uint32.  Test infrastructure: pinned below
+    against the published known-answer vectors, then used to pin the device draw of vame_latent_fwd_f32."""
+    c = np.array(ctr, dtype=np.uint64, copy=True)
+    k0, k1 = np.uint64(key[0]), np.uint64(key[1])
+    M0, M1, m32 = np.uint64(0xD2511F53), np.uint64(0xCD9E8D57), np.uint64(0xffffffff)
+    for _ in range(10):
+        p0, p1 = M0 * c[:, 0], M1 * c[:, 2]
+        n0 = (p1 >> np.uint64(32)) ^ c[:, 1] ^ k0
+        n2 = (p0 >> np.uint64(32)) ^ c[:, 3] ^ k1
+        c = np.stack([n0, p1 & m32, n2, p0 & m32], axis=1)
+        k0, k1 = (k0 + np.uint64(0x9E3779B9)) & m32, (k1 + np.uint64(0xBB67AE85)) & m32
+    return c.astype(np.uint32)
+
+
+def philox_normal_ref(idx, seed, step):
+    """float64 restatement of the kernel's draw: Box-Muller on words 0, 1 of Philox(counter = (idx, step), key = seed)."""
+    idx = np.asarray(idx, dtype=np.uint64)
+    ctr = np.stack([idx & np.uint64(0xffffffff), idx >> np.uint64(32), np.full_like(idx, step & 0xffffffff), np.full_like(idx, step >> 32)], axis=1)
+    r = philox4x32_10(ctr, (seed & 0xffffffff, seed >> 32)).astype(np.float64)
+    u1 = (np.floor(r[:, 0] / 256) + 0.5) / 16777216.0
+    u2 = (np.floor(r[:, 1] / 256) + 0.5) / 16777216.0
+    return np.sqrt(-2.0 * np.log(u1)) * np.cos(2.0 * np.pi * u2)
+
+
+def check_latent_draw(dev, n_rows=33334):
+    """The reparameterisation's N(0,1) draw made inside vame_latent_fwd_f32 (rng != NULL; the reference's torch.randn_like, rnn_model.py:71-74):
+    the generator against its published known-answer vectors, the kernel's values against the float64 restatement, N(0,1) moments and a
+    Kolmogorov-Smirnov test on ~1e6 samples, reproducibility per (seed, step), independence of the launch size, and the device-side
+    step counter (consecutive launches draw fresh values with identical arguments)."""
+    from scipy import stats
+    kat = philox4x32_10([[0, 0, 0, 0], [0xffffffff] * 4, [0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344]], (0, 0))[0]
+    assert [hex(v) for v in kat] == ["0x6627e8d5", "0xe169c58d", "0xbc57ac4c", "0x9b00dbd8"]
+    assert [hex(v) for v in philox4x32_10([[0xffffffff] * 4], (0xffffffff, 0xffffffff))[0]] == ["0x408f276d", "0x41c83b0e", "0xa20bc7c6", "0x6d5451fd"]
+    assert [hex(v) for v in philox4x32_10([[0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344]], (0xa4093822, 0x299f31d0))[0]] == \
+        ["0xd16cfe09", "0x94fdcceb", "0x5001e420", "0x24126ea1"]
+    Z = 30
+    seed = 0x1234567811223344
+
+    def draw(B, st, launches=1):
+        rng = torch.tensor([seed, st, 0, 0], dtype=torch.int64, device=dev)
+        mu, lv = torch.zeros(B, Z, device=dev), torch.zeros(B, Z, device=dev)
+        eps, z, lvo = torch.empty(B, Z, device=dev), torch.empty(B, Z, device=dev), torch.empty(B, Z, device=dev)
+        outs = []
+        for _ in range(launches):
+            ops.latent_fwd(mu, lv, eps, B, Z, 0, 1, lvo, z, None, rng=rng)
+            outs.append(N_(eps).copy())
+            np.testing.assert_array_equal(N_(z), outs[-1])                 # mu = 0, logvar = 0: z = eps
+        return outs, N_(rng)
+    (e0, e1), state = draw(n_rows, 5, launches=2)
+    assert list(state) == [seed, 7, 0, 0]                                   # two launches advanced the step twice, ticket back at 0
+    x = e0.ravel().astype(np.float64)
+    assert not np.array_equal(e0, e1)
+    np.testing.assert_allclose(x[:4096], philox_normal_ref(np.arange(4096), seed, 5), atol=2e-5)
+    np.testing.assert_allclose(e1.ravel()[-4096:], philox_normal_ref(np.arange(x.size - 4096, x.size), seed, 6), atol=2e-5)
+    n = x.size
+    assert abs(x.mean()) < 4.0 / np.sqrt(n) and abs(x.var() - 1.0) < 4.0 * np.sqrt(2.0 / n)
+    assert abs(stats.skew(x)) < 4.0 * np.sqrt(6.0 / n) and abs(stats.kurtosis(x)) < 4.0 * np.sqrt(24.0 / n)
+    assert stats.kstest(x, "norm").statistic < 1.95 / np.sqrt(n)                # alpha = 0.001
+    assert np.abs(x).max() < 6.0
+    # same (seed, step) -> same bits, whatever the launch size; another step / seed -> another draw
+    (r0,), _ = draw(n_rows, 5)
+    np.testing.assert_array_equal(r0, e0)
+    (small,), _ = draw(100, 5)
+    np.testing.assert_array_equal(small.ravel(), e0.ravel()[:3000])
+    assert abs(np.corrcoef(e0.ravel(), e1.ravel())[0, 1]) < 5.0 / np.sqrt(n)
+
+
+def check_loss_finish(dev):
+    """vame_loss_finish_f32: scaled terms, weighted total, float64 epoch accumulators, sums zeroed (rnn_vae.py:129-150)."""
+    raw0 = np.array([3.5e4, 1.7e4, -812.25, 2.75, 9.0, 9.0, 9.0, 9.0], np.float32)
+    scale, wts = (1.0, 0.5, -0.5 / 900, 1.0), (1.0, 1.0, 0.35, 0.7)
+    acc = torch.zeros(6, dtype=torch.float64, device=dev)
+    tot = []
+    for with_fut in (1, 0):
+        raw, out = T_(raw0, dev), torch.zeros(5, device=dev)
+        ops.loss_finish(raw, scale, wts, with_fut, out, acc)
+        t = raw0[:4] * np.array(scale, np.float32)
+        if not with_fut:
+            t[1] = 0
+        np.testing.assert_allclose(N_(out)[:4], t, rtol=1e-6)
+        np.testing.assert_allclose(N_(out)[4], float(np.dot(t.astype(np.float64), wts)), rtol=1e-6)
+        assert not N_(raw).any()
+        tot.append(N_(out).astype(np.float64))
+    a = N_(acc)
+    np.testing.assert_allclose(a[0], tot[0][4] + tot[1][4], rtol=1e-12)
+    np.testing.assert_allclose(a[1:5], tot[0][:4] + tot[1][:4], rtol=1e-12)
+    assert a[5] == tot[1][4]
+    out = torch.zeros(5, device=dev)
+    ops.loss_finish(T_(raw0, dev), scale, wts, 1, out, None)                 # no accumulator
+
+
 def check_mse(dev):
     rng = np.random.default_rng(4)
     B, TF, row = 11, 30 * 24, 45 * 24
@@ -767,12 +859,19 @@ def check_adam(dev):
     pt = torch.nn.Parameter(torch.from_numpy(p0.copy()))
     opt = torch.optim.Adam([pt], lr=5e-4, amsgrad=True)
     p, m, v, vm = T_(p0, dev), torch.zeros(n, device=dev), torch.zeros(n, device=dev), torch.zeros(n, device=dev)
+    p2, m2, v2, vm2 = T_(p0, dev), torch.zeros(n, device=dev), torch.zeros(n, device=dev), torch.zeros(n, device=dev)
+    state = torch.zeros(4, dtype=torch.int32, device=dev)
+    state.view(torch.float32)[0] = 5e-4
     for step in range(1, 4):
         g = rng.standard_normal(n).astype(np.float32) * (10.0 ** (step - 2))
         pt.grad = torch.from_numpy(g.copy())
         opt.step()
         ops.adam_amsgrad(p, T_(2 * g, dev), m, v, vm, n, 5e-4, step, gscale=0.5)
         np.testing.assert_allclose(N_(p), pt.detach().numpy(), atol=1e-6)
+        # the same update with the learning rate and the step number read from (and counted on) the device: identical arguments every step
+        ops.adam_amsgrad(p2, T_(2 * g, dev), m2, v2, vm2, n, 123.0, 0, gscale=0.5, state=state)
+        np.testing.assert_allclose(N_(p2), pt.detach().numpy(), atol=1e-6)
+        assert N_(state)[1:3].tolist() == [step, 0]
 
 
 def check_nuclear(dev, B, Z, k):

@@ -51,10 +51,14 @@ def test_error_codes_and_messages(emu):
     assert L.vame_gru_coop_supported(2, 513, 256) == 0 and L.vame_gru_coop_supported(4, 257, 256) == 0
     assert L.vame_gru_coop_supported(2, 64, 64) == 0 and L.vame_gru_coop_supported(2, 1024, 128) == 1
     flags = torch.zeros(64, dtype=torch.int32)
-    rc = L.vame_gru_coop_fwd_f32(d.data_ptr(), 2, 4096, 256, 0, 0, flags.data_ptr(), 1, flags.data_ptr(), None)
+    epoch = torch.tensor([1, 0], dtype=torch.int32)
+    rc = L.vame_gru_coop_fwd_f32(d.data_ptr(), 2, 4096, 256, 0, 0, flags.data_ptr(), 64, epoch.data_ptr(), flags.data_ptr(), None)
     assert rc == -4 and b"one workgroup per CU" in L.vame_last_error()
-    rc = L.vame_gru_coop_fwd_f32(d.data_ptr(), 1, 64, 256, 16, 32, flags.data_ptr(), 1, flags.data_ptr(), None)
+    rc = L.vame_gru_coop_fwd_f32(d.data_ptr(), 1, 64, 256, 16, 32, flags.data_ptr(), 64, epoch.data_ptr(), flags.data_ptr(), None)
     assert rc == -2 and b"row range" in L.vame_last_error()
+    # the launch checks the caller's flag / hand-off buffer against what it will write (a C caller sizing it the old way: refused, not overrun)
+    rc = L.vame_gru_coop_fwd_f32(d.data_ptr(), 1, 64, 256, 0, 0, flags.data_ptr(), 64, epoch.data_ptr(), flags.data_ptr(), None)
+    assert rc == -2 and b"flags holds 64 ints" in L.vame_last_error()
     # training-set preparation: shape checks
     xd = torch.zeros(16, dtype=torch.float64)
     rc = L.vame_prep_savgol_f64(xd.data_ptr(), 1, 3, 3, xd.data_ptr(), 5, xd.data_ptr() + 64, 3, None)

@@ -297,3 +297,19 @@ def test_train_and_segment_drivers_two_ranks(emu, tmp_path):
     ref = vo.embed_series(p, np.load(root / "data" / "vid1" / "vid1-PE-seq-clean.npy"),
                           vo.Spec(T=30, F=24, Z=30, H=cfg["hidden_size_layer_1"], FS=15), batch=64)
     np.testing.assert_allclose(lat, ref, atol=2e-5)                                         # shards of two ranks, gathered, in order
+
+
+def test_scale_sweep_script_two_ranks(emu):
+    """tools/scale_sweep.sh (one call = the 1 / 2 / ... rank train lines + the sharded embedding line: what the first visit to an 8-GPU node runs,
+    SURVEY 8(e)) on the 2-rank gloo harness with a tiny model: three JSON lines, the rank counts and the whole-job window count as asked."""
+    import json
+    import subprocess
+    env = dict(os.environ, VAME_SCALE_PYTHON=f"{sys.executable} {os.path.join(ROOT, 'tests', 'emu', 'harness.py')}", VAME_SCALE_VISIBLE="2",
+               VAME_SCALE_EMBED_ARGS="--hidden 32 --time-window 4")
+    env = {k: v for k, v in env.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run(["bash", os.path.join(ROOT, "tools", "scale_sweep.sh"), "8", "300", "--"] + BENCH_TINY[2:],
+                       capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    lines = [json.loads(ln) for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert r.returncode == 0 and len(lines) == 3, (r.stdout[-800:], r.stderr[-800:])
+    assert [ln["n_gpus"] for ln in lines] == [1, 2, 2] and "error" not in "".join(r.stdout.splitlines())
+    assert lines[1]["distributed"]["world_size"] == 2 and lines[2]["windows"] == 600 and lines[2]["config"]["parallelism"] == "shard2"

@@ -2,7 +2,7 @@
 import pytest
 
 from kernel_cases import (check_head_fused, check_gemm_group_shared_output, check_gru_wide, check_gru_wide_small, check_hmm, check_adam, check_adam_abort_and_mask_scale, check_colsum, check_colsum_batch, check_kmeans, check_gather, check_gemm_cases, check_gemm_group, check_gemm_split, check_gru_bwd, check_gru_skew_fwd, check_gru_wide_skew_fwd, check_gru_fwd_ring_stress, check_gru_ws_bwd, check_gru_kernel_option_is_an_argument, check_gru_coop_bwd, check_gru_coop_fwd, check_gru_fwd, check_gru_fwd_fused,
-                          check_latent, check_mse, check_nuclear, check_prep_fill_rules, check_prepare_series_golden,
+                          check_latent, check_latent_draw, check_loss_finish, check_mse, check_nuclear, check_prep_fill_rules, check_prepare_series_golden,
                           check_prepare_series_vs_oracle)
 
 pytestmark = pytest.mark.gpu
@@ -46,6 +46,12 @@ def test_gru_wide_skewed_fwd(hip, H, B, T, force):
 
 def test_gru_kernel_option_is_a_launch_argument(hip):
     check_gru_kernel_option_is_an_argument(DEV)
+
+
+def test_reparameterisation_draw_and_loss_bookkeeping_kernels(hip):
+    """round 5: eps drawn inside the latent kernel (Philox4x32-10, device-side step counter) and the step's loss bookkeeping in one launch"""
+    check_latent_draw(DEV)
+    check_loss_finish(DEV)
 
 
 def test_elementwise(hip):

@@ -112,3 +112,45 @@ def test_headline_hidden_size_takes_the_grouped_dz_path(emu):
 
 def test_fused_output_heads_match_the_default_path(emu):
     check_fused_heads_match("cpu")
+
+
+def test_round4_advisor_findings(emu, monkeypatch):
+    """(1) a Parameter OBJECT replaced after the engine was built (module surgery) is noticed -- the old object still points into the flat
+    bucket, so comparing addresses alone kept the stale weights; (2) the epoch-end error check enters its all-reduce on every rank, also on one
+    that made no cooperative launch; (4) malformed GRU option words are refused on both sides of the C ABI."""
+    import numpy as np
+    import torch
+    from vame_amd import _lib, ops
+    from vame_amd.model.rnn_model import RNN_VAE
+    torch.manual_seed(3)
+    model = RNN_VAE(8, 5, 6, 1, 2, 32, 32, 32, 32, 0, 0, 0, False).eval()
+    x = torch.randn(3, 4, 6)
+    base = model(x)[0].clone()
+    eng0, bucket0 = model._engine, model._flat_p
+    w_old = model.decoder.hidden_to_output.weight
+    model.decoder.hidden_to_output.weight = torch.nn.Parameter(torch.zeros_like(w_old))          # a NEW object; the old one still aliases the bucket
+    out = model(x)[0]
+    assert model._flat_p is not bucket0 and model._engine is not eng0, "the flat bucket was not rebuilt over the live parameters"
+    bias = model.decoder.hidden_to_output.bias.detach()
+    np.testing.assert_allclose(out.numpy(), np.broadcast_to(bias.numpy(), out.shape), atol=1e-6)   # zero weight: the output is the bias
+    assert not np.allclose(out.numpy(), base.numpy())
+    # (2)
+    eng = model._engine
+    assert eng._coop_state is None
+    calls = []
+    monkeypatch.setattr(eng, "_multi_rank", lambda: True)
+    monkeypatch.setattr(torch.distributed, "all_reduce", lambda t, op=None: calls.append(int(t.item())))
+    eng.check_async_errors(all_ranks=True)
+    assert calls == [0]
+    monkeypatch.setattr(torch.distributed, "all_reduce", lambda t, op=None: t.fill_(1))              # another rank reports a timeout
+    with pytest.raises(_lib.VameHipError):
+        eng.check_async_errors(all_ranks=True)
+    eng.check_async_errors()                                                                        # rank-local: nothing to do, no collective
+    # (4)
+    with pytest.raises(ValueError):
+        ops.gru_opt(ops.KERNEL_WS, pace_cp=255)
+    with pytest.raises(ValueError):
+        ops.gru_opt(16)
+    d = torch.zeros(ops.GF["N"], dtype=torch.int64)
+    d[ops.GF["OPT"]] = 1 << 24
+    assert _lib.lib().vame_gru_seq_fwd_f32(d.data_ptr(), 1, 4, 32, None) == -1 and b"malformed option word" in _lib.lib().vame_last_error()

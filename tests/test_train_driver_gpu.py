@@ -61,3 +61,54 @@ def test_read_config_contract(tmp_path, hip):
 def test_parameterization_with_gpu_kmeans_option(hip):
     dc.check_parameterization_with_gpu_kmeans_option()
 
+
+
+def test_graphed_step_is_bit_identical_to_eager(hip):
+    """round 5: the stock-batch train step (gather -> loss_step -> fused Adam) captured once as a hipGraph and replayed (rnn_vae.GraphedTrainStep)
+    against the same ten steps enqueued launch by launch: the weights after every step, the Adam state and the device-side counters (Philox
+    step, Adam step, cooperative launch epoch) are the same bits; the loss terms agree to the rounding of their atomic sums."""
+    import numpy as np
+    import torch
+    from vame_amd.model.dataloader import DeviceWindowLoader
+    from vame_amd.model.rnn_model import RNN_VAE
+    from vame_amd.model.rnn_vae import FusedAdamAMSGrad, GraphedTrainStep
+    T, F, Z, H, FS, B, N = 30, 12, 30, 256, 15, 256, 40000
+
+    class DS:
+        data_points, X, temporal_window = N, np.empty((F, 1)), 2 * T
+
+        @staticmethod
+        def normalised_f32():
+            return np.random.default_rng(5).standard_normal((F, N)).astype(np.float32)
+    dev = torch.device("cuda", 0)
+    kw = dict(kl_weight=0.5, beta=1.0, kloss=Z, klmbda=0.1, bsize=B, weights=(1.0, 1.0, 0.5, 0.5))
+    starts = np.random.default_rng(6).integers(0, N - 2 * T, size=(10, B))
+    runs = []
+    for graphed in (False, True):
+        torch.manual_seed(19)
+        model = RNN_VAE(2 * T, Z, F, 1, FS, H, H, H, H, 0, 0, 0, False).to(dev).train()
+        opt = FusedAdamAMSGrad(model, lr=5e-4)
+        loader = DeviceWindowLoader(DS(), B, T + FS, dev)
+        acc = torch.zeros(6, dtype=torch.float64, device=dev)
+        eng = model._ensure_engine()
+        eng.seed_rng(777)
+        g = GraphedTrainStep(model, opt, loader, acc, warmup=3 if graphed else 10 ** 9, **kw)
+        snaps, terms = [], []
+        for i in range(10):
+            t = g(starts[i])
+            terms.append(t.cpu().numpy().copy())
+            snaps.append(model.flat_parameters()[0].cpu().numpy().copy())
+        assert (g.graph is not None) == graphed
+        assert eng._coop_state is not None                     # batch 256: the cooperative GRU kernels (their epoch counter lives on the device)
+        eng.check_async_errors()
+        runs.append(dict(snaps=snaps, terms=terms, acc=acc.cpu().numpy(), m=opt.m.cpu().numpy(), vmax=opt.vmax.cpu().numpy(),
+                         adam=opt.state.cpu().numpy()[1:3], rng=eng._rng.cpu().numpy(), epoch=eng._coop_state.epoch.cpu().numpy(), t=opt.t))
+    a, b = runs
+    for i in range(10):
+        np.testing.assert_array_equal(a["snaps"][i], b["snaps"][i], err_msg=f"weights after step {i}")
+        np.testing.assert_allclose(a["terms"][i], b["terms"][i], rtol=1e-5)
+    for k in ("m", "vmax", "adam", "rng", "epoch"):
+        np.testing.assert_array_equal(a[k], b[k], err_msg=k)
+    assert a["t"] == b["t"] == 10 and a["adam"].tolist() == [10, 0] and a["rng"][1] == 10
+    np.testing.assert_allclose(a["acc"], b["acc"], rtol=1e-6)
+    assert not np.array_equal(a["snaps"][0], a["snaps"][9])

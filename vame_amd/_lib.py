@@ -41,7 +41,8 @@ _SIGS = {
     "vame_gru_cell_bwd_f32": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int, c_int,
                                       c_void_p]),
     "vame_latent_fwd_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,
-                                    c_void_p]),
+                                    c_void_p, c_void_p]),
+    "vame_loss_finish_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
     "vame_latent_bwd_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_void_p,
                                     c_void_p, c_void_p]),
     "vame_head_fused_lds_bytes": (c_int64, [c_int, c_int]),
@@ -56,16 +57,16 @@ _SIGS = {
     "vame_colsum_f32": (c_int, [c_void_p, c_int64, c_int, c_int64, c_void_p, c_int, c_void_p, c_void_p]),
     "vame_colsum_batch_f32": (c_int, [c_void_p, c_int, c_void_p]),
     "vame_adam_amsgrad_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, c_float,
-                                      c_float, c_int, c_float, c_void_p, c_void_p, c_void_p]),
+                                      c_float, c_int, c_float, c_void_p, c_void_p, c_void_p, c_void_p]),
     "vame_mask_scale_f32": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_int64, c_void_p, c_float, c_void_p, c_int64, c_int, c_void_p]),
     "vame_axpy_f32": (c_int, [c_void_p, c_float, c_void_p, c_int64, c_void_p]),
     "vame_index_copy_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
     "vame_gru_coop_flag_ints": (c_int64, [c_int, c_int, c_int]),
     "vame_gru_coop_supported": (c_int, [c_int, c_int, c_int]),
     "vame_gru_coop_set_poll_limit": (c_int, [c_int]),
-    "vame_gru_coop_fwd_f32": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p]),
+    "vame_gru_coop_fwd_f32": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int64, c_void_p, c_void_p, c_void_p]),
     "vame_gru_coop_xbuf_floats": (c_int64, [c_int, c_int, c_int]),
-    "vame_gru_coop_bwd_f32": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
+    "vame_gru_coop_bwd_f32": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p]),
     "vame_gru_wide_supported": (c_int, [c_int]),
     "vame_gru_wide_fwd_f32": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p]),
     "vame_gru_wide_bwd_f32": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p]),

@@ -99,34 +99,93 @@ extern "C" int vame_window_gather_f32(const float* X, int64_t N, int F, const in
 // --------------------------------------------------------------------------------- latent fwd/bwd
 __device__ __forceinline__ float softplus_f(float x) { return x > 20.f ? x : log1pf(expf(x)); }
 
+// Counter-based N(0,1) draw for the reparameterisation (rnn_model.py:71-74: `epsilon = torch.randn_like(...)`): Philox4x32-10 keyed by the
+// caller's seed, counter = (element index, step), Box-Muller on two of its four words.  A draw depends on (seed, step, element) only --
+// reproducible, independent of the launch geometry, nothing to carry between launches but the step number.
+__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, uint32_t (&out)[4]) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        c1 = (uint32_t)p1; c3 = (uint32_t)p0; c0 = n0; c2 = n2;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+__device__ __forceinline__ float philox_normal(uint64_t idx, uint64_t seed, uint64_t step) {
+    uint32_t r[4];
+    philox4x32_10((uint32_t)idx, (uint32_t)(idx >> 32), (uint32_t)step, (uint32_t)(step >> 32), (uint32_t)seed, (uint32_t)(seed >> 32), r);
+    const float u1 = ((float)(r[0] >> 8) + 0.5f) * (1.0f / 16777216.0f);        // (0, 1): 24 bits, never 0 or 1
+    const float u2 = ((float)(r[1] >> 8) + 0.5f) * (1.0f / 16777216.0f);
+    return sqrtf(-2.0f * logf(u1)) * cosf(6.28318530717958647692f * u2);
+}
+
+// rng (device, 4 x uint64, or null): {seed, step, ticket, -}.  Non-null in training mode: eps is an OUTPUT -- the draw of this launch -- and the
+// last workgroup to finish advances `step` (every workgroup has read it by then), so consecutive launches -- incl. replays of a captured
+// graph, whose arguments are frozen -- draw fresh values with no host involvement.
 __global__ __launch_bounds__(256) void latent_fwd_kernel(const float* __restrict__ mu, const float* __restrict__ lv_raw,
-                                                         const float* __restrict__ eps, int64_t n, int softplus,
+                                                         float* eps, int64_t n, int softplus,
                                                          int training, float* __restrict__ logvar, float* __restrict__ z,
-                                                         float* __restrict__ kl_out) {
+                                                         float* __restrict__ kl_out, unsigned long long* rng) {
     float part = 0.f;
+    const bool gen = rng != nullptr && training;
+    const uint64_t seed = gen ? rng[0] : 0, step = gen ? rng[1] : 0;
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         const float m = mu[i];
         const float lv = softplus ? softplus_f(lv_raw[i]) : lv_raw[i];
         const float ev = expf(lv);
         logvar[i] = lv;
-        z[i] = training ? eps[i] * expf(0.5f * lv) + m : m;
+        float e = 0.f;
+        if (gen) { e = philox_normal((uint64_t)i, seed, step); eps[i] = e; }
+        else if (training) e = eps[i];
+        z[i] = training ? e * expf(0.5f * lv) + m : m;
         part += 1.0f + lv - m * m - ev;
     }
     if (kl_out) {
         part = block_sum_256(part);
         if (threadIdx.x == 0) atomicAdd(kl_out, part);
     }
+    if (gen) {
+        __syncthreads();                                   // every thread of this workgroup has read `step`
+        if (threadIdx.x == 0) {
+            int* ticket = reinterpret_cast<int*>(rng + 2);
+            if (atomicAdd(ticket, 1) == (int)gridDim.x - 1) { *ticket = 0; rng[1] = step + 1; }
+        }
+    }
 }
 
-extern "C" int vame_latent_fwd_f32(const float* mu, const float* lv_raw, const float* eps, int B, int Z, int softplus,
-                                   int training, float* logvar, float* z, float* kl_out, void* stream) {
+extern "C" int vame_latent_fwd_f32(const float* mu, const float* lv_raw, float* eps, int B, int Z, int softplus,
+                                   int training, float* logvar, float* z, float* kl_out, uint64_t* rng, void* stream) {
     VAME_CHECK_ARG(mu && lv_raw && logvar && z, VAME_E_BADARG, "latent_fwd: null pointer");
-    VAME_CHECK_ARG(!training || eps, VAME_E_BADARG, "latent_fwd: training mode needs eps");
+    VAME_CHECK_ARG(!training || eps, VAME_E_BADARG, "latent_fwd: training mode needs eps (input, or output of the draw when rng is given)");
     VAME_CHECK_ARG(B >= 1 && Z >= 1, VAME_E_SHAPE, "latent_fwd: bad shape");
     const int64_t n = (int64_t)B * Z;
     hipLaunchKernelGGL(latent_fwd_kernel, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, mu, lv_raw, eps, n,
-                       softplus, training, logvar, z, kl_out);
+                       softplus, training, logvar, z, kl_out, reinterpret_cast<unsigned long long*>(rng));
     VAME_LAUNCH_CHECK("latent_fwd");
+    return VAME_OK;
+}
+
+// The step's loss bookkeeping (rnn_vae.py:129-150: loss = rec + fut + BETA kl_weight kl + kl_weight kmeans; train_loss += loss.item() ...)
+// in one single-thread launch: raw = the four sums the loss kernels left ([rec, fut, sum(1 + logvar - mu^2 - exp logvar), kmeans]) -> the
+// terms in the reference's units (x scale), the weighted total, the epoch accumulators (float64: total, rec, fut, kl, kmeans, total of
+// the LAST step) -- and raw is zeroed for the next step's atomics.
+__global__ void loss_finish_kernel(float* raw, float s0, float s1, float s2, float s3, float w0, float w1, float w2, float w3, int with_fut,
+                                   float* out, double* acc) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const float t0 = raw[0] * s0, t1 = with_fut ? raw[1] * s1 : 0.f, t2 = raw[2] * s2, t3 = raw[3] * s3;
+    const float total = ((w0 * t0 + w1 * t1) + w2 * t2) + w3 * t3;
+    out[0] = t0; out[1] = t1; out[2] = t2; out[3] = t3; out[4] = total;
+    if (acc) { acc[0] += total; acc[1] += t0; acc[2] += t1; acc[3] += t2; acc[4] += t3; acc[5] = total; }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) raw[i] = 0.f;
+}
+
+extern "C" int vame_loss_finish_f32(float* raw, const float* scale, const float* weights, int with_fut, float* out, double* acc, void* stream) {
+    VAME_CHECK_ARG(raw && scale && weights && out, VAME_E_BADARG, "loss_finish: null pointer");
+    hipLaunchKernelGGL(loss_finish_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, raw, scale[0], scale[1], scale[2], scale[3], weights[0], weights[1],
+                       weights[2], weights[3], with_fut, out, acc);
+    VAME_LAUNCH_CHECK("loss_finish");
     return VAME_OK;
 }
 
@@ -377,16 +436,26 @@ extern "C" int vame_timesum_f32(const float* in, int B, int T, int C, int64_t ld
 }
 
 // --------------------------------------------------------------------------------- Adam (AMSGrad)
+// state (device, 4 words, or null): {lr as float, steps applied so far as int, ticket, -}.  Non-null: the learning rate and the step number of
+// the bias corrections are read from the DEVICE and the last workgroup to finish counts the step -- nothing in the argument list changes from
+// step to step, so a captured graph can replay the launch (and an LR scheduler writes one word); a dropped step (abort_flag) is not counted.
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                    float* __restrict__ v, float* __restrict__ vmax, int64_t n, float step_size,
                                                    float beta1, float beta2, float eps, float inv_sqrt_bc2, float gscale,
-                                                   const int* __restrict__ abort_flag, int* __restrict__ dropped) {
+                                                   const int* __restrict__ abort_flag, int* __restrict__ dropped, int* state) {
     // a device-side failure upstream (a cooperative GRU launch that gave up waiting: gru_coop.hip) must not reach the weights:
     // the step is dropped here, on the device, and the host raises when it next looks at the same word; `dropped` counts the
     // launches that did nothing, so the host can take them out of its bias-correction step count
     if (abort_flag && *abort_flag != 0) {
         if (dropped && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(dropped, 1);
         return;
+    }
+    int t = 0;
+    if (state) {
+        t = state[1] + 1;
+        const double bc1 = 1.0 - pow((double)beta1, (double)t), bc2 = 1.0 - pow((double)beta2, (double)t);
+        step_size = (float)((double)__builtin_bit_cast(float, state[0]) / bc1);
+        inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
     }
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         const float gi = g[i] * gscale;
@@ -397,15 +466,19 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
         const float denom = sqrtf(vm) * inv_sqrt_bc2 + eps;
         p[i] -= step_size * (mi / denom);
     }
+    if (state) {
+        __syncthreads();                                   // every thread of this workgroup has read the step number
+        if (threadIdx.x == 0 && atomicAdd(state + 2, 1) == (int)gridDim.x - 1) { state[2] = 0; state[1] = t; }
+    }
 }
 
 extern "C" int vame_adam_amsgrad_f32(float* p, const float* g, float* m, float* v, float* vmax, int64_t n, float lr,
                                      float beta1, float beta2, float eps, int step, float gscale, const int* abort_flag, int* dropped,
-                                     void* stream) {
-    VAME_CHECK_ARG(p && g && m && v && vmax && n >= 1 && step >= 1, VAME_E_BADARG, "adam: bad argument");
-    const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
+                                     int* state, void* stream) {
+    VAME_CHECK_ARG(p && g && m && v && vmax && n >= 1 && (state || step >= 1), VAME_E_BADARG, "adam: bad argument");
+    const double bc1 = state ? 1.0 : 1.0 - pow((double)beta1, step), bc2 = state ? 1.0 : 1.0 - pow((double)beta2, step);
     hipLaunchKernelGGL(adam_kernel, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, vmax, n,
-                       (float)(lr / bc1), beta1, beta2, eps, (float)(1.0 / sqrt(bc2)), gscale, abort_flag, dropped);
+                       (float)(lr / bc1), beta1, beta2, eps, (float)(1.0 / sqrt(bc2)), gscale, abort_flag, dropped, state);
     VAME_LAUNCH_CHECK("adam");
     return VAME_OK;
 }

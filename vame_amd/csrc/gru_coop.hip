@@ -61,7 +61,18 @@ static inline unsigned emu_tag(float x) { unsigned u; __builtin_memcpy(&u, &x, 4
 #define COOP_WAIT_LOADS8(a, b, c, d, e, f, g, h) \
     asm volatile("s_waitcnt vmcnt(0)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f), "+v"(g), "+v"(h))
 // tagged hand-off: (value, tag, value, tag) in one 16-byte write-through store; the s_nop keeps a VALU write off the data registers
-// until the store has read them (the recogniser does not see into the asm)
+// until the store has read them (the recogniser does not see into the asm).
+// HARDWARE ASSUMPTION (gfx950, the only target of this file -- enforced below): a naturally aligned 8-byte (value, tag) pair written by ONE
+// store instruction is never observed torn by a load that covers it -- each pair lies in one 16-byte, hence one 64-byte, L2 granule, is
+// written by a single write-through (sc1) request and read by single L1-bypassing (sc1) requests; the reader accepts a pair only when ITS
+// OWN tag matches, so the two pairs of a 16-byte packet may arrive at different times and nothing depends on ordering between packets, on
+// which XCD a producer or consumer runs (b % 8 -> XCD is a speed heuristic only: a group spread over XCDs exchanges through the shared
+// memory side instead of one L2, ~1.7x slower hops, same protocol) or on release / acquire semantics (MI355X_MICROARCH.md, "handoff-1to1":
+// granule = one naturally aligned 8-byte {data, tag} written by ONE sc1 store).  tools/coop_stress.py and tests/test_kernels_gpu.py::
+// test_gru_coop_* compare every VALUE that travelled through the packets with the batch-tile-persistent kernels' over repeated launches.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+#error "gru_coop.hip's tagged hand-off relies on gfx950 memory-system behaviour (see above); it has not been validated anywhere else"
+#endif
 #define COOP_STORE16_LL(ptr, a, b, tag)                                                                          \
     do {                                                                                                         \
         const f32x4 ll_ = {(a), __uint_as_float(tag), (b), __uint_as_float(tag)};                                \
@@ -101,6 +112,17 @@ extern "C" int vame_probe_set_coop(long long* p) { return (int)hipMemcpyToSymbol
 #define COOP_PHASE(i)
 #define COOP_PHASE_END()
 #endif
+
+// The launch epoch lives on the DEVICE: epoch[0] = the tag base of this launch (every hand-off tag / flag value of the launch is base + step
+// + 1 ... compared modulo 2^32), epoch[1] = a ticket.  Every workgroup reads the base when it starts; the last one to finish moves it on by
+// `advance` (> the launch's steps + 1), so the next launch sharing `flags` -- also a REPLAY of a captured graph, whose arguments are
+// frozen -- finds every word of this one stale.  No host counter, no argument that changes from launch to launch.
+__device__ __forceinline__ void coop_advance_epoch(int* epoch, int base, int advance) {
+    if (threadIdx.x == 0 && atomicAdd(epoch + 1, 1) == (int)gridDim.x - 1) {
+        epoch[1] = 0;
+        epoch[0] = (int)((unsigned)base + (unsigned)advance);
+    }
+}
 
 // Poll budget of one hand-off wait.  A stuck group reports through *status instead of hanging the queue; once *status != 0 every
 // later wait of the launch gives up at once (results undefined, the launch ends) and the optimizer kernel that follows refuses to
@@ -150,8 +172,7 @@ __device__ __forceinline__ bool coop_map(int ngroups, int& g, int& m, int& half)
 // and step against 128 of 64 cycles on three of four SIMDs in the 32 x 32 form of rounds 2-3).  The four K quarters are summed
 // separately and then added in the same order in either form, so a launch gives the same bits whichever R its row range selects.
 template <int H, int R>
-__global__ __launch_bounds__(COOP_NT) COOP_WAVES_PER_SIMD void gru_coop_fwd_kernel(GruFwdParams P, int* __restrict__ flags, int base, int* __restrict__ status,
-                                                           int max_polls) {
+__device__ __forceinline__ void gru_coop_fwd_body(const GruFwdParams& P, int* __restrict__ flags, int base, int* __restrict__ status, int max_polls) {
     constexpr int NM = H / 32, NH = 32 / R, LDW = H + 4, LDH = H + 4, NCH = H / 16, QN = NCH / 4, PBF = R == 32 ? 4 * 24 * 64 : 2 * 3 * 12 * 64;
     static_assert(R == 32 || R == 16, "row tiles of 32 or 16");
     VAME_DYN_SMEM(smem_raw);
@@ -443,6 +464,14 @@ __global__ __launch_bounds__(COOP_NT) COOP_WAVES_PER_SIMD void gru_coop_fwd_kern
     }
 }
 
+template <int H, int R>
+__global__ __launch_bounds__(COOP_NT) COOP_WAVES_PER_SIMD void gru_coop_fwd_kernel(GruFwdParams P, int* __restrict__ flags, int* epoch, int advance,
+                                                           int* __restrict__ status, int max_polls) {
+    const int base = epoch[0];
+    gru_coop_fwd_body<H, R>(P, flags, base, status, max_polls);
+    coop_advance_epoch(epoch, base, advance);
+}
+
 #ifdef VAME_EMU
 #define COOP_ALLOW_LDS(kernel, bytes)
 #else      // > 64 KiB of dynamic LDS must be granted per kernel
@@ -479,7 +508,7 @@ static int coop_cu_count() {
 }
 
 template <int H, int R> static size_t coop_bwd_lds();
-template <int H, int R> __global__ __launch_bounds__(COOP_NT) COOP_WAVES_PER_SIMD void gru_coop_bwd_kernel(GruBwdParams, float*, int*, int, int*, int);
+template <int H, int R> __global__ __launch_bounds__(COOP_NT) COOP_WAVES_PER_SIMD void gru_coop_bwd_kernel(GruBwdParams, float*, int*, int*, int, int*, int);
 // The runtime's own answer to "how many of these workgroups does one CU hold" (registers, LDS, waves): every cooperative kernel
 // must get >= 1, and the grid is then limited to ONE workgroup per CU (their LDS footprints exclude a second one anyway).
 static int coop_kernels_resident(int H) {
@@ -533,16 +562,22 @@ static int coop_row_range(int B, int row0, int nrows, int& tile_off, int& ntiles
     return 1;
 }
 
-extern "C" int vame_gru_coop_fwd_f32(const int64_t* desc, int nstreams, int B, int H, int row0, int nrows, int* flags, int epoch_base,
+extern "C" int vame_gru_coop_fwd_f32(const int64_t* desc, int nstreams, int B, int H, int row0, int nrows, int* flags, int64_t flag_ints, int* epoch,
                                      int* status, void* stream) {
-    VAME_CHECK_ARG(desc && flags && status && nstreams >= 1 && nstreams <= 8 && B >= 1, VAME_E_BADARG, "gru_coop_fwd: bad arguments");
+    VAME_CHECK_ARG(desc && flags && epoch && status && nstreams >= 1 && nstreams <= 8 && B >= 1, VAME_E_BADARG, "gru_coop_fwd: bad arguments");
     int tile_off, ntiles;
     VAME_CHECK_ARG(coop_row_range(B, row0, nrows, tile_off, ntiles), VAME_E_SHAPE, "gru_coop_fwd: bad row range %d+%d of %d", row0, nrows, B);
     VAME_CHECK_ARG(vame_gru_coop_supported(nstreams, ntiles * 32, H), VAME_E_UNSUPPORTED,
                    "gru_coop_fwd: nstreams=%d rows=%d H=%d does not fit one workgroup per CU (or H not 128/256)", nstreams, ntiles * 32, H);
+    VAME_CHECK_ARG(flag_ints >= vame_gru_coop_flag_ints(nstreams, ntiles * 32, H), VAME_E_SHAPE,
+                   "gru_coop_fwd: flags holds %lld ints, this launch needs %lld (vame_gru_coop_flag_ints)", (long long)flag_ints,
+                   (long long)vame_gru_coop_flag_ints(nstreams, ntiles * 32, H));
     GruFwdParams P;
     if (int rc = gru_parse_fwd(desc, nstreams, B, P)) return rc;
     P.ntiles = ntiles; P.tile_off = tile_off;
+    int advance = 0;
+    for (int i = 0; i < nstreams; ++i) advance = (int)P.s[i].T > advance ? (int)P.s[i].T : advance;
+    advance += 2;
     for (int i = 0; i < nstreams; ++i) {
         VAME_CHECK_ARG(P.s[i].xf == 0 && P.s[i].y, VAME_E_UNSUPPORTED, "gru_coop_fwd: stream %d needs a precomputed gi and an output sequence", i);
         VAME_CHECK_ARG((uintptr_t)P.s[i].y % 16 == 0 && P.s[i].y_row % 4 == 0 && P.s[i].y_t % 4 == 0 &&
@@ -563,7 +598,7 @@ extern "C" int vame_gru_coop_fwd_f32(const int64_t* desc, int nstreams, int B, i
         const size_t lds_ = coop_fwd_lds<HH, RR>();                                                                              \
         const int grid_ = coop_grid<HH / 32>(ngroups) * (32 / RR);                                                               \
         COOP_ALLOW_LDS((gru_coop_fwd_kernel<HH, RR>), lds_);                                                                     \
-        hipLaunchKernelGGL((gru_coop_fwd_kernel<HH, RR>), dim3(grid_), dim3(COOP_NT), lds_, st, P, flags, epoch_base, status, g_coop_polls); \
+        hipLaunchKernelGGL((gru_coop_fwd_kernel<HH, RR>), dim3(grid_), dim3(COOP_NT), lds_, st, P, flags, epoch, advance, status, g_coop_polls); \
     } while (0)
     if (H == 256) { if (r16) COOP_FWD_LAUNCH(256, 16); else COOP_FWD_LAUNCH(256, 32); }
     else          { if (r16) COOP_FWD_LAUNCH(128, 16); else COOP_FWD_LAUNCH(128, 32); }
@@ -591,8 +626,8 @@ extern "C" int vame_gru_coop_fwd_f32(const int64_t* desc, int nstreams, int B, i
 // partial tile nor the carry passes through LDS.  The two 16-row groups of a tile add their bias partials in a fixed order
 // (the upper one hands its sums to the lower one at the end of the launch), and the 32-row form sums in the same order.
 template <int H, int R>
-__global__ __launch_bounds__(COOP_NT) COOP_WAVES_PER_SIMD void gru_coop_bwd_kernel(GruBwdParams P, float* __restrict__ xbuf, int* __restrict__ flags, int base,
-                                                           int* __restrict__ status, int max_polls) {
+__device__ __forceinline__ void gru_coop_bwd_body(const GruBwdParams& P, float* __restrict__ xbuf, int* __restrict__ flags, int base,
+                                                  int* __restrict__ status, int max_polls) {
     constexpr int NM = H / 32, NH = 32 / R, LDK = 100, LDG = 132, NCT = H / 16, NWV = COOP_NT / 64, TPW = NCT * (R / 16) / NWV, RG = R / 4;
     static_assert((NM == 8 || NM == 4) && (R == 32 || R == 16), "written for H = 128 / 256, 32- or 16-row groups");
     VAME_DYN_SMEM(smem_raw);
@@ -823,21 +858,33 @@ __global__ __launch_bounds__(COOP_NT) COOP_WAVES_PER_SIMD void gru_coop_bwd_kern
 }
 
 template <int H, int R>
+__global__ __launch_bounds__(COOP_NT) COOP_WAVES_PER_SIMD void gru_coop_bwd_kernel(GruBwdParams P, float* __restrict__ xbuf, int* __restrict__ flags, int* epoch,
+                                                           int advance, int* __restrict__ status, int max_polls) {
+    const int base = epoch[0];
+    gru_coop_bwd_body<H, R>(P, xbuf, flags, base, status, max_polls);
+    coop_advance_epoch(epoch, base, advance);
+}
+
+template <int H, int R>
 static size_t coop_bwd_lds() { return (size_t)(H * 100 + R * 132) * 4; }
 
 extern "C" int64_t vame_gru_coop_xbuf_floats(int nstreams, int B, int H) { return (int64_t)nstreams * cdiv64(B, 32) * 2 * 32 * H * (H / 32); }
 
-extern "C" int vame_gru_coop_bwd_f32(const int64_t* desc, int nstreams, int B, int H, int row0, int nrows, float* xbuf, int* flags,
-                                     int epoch_base, int* status, void* stream) {
-    VAME_CHECK_ARG(desc && xbuf && flags && status && nstreams >= 1 && nstreams <= 8 && B >= 1, VAME_E_BADARG, "gru_coop_bwd: bad arguments");
+extern "C" int vame_gru_coop_bwd_f32(const int64_t* desc, int nstreams, int B, int H, int row0, int nrows, float* xbuf, int* flags, int64_t flag_ints,
+                                     int* epoch, int* status, void* stream) {
+    VAME_CHECK_ARG(desc && xbuf && flags && epoch && status && nstreams >= 1 && nstreams <= 8 && B >= 1, VAME_E_BADARG, "gru_coop_bwd: bad arguments");
     int tile_off, ntiles;
     VAME_CHECK_ARG(coop_row_range(B, row0, nrows, tile_off, ntiles), VAME_E_SHAPE, "gru_coop_bwd: bad row range %d+%d of %d", row0, nrows, B);
     VAME_CHECK_ARG(vame_gru_coop_supported(nstreams, ntiles * 32, H), VAME_E_UNSUPPORTED,
                    "gru_coop_bwd: nstreams=%d rows=%d H=%d does not fit one workgroup per CU (or H not 128/256)", nstreams, ntiles * 32, H);
     VAME_CHECK_ARG((uintptr_t)xbuf % 16 == 0, VAME_E_SHAPE, "gru_coop_bwd: exchange buffer must be 16-byte aligned");
+    VAME_CHECK_ARG(flag_ints >= COOP_LL_OFF, VAME_E_SHAPE, "gru_coop_bwd: flags holds %lld ints, BPTT needs the %d flag words", (long long)flag_ints, (int)COOP_LL_OFF);
     GruBwdParams P;
     if (int rc = gru_parse_bwd(desc, nstreams, B, P)) return rc;
     P.ntiles = ntiles; P.tile_off = tile_off;
+    int advance = 0;
+    for (int i = 0; i < nstreams; ++i) advance = (int)P.s[i].T > advance ? (int)P.s[i].T : advance;
+    advance += 2;
     for (int i = 0; i < nstreams; ++i)
         VAME_CHECK_ARG((uintptr_t)P.s[i].dg % 16 == 0, VAME_E_SHAPE, "gru_coop_bwd: stream %d: dG must be 16-byte aligned", i);
     hipStream_t st = (hipStream_t)stream;
@@ -853,7 +900,7 @@ extern "C" int vame_gru_coop_bwd_f32(const int64_t* desc, int nstreams, int B, i
         const size_t lds_ = coop_bwd_lds<HH, RR>();                                                                              \
         const int grid_ = coop_grid<HH / 32>(ngroups) * (32 / RR);                                                               \
         COOP_ALLOW_LDS((gru_coop_bwd_kernel<HH, RR>), lds_);                                                                     \
-        hipLaunchKernelGGL((gru_coop_bwd_kernel<HH, RR>), dim3(grid_), dim3(COOP_NT), lds_, st, P, xbuf, flags, epoch_base, status, g_coop_polls); \
+        hipLaunchKernelGGL((gru_coop_bwd_kernel<HH, RR>), dim3(grid_), dim3(COOP_NT), lds_, st, P, xbuf, flags, epoch, advance, status, g_coop_polls); \
     } while (0)
     if (H == 256) { if (r16) COOP_BWD_LAUNCH(256, 16); else COOP_BWD_LAUNCH(256, 32); }
     else          { if (r16) COOP_BWD_LAUNCH(128, 16); else COOP_BWD_LAUNCH(128, 32); }

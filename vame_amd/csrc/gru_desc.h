@@ -39,15 +39,17 @@ struct GruBwdParams { GruBwdStream s[8]; int nstreams; int B; int ntiles; int ti
 
 
 // GF_OPT / GB_OPT of stream 0 (include/vame_hip.h, VAME_GRU_OPT): kernel choice and pacing are arguments, not process state
-static inline void gru_parse_opt(int64_t opt, int& kernel, int& pace_cp, int& pace_ld) {
-    kernel = (int)(opt & 15);
+// (kernel in bits 0-7, pacing values + 1 in bits 8-15 / 16-23; anything above bit 23, or a kernel number with bits above 3, is a caller bug: refused)
+static inline bool gru_parse_opt(int64_t opt, int& kernel, int& pace_cp, int& pace_ld) {
+    kernel = (int)(opt & 255);
     pace_cp = (int)((opt >> 8) & 255) - 1;          // -1 = default
     pace_ld = (int)((opt >> 16) & 255) - 1;
+    return (opt >> 24) == 0 && kernel < 16;
 }
 
 static inline int gru_parse_fwd(const int64_t* desc, int nstreams, int B, GruFwdParams& P) {
     P.nstreams = nstreams; P.B = B; P.ntiles = (int)cdiv64(B, 32);
-    gru_parse_opt(desc[GF_OPT], P.kernel, P.pace_cp, P.pace_ld);
+    VAME_CHECK_ARG(gru_parse_opt(desc[GF_OPT], P.kernel, P.pace_cp, P.pace_ld), VAME_E_BADARG, "gru_seq_fwd: malformed option word %lld", (long long)desc[GF_OPT]);
     VAME_CHECK_ARG(P.kernel <= VAME_GRU_KERNEL_SKEWED, VAME_E_BADARG, "gru_seq_fwd: unknown kernel option %d", P.kernel);
     for (int i = 0; i < nstreams; ++i) {
         const int64_t* d = desc + (int64_t)i * VAME_GRU_FWD_FIELDS;
@@ -72,7 +74,7 @@ static inline int gru_parse_fwd(const int64_t* desc, int nstreams, int B, GruFwd
 
 static inline int gru_parse_bwd(const int64_t* desc, int nstreams, int B, GruBwdParams& P) {
     P.nstreams = nstreams; P.B = B; P.ntiles = (int)cdiv64(B, 32);
-    gru_parse_opt(desc[GB_OPT], P.kernel, P.pace_cp, P.pace_ld);
+    VAME_CHECK_ARG(gru_parse_opt(desc[GB_OPT], P.kernel, P.pace_cp, P.pace_ld), VAME_E_BADARG, "gru_seq_bwd: malformed option word %lld", (long long)desc[GB_OPT]);
     VAME_CHECK_ARG(P.kernel <= VAME_GRU_KERNEL_SKEWED, VAME_E_BADARG, "gru_seq_bwd: unknown kernel option %d", P.kernel);
     for (int i = 0; i < nstreams; ++i) {
         const int64_t* d = desc + (int64_t)i * VAME_GRU_BWD_FIELDS;

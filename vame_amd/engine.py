@@ -200,6 +200,9 @@ class VAEEngine:
         self._nuc_pending = None          # arguments of a deferred cluster_terms()
         self._nuc_event = None            # recorded on the side stream after the solve
         self._drop_mask = None
+        self._rng = None                  # device state of the reparameterisation's N(0,1) stream (seed_rng)
+        self.capturing = False            # inside a hipGraph stream capture (rnn_vae.GraphedTrainStep): no event queries, no host copies
+        self._eps_used = None
         self.packed_version = -1
         self.version = 0          # bumped by the owner whenever flat_p changes
         self.serial = 0           # bumped by every call that overwrites the forward workspace (stale-backward guard)
@@ -472,19 +475,23 @@ class VAEEngine:
         all_ranks (the epoch-end checks of train() / test(): every rank is at this program point): the status words are MAX-reduced
         over the ranks first, so either every rank raises or none does -- a rank raising on its own would leave the others in
         their next collective."""
-        if self._coop_state is None:
-            return
         reduce = None
         if all_ranks and self._multi_rank():
             def reduce(n):
                 t = torch.tensor([int(n)], dtype=torch.int32, device=self.dev)
                 torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
                 return int(t.item())
+        if self._coop_state is None:
+            # no cooperative launch on THIS rank so far (a smaller last batch, engine.coop off here): the collective still has to be entered,
+            # contributing 0 -- a rank that skipped it would leave the others waiting at the end of the epoch
+            if reduce is not None and reduce(0):
+                raise ops._lib.VameHipError("cooperative GRU kernel: a hand-off wait timed out on another rank; the affected optimizer step was dropped on every rank")
+            return
         self._coop_state.check(reduce=reduce)
 
     def poll_async_errors(self):
         """Start of a step: raise if an earlier step's status snapshot has arrived non-zero (never blocks)."""
-        if self._coop_state is not None:
+        if self._coop_state is not None and not self.capturing:
             self._coop_state.poll()
 
     def snapshot_async_errors(self, reduced=False):
@@ -493,6 +500,8 @@ class VAEEngine:
         the per-rank call at the end of loss_step does nothing."""
         # (under a process group the rank-local call does nothing from the very first step on -- `shared` is only set by the first
         # all-reduce, and a rank-local word in the snapshot ring would let ONE rank raise a step later)
+        if self.capturing:           # (a step being captured into a graph: the copy to the host and its event are the replayer's business)
+            return
         if self._coop_state is not None and (reduced or (self._coop_state.shared is None and not self._multi_rank())):
             self._coop_state.snapshot()
 
@@ -698,7 +707,17 @@ class VAEEngine:
         self._gru_fwd(rows, B)
         return hn
 
+    def loss_sums(self):
+        """The 8-float buffer the loss kernels add their sums to (slots LOSS_*).  Zero between steps: allocated zeroed, and
+        ops.loss_finish -- the one reader -- leaves it zeroed (so no fill launch opens a step)."""
+        return self.ws.get("losses", 8, self.dev, zero=True)
+
+    def seed_rng(self, seed, step=0):
+        """(Re)start the device-side N(0,1) stream of the reparameterisation: Philox keyed by `seed`, next draw = `step`."""
+        self._rng = torch.tensor([int(seed) & 0x7fffffffffffffff, int(step), 0, 0], dtype=torch.int64, device=self.dev)
+
     def latent(self, hn, B, eps, training, want_kl=True):
+        """eps = None in training mode: the latent kernel draws it (device-side Philox stream, seed_rng) into the engine's own eps buffer."""
         s, H, Z = self.spec, self.spec.H, self.spec.Z
         self.serial += 1
         mu, lvr = self.buf("mu", B, Z), self.buf("lv_raw", B, Z)
@@ -708,9 +727,13 @@ class VAEEngine:
                  bias=self._pv("lmbda.hidden_to_mean.bias"), splitk=0)
         ops.gemm(B, Z, 4 * H, hn_op, 0, self.P("lmbda.hidden_to_logvar.weight", 4 * H), 0, lvr, Z,
                  bias=self._pv("lmbda.hidden_to_logvar.bias"), splitk=0)
-        losses = self.buf("losses", 8)
-        losses.zero_()
-        ops.latent_fwd(mu, lvr, eps, B, Z, s.softplus, training, logvar, z, losses[LOSS_KLSUM:] if want_kl else None)
+        rng = None
+        if training and eps is None:
+            if self._rng is None:
+                self.seed_rng(int(torch.empty((), dtype=torch.int64).random_().item()))       # from torch's (seedable) CPU generator, once
+            rng, eps = self._rng, self.buf("eps", B, Z)
+        self._eps_used = eps
+        ops.latent_fwd(mu, lvr, eps, B, Z, s.softplus, training, logvar, z, self.loss_sums()[LOSS_KLSUM:] if want_kl else None, rng=rng)
         return z, mu, logvar
 
     def _decode_one(self, tag, name, dirs, steps, z, B, training, rows, jobs, inputs=None):
@@ -780,7 +803,7 @@ class VAEEngine:
         ops.gemm(Z, Z, B, Operand(z, Z), 1, Operand(z, Z), 1, G, Z, splitk=sk, ws=ws)
         if self._nuc_state is None:
             self._nuc_state = torch.zeros(ops.nuclear_state_doubles(Z), device=self.dev, dtype=torch.float64)
-        ops.nuclear(G, Z, kloss, B, klmbda, bsize, self.buf("losses", 8), LOSS_KMEANS, self.buf("Minv", Z, Z), gscale=kl_weight,
+        ops.nuclear(G, Z, kloss, B, klmbda, bsize, self.loss_sums(), LOSS_KMEANS, self.buf("Minv", Z, Z), gscale=kl_weight,
                     vstate=self._nuc_state)
 
     def set_overlap(self, on):
@@ -810,14 +833,16 @@ class VAEEngine:
             torch.cuda.current_stream(self.dev).wait_event(self._nuc_event)
             self._nuc_event = None
 
-    def forward(self, win, win_row, B, eps, training, cluster=None, enc_in=None, drop_mask=None, defer_heads=False):
+    def forward(self, win, win_row, B, eps, training, cluster=None, enc_in=None, drop_mask=None, defer_heads=False, want_kl=False):
         """Full RNN_VAE.forward (rnn_model.py:162-179).  Returns workspace views pred, fut, z, mu, logvar.
         cluster = (kl_weight, kloss, klmbda, bsize) also evaluates the nuclear-norm loss as soon as z exists.
         enc_in (B,T,F contiguous) replaces the first T steps of `win` as the encoder input (input-noise option)."""
         s = self.spec
         xin, xin_row = (win, win_row) if enc_in is None else (enc_in, s.T * s.F)
         hn = self.encode(xin, xin_row, B, training, drop_mask=drop_mask)
-        z, mu, logvar = self.latent(hn, B, eps, training)
+        # want_kl: only a caller that goes on to loss() + ops.loss_finish (which consumes the sums) asks for the KL sum
+        z, mu, logvar = self.latent(hn, B, eps, training, want_kl=want_kl)
+        eps = self._eps_used
         if cluster is not None:
             if self.nuc_side and training and self.dev.type == "cuda":
                 self._nuc_pending = (B,) + tuple(cluster)             # issued by decode() right behind the decoders' GRU launch
@@ -849,7 +874,7 @@ class VAEEngine:
     def loss(self, B, tgt, tgt_row, fut_tgt_off, kl_weight, kloss, klmbda, bsize, mse_red="sum", mse_pred="sum", with_future=True):
         """rnn_vae.py:124-129.  Fills losses[REC,FUT,KLSUM,KMEANS] and the gradient seeds dpred/dfut/Minv."""
         s, T, F, FS, Z = self.spec, self.spec.T, self.spec.F, self.spec.FS, self.spec.Z
-        losses = self.buf("losses", 8)
+        losses = self.loss_sums()
         dpred = self.buf("dpred", B, T, F)
         sc = 2.0 if mse_red == "sum" else 2.0 / (B * T * F)
         if self._heads_deferred:

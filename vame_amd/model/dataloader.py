@@ -96,6 +96,29 @@ class DeviceWindowLoader:
         ops.window_gather(self.Xn, self.N, self.F, st, 0, self.B, self.L, out)
         return out
 
+    # ---- the same batcher in two halves for a captured step graph (rnn_vae.GraphedTrainStep): the window starts travel to a FIXED device
+    # buffer outside the graph (the only host -> device traffic of a step), the gather kernel inside it reads that buffer and writes a
+    # fixed window buffer
+    def upload_starts(self, starts):
+        if getattr(self, "_starts_dev", None) is None:
+            self._starts_dev = torch.empty(self.B, dtype=torch.int64, device=self.dev)
+        k = self._k = self._k ^ 1
+        if self._ev[k] is not None:
+            self._ev[k].synchronize()
+        self._stage[k].copy_(torch.from_numpy(np.ascontiguousarray(starts, dtype=np.int64)))
+        self._starts_dev.copy_(self._stage[k], non_blocking=True)
+        if self.dev.type == "cuda":
+            self._ev[k] = torch.cuda.Event()
+            self._ev[k].record()
+
+    def gather_static(self):
+        if getattr(self, "_starts_dev", None) is None:
+            self._starts_dev = torch.empty(self.B, dtype=torch.int64, device=self.dev)
+        if getattr(self, "_win_static", None) is None:
+            self._win_static = torch.empty(self.B, self.L, self.F, device=self.dev)
+        ops.window_gather(self.Xn, self.N, self.F, self._starts_dev, 0, self.B, self.L, self._win_static)
+        return self._win_static
+
     def __iter__(self):
         for _ in range(self.n_batches):
             yield self.gather(self.draw_starts())

@@ -13,7 +13,7 @@ The torch.nn.GRU / nn.Linear objects are parameter containers only; they are nev
 import torch
 from torch import nn
 
-from .. import _lib
+from .. import _lib, ops
 from ..engine import ParamTable, Spec, VAEEngine
 from ..padding import PadMap, needs_padding
 
@@ -73,9 +73,9 @@ class Lambda(nn.Module, _EngineOwner):
             h = pad.pad_cols(h, 4, pad.true_spec.H)
         B, Z = h.shape[0], eng.spec.Z
         with torch.no_grad():
-            if self.training and eps is None:
-                eps = torch.randn(B, Z, device=eng.dev)
-            z, mu, lv = eng.latent(h, B, eps, self.training, want_kl=False)
+            if eps is not None:
+                eps = _as_f32(eps, eng.dev)
+            z, mu, lv = eng.latent(h, B, eps, self.training, want_kl=False)      # eps = None in training mode: drawn by the kernel
             self.mean, self.logvar = mu[:B * Z].view(B, Z).clone(), lv[:B * Z].view(B, Z).clone()
             zz = z[:B * Z].view(B, Z).clone() if self.training else self.mean
         return zz, self.mean, self.logvar
@@ -248,8 +248,10 @@ class RNN_VAE(nn.Module):
         chk = self._bucket_check
         ok = chk is not None
         if ok:
-            for p_, addr in chk:
-                if p_.data_ptr() != addr:
+            # the LIVE parameter of every slot is still the object the bucket was built over (module surgery, load_state_dict(assign=True) or
+            # `mod.weight = nn.Parameter(...)` replace the object: the old one would go on pointing into the bucket) and still points into it
+            for owner, name, p_, addr in chk:
+                if owner._parameters.get(name) is not p_ or p_.data_ptr() != addr:
                     ok = False
                     break
         plist = None
@@ -262,7 +264,7 @@ class RNN_VAE(nn.Module):
                 base, esz, tab = self._flat_p.data_ptr(), 4, self._table
                 ok = all(p.data_ptr() == base + esz * tab.off(n) for n, p in plist)
                 if ok:
-                    self._bucket_check = [(p, p.data_ptr()) for _, p in plist]
+                    self._bucket_check = self._slots(plist)
         if not ok:
             self._table = ParamTable([(n, p.shape) for n, p in plist])
             flat_p = torch.zeros(self._table.numel, device=dev)
@@ -277,7 +279,7 @@ class RNN_VAE(nn.Module):
             self._flat_p, self._flat_g = flat_p, flat_g
             self._flat_gtmp = torch.zeros_like(flat_g)
             self._param_list = [p for _, p in plist]
-            self._bucket_check = [(p, p.data_ptr()) for _, p in plist]
+            self._bucket_check = self._slots(plist)
             if needs_padding(self.spec):
                 # a hidden size that is not a multiple of 32 (torch.nn.GRU takes any): the kernels run on a zero-padded image of
                 # the parameters; the model, its state_dict, the optimizer and the all-reduce keep the reference's shapes
@@ -291,6 +293,14 @@ class RNN_VAE(nn.Module):
                 self._pad.push_params(self._flat_p)
             self._engine.version += 1          # weights may have changed since the last call: repack (a few tiny kernels)
         return self._engine
+
+    def _slots(self, plist):
+        """[(owning module, attribute name, Parameter, address)] of every parameter: what _ensure_engine's fast path re-checks per call."""
+        out = []
+        for n, p in plist:
+            mod, _, leaf = n.rpartition(".")
+            out.append((self.get_submodule(mod) if mod else self, leaf, p, p.data_ptr()))
+        return out
 
     def _accumulate_tmp_grads(self):
         for n, p in self.named_parameters():
@@ -337,9 +347,7 @@ class RNN_VAE(nn.Module):
         x = seq.to(device=eng.dev, dtype=torch.float32).contiguous()
         _check(x.dim() == 3 and x.shape[1] == s.T and x.shape[2] == s.F, f"input {tuple(x.shape)} != (B,{s.T},{s.F})")
         B = x.shape[0]
-        if self.training:
-            if eps is None:
-                eps = torch.randn(B, s.Z, device=eng.dev)
+        if self.training and eps is not None:            # (None: the latent kernel draws it -- device-side Philox stream, VAEEngine.seed_rng)
             eps = eps.to(device=eng.dev, dtype=torch.float32).contiguous()
         drop_mask = self._engine_mask(self._dropout_mask(B, drop_mask, eng.dev))
         if self.training and torch.is_grad_enabled():
@@ -358,28 +366,29 @@ class RNN_VAE(nn.Module):
 
     # ---------------------------------------------------------------- fused training / evaluation step
     def loss_step(self, win, kl_weight, *, beta, kloss, klmbda, bsize, mse_red="sum", mse_pred="sum", eps=None, backward=True,
-                  enc_in=None, drop_mask=None):
+                  enc_in=None, drop_mask=None, weights=None, acc=None):
         """One fused forward + loss (+ backward) over a batch of windows, entirely on device.
 
         win: (B, L, F) fp32 device tensor, L >= T (+FS): steps [0,T) are the encoder input and
         reconstruction target, steps [T, T+FS) the future target (rnn_vae.py:111-112).
         `enc_in` (B,T,F) optionally replaces the encoder input (cfg['noise'], rnn_vae.py:116-119); targets stay `win`.
         Gradients land in the flat bucket (p.grad views).  Returns a device tensor
-        [rec, fut, kl, kmeans] in the reference's units (no host sync)."""
+        [rec, fut, kl, kmeans] in the reference's units (no host sync).  `acc` (float64[6] device tensor, optional): the same launch adds
+        [total, rec, fut, kl, kmeans] to acc[0:5] and stores this step's total in acc[5], total = sum(weights x terms) with `weights`
+        defaulting to the reference's (1, 1, beta kl_weight, kl_weight) (rnn_vae.py:129-150's bookkeeping, on the device)."""
         eng = self._ensure_engine()
         s = self.spec
         B, L, F = win.shape
         training = self.training
         eng.poll_async_errors()
         _check(F == s.F and L >= s.T + (s.FS if (training and s.future) else 0), f"window batch {tuple(win.shape)} too short")
-        if training and eps is None:
-            eps = torch.randn(B, s.Z, device=eng.dev)
         with torch.no_grad():
             if enc_in is not None:
                 enc_in = enc_in.to(device=eng.dev, dtype=torch.float32).contiguous()
                 _check(tuple(enc_in.shape) == (B, s.T, F), f"enc_in {tuple(enc_in.shape)} != {(B, s.T, F)}")
+            # eps = None in training mode: drawn inside the latent kernel (the reference's torch.randn_like, rnn_model.py:71-74)
             eng.forward(win, L * F, B, eps, training, cluster=(kl_weight, kloss, klmbda, bsize), enc_in=enc_in,
-                        drop_mask=self._engine_mask(self._dropout_mask(B, drop_mask, eng.dev)), defer_heads=True)
+                        drop_mask=self._engine_mask(self._dropout_mask(B, drop_mask, eng.dev)), defer_heads=True, want_kl=True)
             # test(): no future term (rnn_vae.py:183-198)
             losses = eng.loss(B, win, L * F, s.T * F, kl_weight, kloss, klmbda, bsize, mse_red, mse_pred,
                               with_future=training and s.future)
@@ -388,20 +397,14 @@ class RNN_VAE(nn.Module):
                 if self._pad is not None:
                     self._pad.pull_grads(self._flat_g)
             eng.join_cluster()
-            # [rec, fut, kl, kmeans] in the reference's units: one multiply by a cached scale vector (every small torch op here is
-            # enqueue time of a step that is nearly host-bound at the stock batch)
+            # [rec, fut, kl, kmeans] in the reference's units, their weighted total and the caller's epoch accumulators: ONE single-thread
+            # launch (vame_loss_finish_f32), which also leaves the sums zeroed for the next step -- no torch op, no vendor BLAS call
             with_fut = bool(training and s.future)
-            key = (B, mse_red, mse_pred, with_fut, str(eng.dev))
-            scale = self._loss_scale.get(key) if hasattr(self, "_loss_scale") else None
-            if scale is None:
-                if not hasattr(self, "_loss_scale"):
-                    self._loss_scale = {}
-                scale = self._loss_scale[key] = torch.tensor(
-                    [1.0 if mse_red == "sum" else 1.0 / (B * s.T * F), 1.0 if (not s.future or mse_pred == "sum") else 1.0 / (B * s.FS * F),
-                     -0.5 / (B * s.Z), 1.0], device=eng.dev, dtype=torch.float32)
-            out = losses[:4] * scale
-            if not with_fut:
-                out[1] = 0.0                    # (no future term in this pass: the slot may hold anything)
+            scale = (1.0 if mse_red == "sum" else 1.0 / (B * s.T * F), 1.0 if (not s.future or mse_pred == "sum") else 1.0 / (B * s.FS * F),
+                     -0.5 / (B * s.Z), 1.0)
+            out5 = torch.empty(5, device=eng.dev)                  # (allocation only; a fresh tensor per step: callers may keep the terms)
+            ops.loss_finish(losses, scale, weights if weights is not None else (1.0, 1.0, beta * kl_weight, kl_weight), with_fut, out5, acc)
+            out = out5[:4]
         eng.snapshot_async_errors()
         return out
 

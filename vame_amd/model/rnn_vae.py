@@ -100,9 +100,20 @@ class FusedAdamAMSGrad(torch.optim.Optimizer):
         self.m = torch.zeros_like(self.flat_p)
         self.v = torch.zeros_like(self.flat_p)
         self.vmax = torch.zeros_like(self.flat_p)
-        self.t = 0
+        self.t = 0                                           # host mirror of the step count (the device's is authoritative: `state`)
         self.dropped = torch.zeros(1, dtype=torch.int32, device=self.flat_p.device)   # launches the abort word turned into no-ops
+        # {learning rate (float bits), updates applied, ticket, -}: the kernel reads lr and the bias-correction step from here and counts itself,
+        # so its argument list never changes (vame_adam_amsgrad_f32 `state`; a captured step graph replays it, GraphedTrainStep)
+        self.state = torch.zeros(4, dtype=torch.int32, device=self.flat_p.device)
+        self._lr_on_device = None
         self._hooked = None
+
+    def sync_lr(self):
+        """Write the current learning rate to the device word the kernel reads (one tiny fill, only when a scheduler changed it)."""
+        lr = float(self.param_groups[0]["lr"])
+        if lr != self._lr_on_device:
+            self.state.view(torch.float32)[0:1].fill_(lr)
+            self._lr_on_device = lr
 
     def _forget_dropped_steps(self):
         """Runs when a device-side failure is raised (ops.CoopState.on_error; the host is synchronised there): the launches that
@@ -116,6 +127,7 @@ class FusedAdamAMSGrad(torch.optim.Optimizer):
         if flat_p is not self.flat_p:
             raise RuntimeError("the model was moved after the optimizer was built")
         self.t += 1
+        self.sync_lr()
         g = self.param_groups[0]
         eng = self.model._engine
         flag = eng.abort_flag() if eng is not None else None
@@ -124,10 +136,67 @@ class FusedAdamAMSGrad(torch.optim.Optimizer):
             self._hooked = eng._coop_state
         ops.adam_amsgrad(flat_p, flat_g, self.m, self.v, self.vmax, flat_p.numel(), g["lr"], self.t, gscale=gscale,
                          beta1=g["betas"][0], beta2=g["betas"][1], eps=g["eps"], abort_flag=flag,
-                         dropped=self.dropped if flag is not None else None)
+                         dropped=self.dropped if flag is not None else None, state=self.state)
 
     def zero_grad(self, set_to_none=False):
         pass  # every backward overwrites the whole bucket
+
+
+class GraphedTrainStep:
+    """One training step -- window gather -> RNN_VAE.loss_step (forward, losses, BPTT, weight gradients) -> fused Adam -- captured ONCE as a
+    hipGraph and replayed per batch.  At the reference's stock batch (256, vame/initialize_project/new.py:111) a step is ~160 short launches
+    and the host needs as long to enqueue them as the GPU to run them; a replay is one call.  What makes the step replayable: every launch
+    takes only device pointers and shape constants -- the cooperative GRU launches keep their epoch on the device, the reparameterisation
+    draws eps from a device-side Philox counter, Adam reads the learning rate and its step number from the device, the loss kernel
+    accumulates the epoch's statistics on the device -- and the window starts are uploaded into a fixed buffer before each replay.
+    Single rank only (the gradient all-reduce stays outside a graph).  Results are bit-identical to the eager step
+    (tests/test_train_driver_gpu.py::test_graphed_step_is_bit_identical_to_eager)."""
+
+    def __init__(self, model, optimizer, loader, acc, warmup=3, **loss_kwargs):
+        assert isinstance(optimizer, FusedAdamAMSGrad) and not _dist_active()
+        self.model, self.opt, self.loader, self.acc, self.kw = model, optimizer, loader, acc, loss_kwargs
+        self.dev = model.flat_parameters()[0].device
+        self.graph = None
+        self.terms = None
+        self.warmup = warmup
+
+    def _eager(self):
+        win = self.loader.gather_static()
+        terms = self.model.loss_step(win, acc=self.acc, **self.kw)
+        self.opt.step()
+        return terms
+
+    def _capture(self):
+        eng = self.model._ensure_engine(touch=False)
+        self.graph = torch.cuda.CUDAGraph()
+        eng.capturing = True
+        try:
+            # "relaxed": the launches' host side makes harmless runtime queries (occupancy, kernel attributes) that a stricter mode refuses
+            with torch.cuda.graph(self.graph, capture_error_mode="relaxed"):
+                self.terms = self._eager()
+        finally:
+            eng.capturing = False
+        self.opt.t -= 1                                  # (the capture ran the host part of one step without executing it)
+
+    def __call__(self, starts):
+        """One step on the windows starting at `starts`; returns the step's [rec, fut, kl, kmeans] (a device view that the next step overwrites)."""
+        self.loader.upload_starts(starts)
+        eng = self.model._engine
+        if self.warmup > 0 or self.dev.type != "cuda":   # the first steps run eagerly: workspaces, plans and caches settle before the capture
+            self.warmup -= 1
+            return self._eager()
+        if self.graph is None:
+            self._capture()
+        if eng is not None:
+            eng.poll_async_errors()
+        self.opt.sync_lr()
+        self.opt.t += 1
+        self.graph.replay()
+        if eng is not None:
+            if eng._coop_state is not None:
+                eng._coop_state.dirty = True
+            eng.snapshot_async_errors()
+        return self.terms
 
 
 def _world():
@@ -177,35 +246,60 @@ def _to_windows(item, keep, dev):
     return item.permute(0, 2, 1)[:, :keep, :].to(dtype=torch.float32).to(dev).contiguous()
 
 
+def _graphed_step_for(model, optimizer, loader, noise, hip_graph, kw):
+    """The cached GraphedTrainStep of this (model, optimizer, loader, loss arguments), or None where the step runs eagerly: several ranks (the
+    all-reduce stays outside a graph), options that draw with torch inside the step (input noise, encoder dropout), a loader that is not the
+    device batcher, hip_graph = False, or -- hip_graph = None, "auto" -- a batch above 1024, where the step is GPU-bound anyway."""
+    from .dataloader import DeviceWindowLoader
+    dev = model.flat_parameters()[0].device
+    if (hip_graph is False or dev.type != "cuda" or _dist_active() or noise == True or model.spec.dropout > 0  # noqa: E712
+            or not isinstance(optimizer, FusedAdamAMSGrad) or not isinstance(loader, DeviceWindowLoader) or loader.world != 1):
+        return None
+    if hip_graph in (None, "auto") and loader.B > 1024:
+        return None
+    cache = optimizer.__dict__.setdefault("_graphed_steps", {})
+    key = (id(loader), tuple(sorted((k, v) for k, v in kw.items())))
+    g = cache.get(key)
+    if g is None:
+        if len(cache) >= 8:                  # (KL annealing makes a few distinct weights, then one for the rest of the run)
+            cache.pop(next(iter(cache)))
+        acc = optimizer.__dict__.setdefault("_epoch_acc", torch.zeros(6, device=dev, dtype=torch.float64))
+        g = cache[key] = GraphedTrainStep(model, optimizer, loader, acc, **kw)
+    return g
+
+
 def train(train_loader, epoch, model, optimizer, anneal_function, BETA, kl_start, annealtime, seq_len, future_decoder,
-          future_steps, scheduler, mse_red, mse_pred, kloss, klmbda, bsize, noise):
+          future_steps, scheduler, mse_red, mse_pred, kloss, klmbda, bsize, noise, hip_graph=None):
     model.train()
     dev = model.flat_parameters()[0].device
     seq_len_half = int(seq_len / 2)
     keep = seq_len_half + (future_steps if future_decoder else 0)
     kl_weight = kl_annealing(epoch, kl_start, annealtime, anneal_function)
-    acc = torch.zeros(5, device=dev, dtype=torch.float64)     # total, rec, fut, kl, kmeans (summed over batches)
-    # total = rec + fut + BETA * kl_weight * kl + kl_weight * kmeans as ONE weighted sum per step (the stock batch is nearly host-bound:
-    # every small torch op in this loop is ~8 us of enqueue time)
-    wts = torch.tensor([1.0, 1.0, BETA * kl_weight, kl_weight], device=dev, dtype=torch.float32)
-    acc_total, acc_terms = acc[:1], acc[1:]
-    last = None
+    # total, rec, fut, kl, kmeans summed over the epoch's batches + the last batch's total: filled by the step's own loss kernel
+    # (vame_loss_finish_f32: total = rec + fut + BETA * kl_weight * kl + kl_weight * kmeans, rnn_vae.py:129-150) -- no torch op per step
+    acc = torch.zeros(6, device=dev, dtype=torch.float64)
+    wts = (1.0, 1.0, BETA * kl_weight, kl_weight)
     idx = -1
-    for idx, data_item in enumerate(train_loader):
-        win = _to_windows(data_item, keep, dev)
-        enc_in = gaussian(win[:, :seq_len_half, :], True, seq_len_half) if noise == True else None  # noqa: E712
-        terms = model.loss_step(win, kl_weight, beta=BETA, kloss=kloss, klmbda=klmbda, bsize=bsize, mse_red=mse_red,
-                                mse_pred=mse_pred, enc_in=enc_in)
-        gscale = allreduce_gradients(model)
-        optimizer.step(gscale=gscale) if isinstance(optimizer, FusedAdamAMSGrad) else optimizer.step()
-        total = torch.dot(terms, wts)
-        acc_total += total
-        acc_terms += terms
-        last = total
+    graphed = _graphed_step_for(model, optimizer, train_loader, noise, hip_graph,
+                                dict(kl_weight=kl_weight, beta=BETA, kloss=kloss, klmbda=klmbda, bsize=bsize, mse_red=mse_red, mse_pred=mse_pred, weights=wts))
+    if graphed is not None:
+        # host-bound regime (the stock batch 256): the whole step is one replayed hipGraph, the host only draws and uploads the window starts
+        acc = graphed.acc
+        acc.zero_()
+        for idx in range(len(train_loader)):
+            graphed(train_loader.draw_starts())
+    else:
+        for idx, data_item in enumerate(train_loader):
+            win = _to_windows(data_item, keep, dev)
+            enc_in = gaussian(win[:, :seq_len_half, :], True, seq_len_half) if noise == True else None  # noqa: E712
+            model.loss_step(win, kl_weight, beta=BETA, kloss=kloss, klmbda=klmbda, bsize=bsize, mse_red=mse_red,
+                            mse_pred=mse_pred, enc_in=enc_in, weights=wts, acc=acc)
+            gscale = allreduce_gradients(model)
+            optimizer.step(gscale=gscale) if isinstance(optimizer, FusedAdamAMSGrad) else optimizer.step()
     if idx < 1:
         raise ValueError("train(): need at least 2 batches per epoch (the reference divides by the last batch index, "
                          "rnn_vae.py:158,164); lower batch_size or provide more data")
-    acc = _rank_mean(torch.cat([acc, last.to(torch.float64).reshape(1)]))      # identical statistics (and decisions) on all ranks
+    acc = _rank_mean(acc)                                                      # identical statistics (and decisions) on all ranks
     scheduler.step(float(acc[5]))
     train_loss, mse_loss, fut_loss, kullback_loss, kmeans_losses = [float(v) for v in acc[:5].cpu()]
     if getattr(model, "_engine", None) is not None:
@@ -223,18 +317,15 @@ def test(test_loader, epoch, model, optimizer, BETA, kl_weight, seq_len, mse_red
     model.eval()
     dev = model.flat_parameters()[0].device
     seq_len_half = int(seq_len / 2)
-    acc5 = torch.zeros(5, device=dev, dtype=torch.float64)    # total, rec, (fut: not part of the test loss), kl, kmeans
-    wts = torch.tensor([1.0, 0.0, BETA * kl_weight, kl_weight], device=dev, dtype=torch.float32)
-    acc_total, acc_terms = acc5[:1], acc5[1:]
+    acc6 = torch.zeros(6, device=dev, dtype=torch.float64)    # total, rec, (fut: not part of the test loss), kl, kmeans, last total
+    wts = (1.0, 0.0, BETA * kl_weight, kl_weight)
     idx = -1
     with torch.no_grad():
         for idx, data_item in enumerate(test_loader):
             win = _to_windows(data_item, seq_len_half, dev)
-            terms = model.loss_step(win, kl_weight, beta=BETA, kloss=kloss, klmbda=klmbda, bsize=bsize, mse_red=mse_red,
-                                    backward=False)
-            acc_total += torch.dot(terms, wts)
-            acc_terms += terms
-    acc = acc5[[0, 1, 3, 4]]
+            model.loss_step(win, kl_weight, beta=BETA, kloss=kloss, klmbda=klmbda, bsize=bsize, mse_red=mse_red,
+                            backward=False, weights=wts, acc=acc6)
+    acc = acc6[[0, 1, 3, 4]]
     if idx < 1:
         raise ValueError("test(): need at least 2 test batches of batch_size/4 (rnn_vae.py:207-210 divides by the last index)")
     test_loss, mse_loss, kullback_loss, kmeans_losses = [float(v) for v in _rank_mean(acc).cpu()]
@@ -376,7 +467,8 @@ def train_model(config):
         print("Epoch: %d" % epoch)
         weight, train_loss, km_loss, kl_loss, mse_loss, fut_loss = train(
             train_loader, epoch, model, optimizer, anneal_function, BETA, KL_START, ANNEALTIME, TEMPORAL_WINDOW, FUTURE_DECODER,
-            FUTURE_STEPS, scheduler, MSE_REC_REDUCTION, MSE_PRED_REDUCTION, KMEANS_LOSS, KMEANS_LAMBDA, TRAIN_BATCH_SIZE, noise)
+            FUTURE_STEPS, scheduler, MSE_REC_REDUCTION, MSE_PRED_REDUCTION, KMEANS_LOSS, KMEANS_LAMBDA, TRAIN_BATCH_SIZE, noise,
+            hip_graph=cfg.get('vame_amd_hip_graph', 'auto'))           # optional key: true / false / auto (default: batches up to 1024)
         current_loss, test_loss, test_list = test(test_loader, epoch, model, optimizer, BETA, weight, TEMPORAL_WINDOW,
                                                   MSE_REC_REDUCTION, KMEANS_LOSS, KMEANS_LAMBDA, FUTURE_DECODER, TEST_BATCH_SIZE)
         train_losses.append(train_loss); test_losses.append(test_loss); kmeans_losses.append(km_loss)

@@ -16,6 +16,10 @@ KERNEL_AUTO, KERNEL_LOCKSTEP, KERNEL_WS, KERNEL_SKEWED = 0, 1, 2, 3
 
 
 def gru_opt(kernel=KERNEL_AUTO, pace_cp=-1, pace_ld=-1):
+    """The GF_OPT / GB_OPT word: kernel in bits 0-7, pacing values + 1 (0 = default) in bits 8-15 / 16-23."""
+    if not (0 <= int(kernel) < 16 and -1 <= int(pace_cp) < 255 and -1 <= int(pace_ld) < 255):      # (which kernels exist is the library's answer)
+        raise ValueError(f"gru_opt: kernel={kernel} (a kernel number < 16), pace_cp={pace_cp}, pace_ld={pace_ld} (-1 = default, or 0..254): "
+                         "the value would spill into the neighbouring field of the option word")
     return int(kernel) | ((pace_cp + 1 if pace_cp >= 0 else 0) << 8) | ((pace_ld + 1 if pace_ld >= 0 else 0) << 16)
 
 
@@ -245,9 +249,10 @@ class CoopState:
     def __init__(self, dev, ints=1 << 16):
         self.flags = torch.full((ints,), -7, dtype=torch.int32, device=dev)      # older than the first epoch, equal to no tag the first launches look for
         self.status = torch.zeros(1, dtype=torch.int32, device=dev)
+        # {launch epoch, ticket}: read and advanced by the kernels themselves (vame_gru_coop_fwd_f32), so that a captured graph can replay them
+        self.epoch = torch.tensor([1, 0], dtype=torch.int32, device=dev)
         self.shared = None
         self.on_error = []
-        self.epoch = 1
         self.dirty = False                                   # cooperative launches since the last check()
         self._host = [torch.zeros(1, dtype=torch.int32, pin_memory=dev.type == "cuda") for _ in range(2)]
         self._ev = [None, None]
@@ -255,9 +260,10 @@ class CoopState:
 
     def ensure_flags(self, ints):
         """Flag words + the forward kernel's tagged hand-off packets (vame_gru_coop_flag_ints).  A larger buffer starts out as if a launch
-        a few epochs back had left it behind: older than anything the next launch waits for, equal to no tag it will look for."""
+        a few epochs back had left it behind: older than anything the next launch waits for, equal to no tag it will look for.  (Reads
+        the device's epoch: a host sync, but only when the buffer grows -- the first launches of a shape.)"""
         if self.flags.numel() < ints:
-            stale = (self.epoch - 8) & 0xffffffff
+            stale = (int(self.epoch[0].item()) - 8) & 0xffffffff
             self.flags = torch.full((int(ints),), stale - (1 << 32) if stale >= (1 << 31) else stale, dtype=torch.int32, device=self.flags.device)
 
     def snapshot(self):
@@ -299,11 +305,6 @@ class CoopState:
             raise _lib.VameHipError(f"cooperative GRU kernel: {n} hand-off wait(s) timed out (workgroups of a group were not co-resident); "
                                     "the affected optimizer step was dropped on the device; set engine.coop = False "
                                     "(VAME_AMD_COOP=0) to use the batch-tile-persistent kernels")
-
-    def next_base(self, T):
-        b = self.epoch                                       # compared modulo 2^32 on the device (signed difference)
-        self.epoch = (self.epoch + T + 2) & 0xffffffff
-        return b - (1 << 32) if b >= (1 << 31) else b
 
     def check(self, reduce=None):
         """Host sync: raise if a cooperative launch ever gave up waiting for a group member (its results were undefined).
@@ -349,10 +350,9 @@ def gru_coop_fwd(streams, B, H, state: CoopState, rows=(0, 0), kernel=KERNEL_AUT
     d = _desc_tensor(streams, GF["N"])
     d[0, GF["OPT"]] = gru_opt(kernel, -1, -1)
     state.ensure_flags(_lib.lib().vame_gru_coop_flag_ints(len(streams), rows[1] or B, H))
-    T = max(int(s[GF["T"]]) for s in streams)
     state.dirty = True
-    rc = _lib.lib().vame_gru_coop_fwd_f32(d.data_ptr(), len(streams), B, H, rows[0], rows[1], _ptr(state.flags), state.next_base(T),
-                                          _ptr(state.status), _stream())
+    rc = _lib.lib().vame_gru_coop_fwd_f32(d.data_ptr(), len(streams), B, H, rows[0], rows[1], _ptr(state.flags), state.flags.numel(),
+                                          _ptr(state.epoch), _ptr(state.status), _stream())
     _lib.check(rc, "vame_gru_coop_fwd_f32")
 
 
@@ -362,10 +362,9 @@ def gru_coop_bwd(streams, B, H, state: CoopState, rows=(0, 0), kernel=KERNEL_AUT
     need = _lib.lib().vame_gru_coop_xbuf_floats(len(streams), rows[1] or B, H)
     if getattr(state, "xbuf", None) is None or state.xbuf.numel() < need:
         state.xbuf = torch.empty(need, device=state.flags.device)
-    T = max(int(s[GB["T"]]) for s in streams)
     state.dirty = True
-    rc = _lib.lib().vame_gru_coop_bwd_f32(d.data_ptr(), len(streams), B, H, rows[0], rows[1], _ptr(state.xbuf), _ptr(state.flags),
-                                          state.next_base(T), _ptr(state.status), _stream())
+    rc = _lib.lib().vame_gru_coop_bwd_f32(d.data_ptr(), len(streams), B, H, rows[0], rows[1], _ptr(state.xbuf), _ptr(state.flags), state.flags.numel(),
+                                          _ptr(state.epoch), _ptr(state.status), _stream())
     _lib.check(rc, "vame_gru_coop_bwd_f32")
 
 
@@ -418,10 +417,21 @@ def gru_cell_bwd(stash, st_off, st_row, dh, dy, dy_off, dy_row, dG, dg_off, dg_r
     _lib.check(rc, "vame_gru_cell_bwd_f32")
 
 
-def latent_fwd(mu, lv_raw, eps, B, Z, softplus, training, logvar, z, kl_out):
+def latent_fwd(mu, lv_raw, eps, B, Z, softplus, training, logvar, z, kl_out, rng=None):
+    """rng (int64[4] device tensor {seed, step, 0, 0}) in training mode: eps is the OUTPUT of the kernel's own N(0,1) draw and `step` advances on
+    the device; rng = None: eps is an input."""
     rc = _lib.lib().vame_latent_fwd_f32(_ptr(mu), _ptr(lv_raw), _ptr(eps), B, Z, int(softplus), int(training), _ptr(logvar),
-                                        _ptr(z), _ptr(kl_out), _stream())
+                                        _ptr(z), _ptr(kl_out), _ptr(rng), _stream())
     _lib.check(rc, "vame_latent_fwd_f32")
+
+
+_F4 = ctypes.c_float * 4
+
+
+def loss_finish(raw, scale, weights, with_fut, out, acc=None):
+    """raw (8 floats, consumed: zeroed) -> out[0:4] = terms x scale, out[4] = sum weights x terms; acc (float64[6]) += ... (vame_loss_finish_f32)."""
+    rc = _lib.lib().vame_loss_finish_f32(_ptr(raw), _F4(*scale), _F4(*weights), int(bool(with_fut)), _ptr(out), _ptr(acc), _stream())
+    _lib.check(rc, "vame_loss_finish_f32")
 
 
 def latent_bwd(dz, mu, logvar, lv_raw, eps, B, Z, softplus, ckl, dmu, dlv):
@@ -497,9 +507,10 @@ def colsum_batch(jobs):
         _lib.check(rc, "vame_colsum_batch_f32")
 
 
-def adam_amsgrad(p, g, m, v, vmax, n, lr, step, gscale=1.0, beta1=0.9, beta2=0.999, eps=1e-8, abort_flag=None, dropped=None):
+def adam_amsgrad(p, g, m, v, vmax, n, lr, step, gscale=1.0, beta1=0.9, beta2=0.999, eps=1e-8, abort_flag=None, dropped=None, state=None):
+    """state (int32[4] device tensor {lr as float bits, updates applied, 0, 0}): lr / step come from the device and the launch counts itself."""
     rc = _lib.lib().vame_adam_amsgrad_f32(_ptr(p), _ptr(g), _ptr(m), _ptr(v), _ptr(vmax), n, lr, beta1, beta2, eps, step,
-                                          gscale, _ptr(abort_flag), _ptr(dropped), _stream())
+                                          gscale, _ptr(abort_flag), _ptr(dropped), _ptr(state), _stream())
     _lib.check(rc, "vame_adam_amsgrad_f32")
 
 
