@@ -240,7 +240,7 @@ def check_adam_trajectory(dev):
         np.testing.assert_allclose(sd[k].cpu().numpy(), v, atol=2e-5, err_msg=k)
 
 
-def check_odd_dims_vs_oracle(dev, F=10, Z=7, H=32, T=9, FS=4, B=5):
+def check_odd_dims_vs_oracle(dev, F=10, Z=7, H=32, T=9, FS=4, B=5, expect=None):
     """Unaligned shapes (F, Z not multiples of 4; egocentric_data=False gives F = num_features - 2): exercises the scalar-load
     GEMM paths and the non-fused layer-0 input projection, against the numpy oracle (no golden needed)."""
     from oracle import vame_oracle as vo
@@ -252,6 +252,8 @@ def check_odd_dims_vs_oracle(dev, F=10, Z=7, H=32, T=9, FS=4, B=5):
     win = rng.standard_normal((B, T + FS, F)).astype(np.float32)
     eps = rng.standard_normal((B, Z)).astype(np.float32)
     out = model.loss_step(torch.from_numpy(win).to(dev), 0.7, beta=2.0, kloss=4, klmbda=0.3, bsize=B, eps=torch.from_numpy(eps).to(dev)).cpu().numpy()
+    if expect is not None:
+        expect(model._engine)
     spec = vo.Spec(T=T, F=F, Z=Z, H=H, FS=FS)
     cache = vo.FwdCache()
     x, xf = win[:, :T], win[:, T:]

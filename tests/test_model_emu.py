@@ -154,3 +154,15 @@ def test_round4_advisor_findings(emu, monkeypatch):
     d = torch.zeros(ops.GF["N"], dtype=torch.int64)
     d[ops.GF["OPT"]] = 1 << 24
     assert _lib.lib().vame_gru_seq_fwd_f32(d.data_ptr(), 1, 4, 32, None) == -1 and b"malformed option word" in _lib.lib().vame_last_error()
+
+
+def test_odd_multiples_of_32_between_256_and_512_run_the_wide_kernels(emu):
+    """round 5: hidden sizes 288 / 352 / 416 / 480 (nn.GRU takes any, rnn_model.py:34,91,125) used to fall to the per-step GEMM path at half the speed of
+    their neighbours; they now run the two-blocks-per-wave persistent kernels on a zero-padded image of the next multiple of 64 (vame_amd/padding.py) --
+    a whole train step (losses + all gradients in the reference's shapes) against the numpy oracle."""
+    from vame_amd.padding import pad32
+
+    def wide(eng):
+        assert eng.spec.H == 320 and eng._wide(eng.spec.H) and eng.wide_bwd and not eng.force_stepwise
+    assert [pad32(h) for h in (256, 288, 320, 352, 416, 480, 512, 544, 100)] == [256, 320, 320, 384, 448, 512, 512, 544, 128]
+    check_odd_dims_vs_oracle("cpu", F=12, Z=7, H=288, T=3, FS=2, B=5, expect=wide)

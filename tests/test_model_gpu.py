@@ -372,3 +372,15 @@ def test_round3_fast_path_matches_the_previous_path_over_an_adam_trajectory(hip)
     for k in finals[0]:
         a, b = finals[0][k], finals[1][k]
         assert np.abs(a - b).max() <= 1e-5 * np.abs(b).max(), (k, float(np.abs(a - b).max()), float(np.abs(b).max()))
+
+
+def test_odd_multiples_of_32_between_256_and_512_run_the_wide_kernels(hip):
+    """round 5: hidden sizes 288 / 352 / 416 / 480 (nn.GRU takes any, rnn_model.py:34,91,125) used to fall to the per-step GEMM path at half the speed of
+    their neighbours; they now run the two-blocks-per-wave persistent kernels on a zero-padded image of the next multiple of 64 (vame_amd/padding.py) --
+    a whole train step (losses + all gradients in the reference's shapes) against the numpy oracle."""
+    from vame_amd.padding import pad32
+
+    def wide(eng):
+        assert eng.spec.H == 320 and eng._wide(eng.spec.H) and eng.wide_bwd and not eng.force_stepwise
+    assert [pad32(h) for h in (256, 288, 320, 352, 416, 480, 512, 544, 100)] == [256, 320, 320, 384, 448, 512, 512, 544, 128]
+    check_odd_dims_vs_oracle("cuda", F=12, Z=7, H=288, T=3, FS=2, B=5, expect=wide)

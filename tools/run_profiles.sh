@@ -29,7 +29,8 @@ python tools/rocprof_digest.py pmc $O/raw_fetch4 $O/raw_write4 vame_amd/libvame_
   --cycle "gru_wide_skew_fwd_kernel<512>@262144=enc-l0,enc-l1,dec,fut" --cycle "gru_wide_bwd_kernel<512,false>@262144=dec,fut,enc-l1,enc-l0" \
   --key "gru_wide_fwd_kernel<512> x2 streams gi T=60=>gru_wide_skew_fwd_kernel<512>@262144[enc-l1]" --key "gru_wide_fwd_kernel<512> x2 streams const-gi T=60=>gru_wide_skew_fwd_kernel<512>@262144[dec]" \
   --key "gru_wide_fwd_kernel<512> x2 streams const-gi T=15=>gru_wide_skew_fwd_kernel<512>@262144[fut]" --key "gru_wide_bwd_kernel<512> x2 streams no-dy T=60=>gru_wide_bwd_kernel<512,false>@262144[enc-l1]" \
-  --key "gru_wide_bwd_kernel<512> x2 streams dy T=60=>gru_wide_bwd_kernel<512,false>@262144[enc-l0]"
+  --key "gru_wide_bwd_kernel<512> x2 streams dy T=60=>gru_wide_bwd_kernel<512,false>@262144[enc-l0]" \
+  --key "gemm_kernel TN M=1536 N=512 K=491520 x6 grouped=>gemm_kernel<128,128,2,2,true,true,5,2>@589824"
 python tools/rocprof_digest.py pmc $O/raw_fetche $O/raw_writee vame_amd/libvame_hip.so $O/embed_pmc_hbm_traffic.json \
   --key "gru_seq_fwd_kernel<256> x2 streams gi T=30 embed=>gru_skew_fwd_kernel<256,false>@524288"
 python tools/rocprof_digest.py sq $O/raw_sq $O/pmc_sq_cfg2.json "rocprofv3 --kernel-trace --pmc SQ_* GRBM_GUI_ACTIVE -- python bench.py --no-also --steps 2 --warmup 1 (BASELINE configs[1])"
@@ -39,7 +40,8 @@ for f in pmc_hbm_traffic cfg4_pmc_hbm_traffic embed_pmc_hbm_traffic; do cp $O/$f
 timeout 600 python bench.py --dump-kernels > $O/bench.json 2> $O/bench.err; cut -c1-250 $O/bench.json
 rm -f profiles/_this_run_*.json
 # the other committed lines of a round: stock-config batch, 10 M-window embedding, 100 timed steps, kernel tables, small-batch overlap A/B
-python bench.py --batch 256 --steps 60 --warmup 15 --no-cpu-baseline --no-also > $O/b256.json 2>/dev/null
+python bench.py --batch 256 --steps 200 --warmup 30 --no-cpu-baseline --no-also --graph > $O/b256.json 2>/dev/null
+python bench.py --batch 256 --steps 200 --warmup 30 --no-cpu-baseline --no-also > $O/b256_eager.json 2>/dev/null
 python bench.py --mode embed --embed-windows 10000000 --no-cpu-baseline > $O/embed10m.json 2>/dev/null
 python bench.py --steps 100 --warmup 20 --no-cpu-baseline --no-also > $O/bench_100steps.json 2>/dev/null
 python -u tools/fwd_table.py 2>&1 | grep -v amdgpu > $O/fwd_table.txt
@@ -49,4 +51,19 @@ python tools/step_ab.py 256 join=nuc_join_before_coop:1 nojoin=nuc_join_before_c
 python tools/clock_check.py 2>&1 | grep -v amdgpu > $O/clock_check.txt
 python tools/coop_bench.py 2>&1 | grep -v amdgpu > $O/coop_bench.txt
 python tools/coop_probe.py 2>&1 | grep -v amdgpu > $O/coop_probe.txt
+ls -la $O
+# round 5: the opt-in split-bf16 weight-gradient contraction (error table vs float64, timing; ablations and the other mappings on the tuning build),
+# the MFMA / VALU overlap probe, throughput over batch and hidden sizes, the configs[3] grouped GEMM's traffic over split-K, the stock-batch
+# step as a replayed hipGraph (per-dispatch trace), and the kernel names of a whole train_model() + pose_segmentation() run
+python tools/split_gemm_bench.py 2>&1 | grep -v amdgpu > $O/split_gemm_error_table.txt
+VAME_LIB=tools/libvame_hip_ab.so python tools/split_abl.py 20 2>&1 | grep -v amdgpu > $O/split_abl.txt
+./tools/mfma_valu_overlap_probe > $O/mfma_valu_overlap_probe.txt 2>&1
+python tools/shape_table.py both 2>&1 | grep -v amdgpu > $O/shape_table.txt
+bash tools/traffic_gemm_cfg3.sh ${1:-prof}/gemm3 8 16 32 64 96 > /dev/null 2>&1; cat $O/gemm3/times.txt $O/gemm3/traffic.txt > $O/cfg3_gemm_splitk_traffic.txt; rm -rf $O/gemm3
+bash tools/trace_b256.sh ${1:-prof}/b256_graph 256 --graph > /dev/null 2>&1; cp $O/b256_graph/kernel_trace.csv $O/b256_graph_kernel_trace.csv; rm -rf $O/b256_graph
+cd /tmp && export TMPDIR=/tmp
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/raw_demo -- python $GRAFT_REPO_ROOT/tools/demo_project.py 256 train-only > $O/demo_trace.log 2>&1
+cd $GRAFT_REPO_ROOT
+python tools/rocprof_digest.py stats $O/raw_demo $O/train_model_kernel_stats.csv; rm -rf $O/raw_demo
+python tools/demo_project.py 256 2>&1 | grep DEMO > $O/demo_project.txt; python tools/demo_project.py 4096 2>&1 | grep DEMO >> $O/demo_project.txt
 ls -la $O

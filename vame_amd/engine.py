@@ -108,7 +108,7 @@ class Workspace:
 
 # Scheduling / kernel-choice options of an engine: CONSTRUCTOR ARGUMENTS (VAEEngine(..., options={...}); RNN_VAE(...).engine_options;
 # the optional `vame_amd_engine:` mapping of config.yaml, vame_amd/model/rnn_vae.py) -- never the process environment.  The defaults are
-# the measured best; the A/B tools translate their VAME_AMD_* variables with tools/engine_env.py.
+# the measured best; the A/B tools set them by name (tools/step_ab.py B name=option:value,...; tools/shape_table.py SHAPE_ENGINE=option:value).
 ENGINE_DEFAULTS = dict(
     group_wgrads=True,     # same-shape weight-gradient contractions leave as grouped launches (_group_wgrads)
     fuse_heads=False,      # output Linear + MSE + their backward per decoder in ONE kernel (vame_head_fused_f32): measured 159 us against
@@ -117,6 +117,7 @@ ENGINE_DEFAULTS = dict(
     wgrad_streams=0,       # 0 = auto: 4 streams up to batch 1024, ONE above (two give +1.5 % at batch 4096, but two large GEMMs sharing the
                            # chip each take twice as long, which makes per-kernel durations unreadable); 1 = caller's stream only
     coop=True,             # column-split GRU kernels for batches that leave most CUs idle (_coop_parts); False keeps the persistent ones
+    coop_rounds=3,         # at most this many cooperative launches (row ranges) per stream set before the batch-tile-persistent kernels take over
     wide=True,             # 256 < H <= 512: persistent two-blocks-per-wave kernels (gru_wide.hip) instead of the per-step GEMM path
     wide_bwd=True,         # ... for BPTT too (False: step by step: per-step GEMM + gate kernel)
     nuc_side=True,         # nuclear-norm solve on a side stream next to the output heads
@@ -169,6 +170,7 @@ class VAEEngine:
         self.small_streams = int(opt["small_streams"])
         self.wgrad_streams = int(opt["wgrad_streams"])
         self.coop = bool(opt["coop"])
+        self.coop_rounds = int(opt["coop_rounds"])
         self.wide = bool(opt["wide"])
         self.wide_bwd = bool(opt["wide_bwd"])
         self.split_wgrad = None if opt["split_wgrad"] is None else int(opt["split_wgrad"])
@@ -530,13 +532,13 @@ class VAEEngine:
             return []
         steps = lambda r: int(r[tkey]) if (r and tkey is not None) else 1                    # noqa: E731
         # the cover depends on (stream count, their lengths, batch, hidden size) only: decided once per signature
-        sig = (len(rows), tuple(steps(r) for r in rows), B, H)
+        sig = (len(rows), tuple(steps(r) for r in rows), B, H, self.coop_rounds)
         cover = self._coop_covers.get(sig)
         if cover is None:
             idx = list(range(len(rows)))
-            options = [([idx], ops.coop_row_chunks(len(rows), B, H))]
+            options = [([idx], ops.coop_row_chunks(len(rows), B, H, self.coop_rounds))]
             if len(rows) > 2 and len(rows) % 2 == 0:                   # decoder + future decoder: one pair of directions each
-                options.append(([idx[i:i + 2] for i in range(0, len(rows), 2)], ops.coop_row_chunks(2, B, H)))
+                options.append(([idx[i:i + 2] for i in range(0, len(rows), 2)], ops.coop_row_chunks(2, B, H, self.coop_rounds)))
             options = [(sets, ch) for sets, ch in options if ch]
             if options:
                 # every launch lasts as long as its longest sequence: pick the cover with the fewest (launch x step) slots

@@ -3,7 +3,7 @@
 torch.nn.GRU takes any `hidden_size` (reference rnn_model.py:34,91,125: `hidden_size_layer_1`, `hidden_size_rec`,
 `hidden_size_pred` come straight from config.yaml), while the gfx950 GRU kernels tile hidden units in blocks of 32.  For such a
 model the parameters keep the reference's shapes (state_dict, checkpoints, optimizer state, the all-reduced gradient bucket) and the
-kernels run on a ZERO-PADDED IMAGE of them: every hidden size is rounded up to the next multiple of 32 and each block of H rows /
+kernels run on a ZERO-PADDED IMAGE of them: every hidden size is rounded up to the next multiple of 32 (of 64 between 256 and 512: pad32) and each block of H rows /
 columns that indexes hidden units is laid out as H real entries followed by zeros.  A padded unit has zero input weights, zero
 recurrent weights and zero biases, so r = u = 1/2, n = tanh(0) = 0 and h' = u h = 0 for all steps (its initial state is 0 too: the
 padded rows of latent_to_hidden are zero), nothing downstream reads it (zero columns), and the real units see exactly the
@@ -18,11 +18,18 @@ from .engine import ParamTable, Spec
 
 
 def pad32(h):
-    return (int(h) + 31) // 32 * 32
+    """The hidden size the kernels run a true size h on: the next multiple of 32 -- and, between 256 and 512, of 64: the persistent kernels of
+    that range give a wave two 32-column blocks (gru_wide.hip: 320 / 384 / 448 / 512), and the per-step GEMM path that an odd multiple of 32
+    would otherwise take is half as fast (288: 48 TF against 85 at 320 on one MI355X, profiles/r05_shape_table.txt) -- the 11-23 % of padded
+    flops cost far less."""
+    hp = (int(h) + 31) // 32 * 32
+    if 256 < hp <= 512 and hp % 64:
+        hp += 32
+    return hp
 
 
 def needs_padding(spec: Spec):
-    return any(h % 32 for h in (spec.H, spec.Hd, spec.Hf))
+    return any(pad32(h) != h for h in (spec.H, spec.Hd, spec.Hf))
 
 
 def _blocks(name, shape, spec: Spec):
@@ -56,7 +63,7 @@ def _blocks(name, shape, spec: Spec):
 def _pad_index(n, h):
     """Positions of n consecutive true indices inside the padded dimension (blocks of h -> pad32(h))."""
     i = torch.arange(n, dtype=torch.int64)
-    if not h or h % 32 == 0:
+    if not h or pad32(h) == h:
         return i, n
     assert n % h == 0, (n, h)
     hp = pad32(h)
