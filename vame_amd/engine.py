@@ -122,7 +122,8 @@ ENGINE_DEFAULTS = dict(
     wide_bwd=True,         # ... for BPTT too (False: step by step: per-step GEMM + gate kernel)
     nuc_side=True,         # nuclear-norm solve on a side stream next to the output heads
     bwd_overlap=True,      # the future decoder's two dW_hh contractions beside the small-kernel chain behind the decoders' BPTT launch
-    skinny_side=True,      # narrow weight gradients (an output dimension <= 32) on a side stream beside the wide ones
+    skinny_side=False,     # narrow weight gradients (an output dimension <= 32) on a side stream beside the wide ones: measured +-0 at batch 256 /
+                           # 1024 / 4096 in round 5 (tools/step_ab.py: 14.387 vs 14.392 ms) while it doubles both kernels' durations in every trace -> off
     split_wgrad=None,      # None = the f32-input matrix cores (default).  An int = the `opt` word of vame_gemm_group_bf16x6_f32 (0 = its
                            # defaults): the large grouped weight gradients (two k-major operands, N > 64, K >= 8192) run as the
                            # error-compensated split-bf16 contraction (bf16x6 planes, fp32 accumulate).  OPT-IN.
