@@ -103,6 +103,7 @@ class Workspace:
         if t is None or t.numel() < numel or t.device != dev:
             t = (torch.zeros if zero else torch.empty)(int(numel), device=dev, dtype=dtype)
             self.t[name] = t
+            ops.ALLOC_GEN[0] += 1             # (a captured step graph holds the old address: see ops.ALLOC_GEN)
         return t
 
 

@@ -158,6 +158,7 @@ class GraphedTrainStep:
         self.dev = model.flat_parameters()[0].device
         self.graph = None
         self.terms = None
+        self._seen = None
         self.warmup = warmup
 
     def _eager(self):
@@ -177,6 +178,7 @@ class GraphedTrainStep:
         finally:
             eng.capturing = False
         self.opt.t -= 1                                  # (the capture ran the host part of one step without executing it)
+        self._seen = (eng, ops.ALLOC_GEN[0], self.model._flat_p.data_ptr())
 
     def __call__(self, starts):
         """One step on the windows starting at `starts`; returns the step's [rec, fut, kl, kmeans] (a device view that the next step overwrites)."""
@@ -184,6 +186,11 @@ class GraphedTrainStep:
         eng = self.model._engine
         if self.warmup > 0 or self.dev.type != "cuda":   # the first steps run eagerly: workspaces, plans and caches settle before the capture
             self.warmup -= 1
+            return self._eager()
+        if self.graph is not None and self._seen != (eng, ops.ALLOC_GEN[0], self.model._flat_p.data_ptr()):
+            # a buffer the captured launches point into was reallocated since (another batch size grew a workspace, the model moved):
+            # run this step eagerly -- which settles the buffers for this shape again -- and capture afresh on the next call
+            self.graph = None
             return self._eager()
         if self.graph is None:
             self._capture()

@@ -53,12 +53,17 @@ class Operand:
 
 
 _ws_cache = {}
+# Bumped whenever a scratch / workspace buffer that launches keep addresses of is (re)allocated -- by this module's caches, by
+# engine.Workspace, by CoopState.  A captured step graph holds such addresses: rnn_vae.GraphedTrainStep compares the value it saw at capture
+# time and captures again when it moved (e.g. an embedding pass with a larger batch grew the engine's workspace between two epochs).
+ALLOC_GEN = [0]
 
 
 def _auto_ws(dev, n):
     t = _ws_cache.get(dev)
     if t is None or t.numel() < n:
         t = _ws_cache[dev] = torch.empty(max(n, 1 << 20), device=dev)
+        ALLOC_GEN[0] += 1
     return t
 
 
@@ -265,6 +270,7 @@ class CoopState:
         if self.flags.numel() < ints:
             stale = (int(self.epoch[0].item()) - 8) & 0xffffffff
             self.flags = torch.full((int(ints),), stale - (1 << 32) if stale >= (1 << 31) else stale, dtype=torch.int32, device=self.flags.device)
+            ALLOC_GEN[0] += 1
 
     def snapshot(self):
         """Enqueue a copy of the status word to the host (end of a step); never blocks."""
@@ -362,6 +368,7 @@ def gru_coop_bwd(streams, B, H, state: CoopState, rows=(0, 0), kernel=KERNEL_AUT
     need = _lib.lib().vame_gru_coop_xbuf_floats(len(streams), rows[1] or B, H)
     if getattr(state, "xbuf", None) is None or state.xbuf.numel() < need:
         state.xbuf = torch.empty(need, device=state.flags.device)
+        ALLOC_GEN[0] += 1
     state.dirty = True
     rc = _lib.lib().vame_gru_coop_bwd_f32(d.data_ptr(), len(streams), B, H, rows[0], rows[1], _ptr(state.xbuf), _ptr(state.flags), state.flags.numel(),
                                           _ptr(state.epoch), _ptr(state.status), _stream())
@@ -494,6 +501,7 @@ def colsum(inp, in_off, R, C, ld, out, out_off=0, accumulate=False):
     ws = _colsum_ws.get(inp.device)
     if ws is None or ws.numel() < need:
         ws = _colsum_ws[inp.device] = torch.empty(max(need, 1 << 16), device=inp.device)
+        ALLOC_GEN[0] += 1
     rc = _lib.lib().vame_colsum_f32(_ptr(inp, in_off), R, C, ld, _ptr(out, out_off), int(accumulate), _ptr(ws), _stream())
     _lib.check(rc, "vame_colsum_f32")
 
