@@ -278,7 +278,7 @@ class VAEEngine:
             torch.cuda.current_stream(self.dev).wait_stream(self._early_stream)
             self._early_pending = False
 
-    def _group_wgrads(self, jobs, ws_name="splitk_group", after_first=None):
+    def _group_wgrads(self, jobs, ws_name="splitk_group", after_first=None, deferred=None):
         """Weight-gradient GEMMs of one shape and operand layout -- the dW_hh of the six
         T-step (layer, direction) streams, the two layer-1 dW_ih, the future decoder's two dW_hh -- go out as ONE grouped launch
         each (vame_gemm_group_f32): all their k-slabs are dealt to the XCDs together, so nothing idles at the boundary between
@@ -292,15 +292,23 @@ class VAEEngine:
         if plan is None:
             plan = self._wgrad_plans[sig] = self._plan_wgrads(jobs)
         launches, rest_idx = plan
-        for grp, idx, M, N, K, sk, gap_at, gap, c_offs in launches:
-            if grp == 1 and after_first is not None:
+
+        def launcher(grp, idx, M, N, K, sk, gap_at, gap, c_offs):
+            def run(ws_name_=ws_name):
+                ws = self.ws.get(ws_name_, len(idx) * sk * M * N, self.dev)
+                As, Bs = [jobs[i][3] for i in idx], [jobs[i][4] for i in idx]
+                split = self.split_wgrad if (self.split_wgrad is not None and N > 64 and M >= 128 and K >= 8192
+                                             and ops.gemm_split_ok(M, N, K, As, Bs, sk, gap_at, gap)) else None
+                ops.gemm_group(M, N, K, As, 1, Bs, 1, self.g, c_offs, N, sk, ws, a_gap_at=gap_at, a_gap=gap, split=split)
+            return (float(M) * N * K * len(idx), run)
+        if deferred is not None:               # the caller spreads the grouped launches over its streams together with the single ones
+            deferred += [launcher(*L) for L in launches]
+            return [jobs[i] for i in rest_idx]
+        for L in launches:
+            if L[0] == 1 and after_first is not None:
                 after_first()
                 after_first = None
-            ws = self.ws.get(ws_name, len(idx) * sk * M * N, self.dev)
-            As, Bs = [jobs[i][3] for i in idx], [jobs[i][4] for i in idx]
-            split = self.split_wgrad if (self.split_wgrad is not None and N > 64 and M >= 128 and K >= 8192
-                                         and ops.gemm_split_ok(M, N, K, As, Bs, sk, gap_at, gap)) else None
-            ops.gemm_group(M, N, K, As, 1, Bs, 1, self.g, c_offs, N, sk, ws, a_gap_at=gap_at, a_gap=gap, split=split)
+            launcher(*L)[1]()
         return [jobs[i] for i in rest_idx]
 
     def _plan_wgrads(self, jobs):
@@ -437,7 +445,11 @@ class VAEEngine:
                 for j in self._group_wgrads(skinny, ws_name="splitk_skinny"):
                     self._gemm_wgrad_now(*j, lane="_sk")
             self._early_pending = True
-        jobs = self._group_wgrads(jobs, after_first=start_skinny)                  # same-shape contractions leave as grouped launches first
+        # several streams and a batch up to 512: the grouped launches are spread over the streams as well -- at batch 256 each is 0.75-1.5 rounds
+        # of workgroups with a tail (180 + 106 us back to back), side by side they fill each other's (batch 128 / 256 / 384: +5 / +3 / +2 % of the
+        # step with the bias sums' move; at 768 / 1024 two such launches sharing the chip cost 1.5-2 %, so there they stay in sequence)
+        grouped = [] if (n >= 2 and (self._B_bwd or 0) <= 512) else None
+        jobs = self._group_wgrads(jobs, after_first=start_skinny, deferred=grouped)   # same-shape contractions leave as grouped launches first
         if skinny and not self._early_pending:
             start_skinny()
         if skinny:
@@ -445,27 +457,35 @@ class VAEEngine:
                 self._gemm_wgrad(*j)
             self._join_early()
             return
-        if n < 2 or len(jobs) < 2:
+        if n < 2 or len(jobs) + len(grouped or ()) < 2:
+            for _, run in (grouped or ()):
+                run()
             for j in jobs:
                 self._gemm_wgrad(*j)
             return
         while len(self._side_streams) < n - 1:
             self._side_streams.append(_side_stream(self.dev, len(self._side_streams)))
         main = torch.cuda.current_stream(self.dev)
-        jobs.sort(key=lambda j: -j[0] * j[1] * j[2])
-        lanes, load = [[] for _ in range(n)], [0] * n
-        for j in jobs:                                   # greedy balance by flops
+        items = list(grouped) + [(float(j[0]) * j[1] * j[2], j) for j in jobs]
+        items.sort(key=lambda it: -it[0])
+        lanes, load = [[] for _ in range(n)], [0.0] * n
+        for fl, it in items:                             # greedy balance by flops
             k = load.index(min(load))
-            lanes[k].append(j)
-            load[k] += j[0] * j[1] * j[2]
+            lanes[k].append(it)
+            load[k] += fl
+
+        def run_lane(k):
+            for it in lanes[k]:
+                if callable(it):
+                    it(f"splitk_group_l{k}")             # (a lane's launches are ordered: they share the lane's split-K scratch)
+                else:
+                    self._gemm_wgrad(*it, lane=k)
         for side in self._side_streams[:n - 1]:
             side.wait_stream(main)
-        for j in lanes[0]:
-            self._gemm_wgrad(*j, lane=0)
+        run_lane(0)
         for k, side in enumerate(self._side_streams[:n - 1], start=1):
             with torch.cuda.stream(side):
-                for j in lanes[k]:
-                    self._gemm_wgrad(*j, lane=k)
+                run_lane(k)
         for side in self._side_streams[:n - 1]:
             main.wait_stream(side)
 
@@ -930,6 +950,16 @@ class VAEEngine:
         self._colsum_jobs += [(dbias, 0, ntiles, 3 * H, 4 * H, g, ob_i), (dbias, 0, ntiles, 2 * H, 4 * H, g, ob_h),
                               (dbias, 3 * H, ntiles, H, 4 * H, g, ob_h + 2 * H)]
 
+    def _bias_colsum(self, src, R, C, g_off):
+        """Bias gradient = column sum of a dense (R, C) gradient that stays intact until the end of backward().  Small batches: joins the ONE
+        batched launch that closes the backward pass (nothing reads flat_g before the optimizer) instead of two launches in the middle of the
+        latency-bound chain between the decoders' and the encoder's BPTT launches (batch 256: 8 launches of ~5 us off that chain); large
+        batches keep the two-pass reduction (the batched kernel walks a job's rows with four threads per column)."""
+        if R <= 1024:
+            self._colsum_jobs.append((src, 0, R, C, C, self.g, g_off))
+        else:
+            ops.colsum(src, 0, R, C, C, self.g, g_off)
+
     def _decoder_backward(self, tag, name, dirs, steps, dpred, B, dz, first):
         H, F, Z, t = dirs[0].H, self.spec.F, self.spec.Z, self.table
         ntiles = (B + 31) // 32
@@ -989,7 +1019,7 @@ class VAEEngine:
             if dhid is not None:
                 wl = f"{name}.latent_to_hidden.weight"
                 self._gemm_wgrad(2 * H, Z, B, Operand(dhid, 2 * H), Operand(z, Z), wl)
-                ops.colsum(dhid, 0, B, 2 * H, 2 * H, self.g, t.off(f"{name}.latent_to_hidden.bias"))
+                self._bias_colsum(dhid, B, 2 * H, t.off(f"{name}.latent_to_hidden.bias"))
                 dz_jobs.append((2 * H, Operand(dhid, 2 * H), self.P(wl, Z)))
         if ev_dec is not None:
             Hf_, Kf = s.Hf, B * FS
@@ -1017,7 +1047,7 @@ class VAEEngine:
         dhn = self.buf("dhn", B, 4 * H)
         for nm, dv, first in (("lmbda.hidden_to_mean", dmu, True), ("lmbda.hidden_to_logvar", dlv, False)):
             self._gemm_wgrad(Z, 4 * H, B, Operand(dv, Z), Operand(hn, 4 * H), nm + ".weight")
-            ops.colsum(dv, 0, B, Z, Z, self.g, t.off(nm + ".bias"))
+            self._bias_colsum(dv, B, Z, t.off(nm + ".bias"))
             ops.gemm(B, 4 * H, Z, Operand(dv, Z), 0, self.P(nm + ".weight", 4 * H), 1, dhn, 4 * H, accumulate=not first)
         # ---- encoder layer 1
         Y0, Y1 = self.buf("Y0", B, T + 2, 2 * H), self.buf("Y1", B, T + 2, 2 * H)
