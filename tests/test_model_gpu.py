@@ -384,3 +384,11 @@ def test_odd_multiples_of_32_between_256_and_512_run_the_wide_kernels(hip):
         assert eng.spec.H == 320 and eng._wide(eng.spec.H) and eng.wide_bwd and not eng.force_stepwise
     assert [pad32(h) for h in (256, 288, 320, 352, 416, 480, 512, 544, 100)] == [256, 320, 320, 384, 448, 512, 512, 544, 128]
     check_odd_dims_vs_oracle("cuda", F=12, Z=7, H=288, T=3, FS=2, B=5, expect=wide)
+
+
+@pytest.mark.parametrize("B,T", [(128, 30), (768, 6), (1100, 6)])
+def test_weight_gradient_flush_forms_by_batch(hip, B, T):
+    """The three forms of the weight-gradient flush (engine._flush_wgrads) on the device, each a whole train step against the numpy oracle: up to batch 512
+    the grouped launches are spread over the four flush streams together with the single ones, up to 1,024 they stay in sequence on the caller's stream
+    with the singles on four streams, above that everything is one stream."""
+    check_odd_dims_vs_oracle("cuda", F=12, Z=30, H=64, T=T, FS=3, B=B)

@@ -51,12 +51,19 @@ rows = [("f32 MFMA kernel (vame_gemm_group_f32)", None),
         ("  reads + MFMA only", 1 | (12 << 8)), ("  barriers only", 1 | (13 << 8)),
         ("variant: 4 MFMA + 4 split waves, 3 LDS images, 2 acc", 8), ("  consumers idle (producers alone)", 8 | (1 << 8)), ("  producers load only, consumers idle", 8 | (5 << 8)),
         ("  consumers alone", 8 | (12 << 8)),
-        ("variant: 256 x 128 tiles, 8 waves, 2 images, 2 acc", 128), ("  loads only", 128 | (5 << 8)), ("  split + store only", 128 | (9 << 8)), ("  reads + MFMA only", 128 | (12 << 8)),
+        ("variant: 256 x 128 tiles, 8 waves, 2 images, 2 acc", 128),
+        ("variant: 256 x 128, hand-ordered stream (1 acc)", 128 | 16 | 1), ("  loads only", 128 | (5 << 8)), ("  split + store only", 128 | (9 << 8)), ("  reads + MFMA only", 128 | (12 << 8)),
         ("variant: 4 MFMA + 8 split waves, 3 images, 1 acc", 4), ("  consumers idle (producers alone)", 4 | (1 << 8)), ("  loads only, consumers idle", 4 | (5 << 8)),
         ("  split + store only", 4 | (9 << 8)), ("  consumers alone", 4 | (12 << 8))]
+ref = None
 for label, opt in rows:
     try:
         ms, mhz = t(opt)
+        if opt is None:
+            ref = C.clone()
+        elif (opt >> 8) == 0 and ref is not None:          # a complete (un-ablated) split form: its result against the f32-input kernel's
+            err = float((C - ref).abs().max() / ref.abs().max())
+            label = f"{label} [max diff vs f32 kernel {err:.1e}]"
         print(f"{label:60s} {ms:8.3f} ms  {2.0 * M * N * K * n / ms / 1e9:8.1f} TF   shader clock {mhz or 0:6.0f} MHz")
     except Exception as e:               # the product build refuses the ablation bits
         print(f"{label:60s} refused: {str(e)[:80]}")

@@ -779,7 +779,7 @@ extern "C" int vame_gemm_group_f32(int count, int M, int N, int K, const float* 
 // the f32-input kernel's (one rounding per K = 16 block instead of sixteen); with one accumulator for all six products (NACC = 1) it is
 // the f32-input kernel's level.  6/16 of the f32-input MFMA's pipe time per flop.
 //
-// Mapping (the fastest of four that were built and measured, see below): 128 x 128 output tile, BK = 32, 256-thread workgroups of FOUR
+// Mapping (the fastest of five that were built and measured, see below): 128 x 128 output tile, BK = 32, 256-thread workgroups of FOUR
 // SYMMETRIC waves, two (NACC = 2) or three (NACC = 1) workgroups per CU.  Per k-tile every wave
 //   1. splits its share of the tile -- operand wave >> 1, rows [16 (wave & 1), + 16), a lane owns two adjacent columns: 16
 //      buffer_load_dwordx2 of wave-uniform rows (the two-level (batch, time) row offsets are computed once per k-tile on 16 lanes and handed
@@ -797,10 +797,11 @@ extern "C" int vame_gemm_group_f32(int count, int M, int N, int K, const float* 
 // or the number of waves in flight (~10.6 TB/s L2 -> L1); (b) the split is 576 VALU wave-instructions per CU and k-tile; one wave issues
 // them at 7-8 cycles each and at 14 beside another wave's MFMAs (v_pk_add_f32 15.5), so they need every wave of the CU; (c) the planes are
 // 48 KB of ds_write_b128 per k-tile at ~73 B/clk; (d) with MFMAs, L2 traffic and VALU all active the shader clock falls to 1.9-2.1 GHz
-// (f32-input kernel: 2.2).  Three other mappings measured 12-19 % slower and live in tools/gemm_split_variants.inc (tuning build only):
+// (f32-input kernel: 2.2).  Four other mappings measured 12-35 % slower and live in tools/gemm_split_variants.inc (tuning build only):
 // wave-specialised 4 MFMA + 4 split waves with three LDS images (2.0 ms: one split wave per SIMD is VALU-issue-bound), 256 x 128 tiles with
 // eight waves and two images (1.85 ms: 6.8 GB through the L1s, but the phases of a wave's in-order stream do not overlap), 4 MFMA + 8 split
-// waves (1.89 ms: the MFMA stream alone runs at 0.77 ms = 34 cycles per MFMA with one fragment read between the MFMAs, the producers need 1.06).
+// waves (1.89 ms: the MFMA stream alone runs at 0.77 ms = 34 cycles per MFMA with one fragment read between the MFMAs, the producers need 1.06), and the
+// 256 x 128 mapping as one hand-ordered instruction stream per interval (2.09 ms).
 // =====================================================================================================================================
 namespace split6 {
 constexpr int BK = 32, TILE = 128;
@@ -948,7 +949,7 @@ __device__ __forceinline__ void cons_mfma(const Frags& f, f32x16 (&acc)[NACC][2]
 #ifdef VAME_TUNING_BUILD      // timing-only ablations (tools/split_abl.py; results are garbage): opt bits 8.. = 1 no fragment reads / MFMAs, 2 fragment
 #define SPLIT_ABL_MASK 0x3f00      // reads but no MFMAs, 4 no split / LDS stores, 8 no global loads, 16 split but no LDS stores, 32 the loads as dwordx4
 #define SPLIT_ABL(opt) (((opt) & SPLIT_ABL_MASK) >> 8)
-#define SPLIT_VARIANT_MASK 0x8c   // bits 2, 3, 7: the other mappings (tools/gemm_split_variants.inc)
+#define SPLIT_VARIANT_MASK 0x9c   // bits 2, 3, 7 (+ 4): the other mappings (tools/gemm_split_variants.inc)
 #else
 #define SPLIT_ABL_MASK 0
 #define SPLIT_ABL(opt) 0
@@ -1100,7 +1101,8 @@ extern "C" int vame_gemm_group_bf16x6_f32(int count, int M, int N, int K, const 
         else if (opt & 128) {
             p.tiles_m = (int)cdiv64(M, 2 * split6::TILE);
             grid = dim3((unsigned)(cdiv64(nunits, 8) * p.tiles_m * p.tiles_n * 8));
-            if (nacc == 2) hipLaunchKernelGGL(gemm_split_wide_kernel<2>, grid, dim3(512), 0, st, p, opt);
+            if (opt & 16) hipLaunchKernelGGL(gemm_split_wide_il_kernel, grid, dim3(512), 0, st, p, opt);
+            else if (nacc == 2) hipLaunchKernelGGL(gemm_split_wide_kernel<2>, grid, dim3(512), 0, st, p, opt);
             else hipLaunchKernelGGL(gemm_split_wide_kernel<1>, grid, dim3(512), 0, st, p, opt);
         } else if (nacc == 2) hipLaunchKernelGGL(gemm_split8_kernel<2>, grid, dim3(512), 0, st, p, opt);
         else hipLaunchKernelGGL(gemm_split8_kernel<1>, grid, dim3(512), 0, st, p, opt);

@@ -466,7 +466,7 @@ class VAEEngine:
         while len(self._side_streams) < n - 1:
             self._side_streams.append(_side_stream(self.dev, len(self._side_streams)))
         main = torch.cuda.current_stream(self.dev)
-        items = list(grouped) + [(float(j[0]) * j[1] * j[2], j) for j in jobs]
+        items = list(grouped or ()) + [(float(j[0]) * j[1] * j[2], j) for j in jobs]
         items.sort(key=lambda it: -it[0])
         lanes, load = [[] for _ in range(n)], [0.0] * n
         for fl, it in items:                             # greedy balance by flops
