@@ -1,4 +1,5 @@
 # Round profile pass on the MI355X: bench line, rocprofv3 kernel trace, PMC HBM traffic (separate FETCH / WRITE passes), SQ counters.
+# build first, in the build container: make -j vame_amd/libvame_hip.so ab probe && hipcc --offload-arch=gfx950 -O3 -w tools/mfma_valu_overlap_probe.hip -o tools/mfma_valu_overlap_probe
 # usage (GPU box): bash tools/run_profiles.sh <outdir-name>      -> gpurun_out/<outdir-name>/  (copy what is to be judged into profiles/)
 cd $GRAFT_REPO_ROOT
 O=$GRAFT_REPO_ROOT/gpurun_out/${1:-prof}
