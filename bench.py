@@ -102,11 +102,20 @@ class KernelTimer:
         return inner
 
     def summary(self):
+        """Sums per kernel key.  A launch whose event pair reads more than 20x the median of its key's launches is counted at that median and
+        reported in `timer_outliers` (one 3-step run on a gpurun box once put the dominant row 1000x low, not reproduced since: one bad pair is
+        enough for that); nothing else is filtered."""
         torch.cuda.synchronize()
-        agg = {}
-        for name, (key, work), e0, e1, probe in self.records:
-            d = agg.setdefault(key, dict(api=name, launches=0, ms=0.0, work=0.0, clk_ms=0.0, clk_w=0.0))
-            ms = e0.elapsed_time(e1)
+        agg, per_key = {}, {}
+        timed = [(name, key, work, e0.elapsed_time(e1), probe) for name, (key, work), e0, e1, probe in self.records]
+        for _, key, _, ms, _ in timed:
+            per_key.setdefault(key, []).append(ms)
+        med = {k: sorted(v)[len(v) // 2] for k, v in per_key.items()}
+        for name, key, work, ms, probe in timed:
+            d = agg.setdefault(key, dict(api=name, launches=0, ms=0.0, work=0.0, clk_ms=0.0, clk_w=0.0, outliers=0))
+            if len(per_key[key]) >= 3 and ms > 20.0 * med[key]:
+                d["outliers"] += 1
+                ms, probe = med[key], None
             d["launches"] += 1
             d["ms"] += ms
             d["work"] += work
@@ -248,6 +257,7 @@ def roofline_block(agg, value_per_gpu, mflop_per_window, ms_per_step, dump=False
                 launch_ms=round(per_launch_ms, 4), launches_per_step=dom["launches"],
                 step_frac=round(step_frac, 4),
                 clock_mhz_timed_region=round(region_mhz, 0) if region_mhz else None, step_frac_at_clock=at_clock(step_frac, region_mhz),
+                timer_outliers=sum(d.get("outliers", 0) for d in agg.values()),
                 by_class=by_class, timed_kernel_ms_per_step=round(sum(d["ms"] for d in agg.values()), 3),
                 mfma_kernel_ms_per_step=round(mfma_ms, 3), non_mfma_ms_per_step=round(max(0.0, ms_per_step - mfma_ms), 3),
                 # serial sum of every timed kernel minus the step time of the timed region: what the side-stream overlaps hide (positive) or what
