@@ -95,6 +95,8 @@ def test_graphed_step_is_bit_identical_to_eager(hip):
         g = GraphedTrainStep(model, opt, loader, acc, warmup=3 if graphed else 10 ** 9, **kw)
         snaps, terms = [], []
         for i in range(10):
+            if i == 6:
+                opt.param_groups[0]["lr"] = 2e-4               # a scheduler's cut between two replays: the kernel reads the rate from the device word
             t = g(starts[i])
             terms.append(t.cpu().numpy().copy())
             snaps.append(model.flat_parameters()[0].cpu().numpy().copy())
@@ -124,3 +126,5 @@ def test_graphed_step_is_bit_identical_to_eager(hip):
     assert a["t"] == b["t"] == 13 and a["adam"].tolist() == [13, 0] and a["rng"][1] == 13
     np.testing.assert_allclose(a["acc"], b["acc"], rtol=1e-6)
     assert not np.array_equal(a["snaps"][0], a["snaps"][9])
+    step5, step6 = (np.abs(a["snaps"][i + 1] - a["snaps"][i]).mean() for i in (4, 6))
+    assert step6 < 0.6 * step5                                 # 2e-4 / 5e-4 = 0.4 of the update size
