@@ -166,7 +166,8 @@ def profile_kernels(model, loader, B, steps=3):
         kind = "NT" if (not akm and not bkm) else ("NN" if not akm else "TN")
         if min(M, N, K) <= 32:
             return (f"hbm gemm_kernel {kind} narrow (a dimension <= 32)", 4.0 * (M * K + K * N + M * N))
-        return (f"gemm_kernel {kind} M={M} N={N} K={K}", 2.0 * M * N * K)
+        sp = k.get("split")
+        return (f"gemm_kernel {kind} M={M} N={N} K={K}" + ("" if sp is None else f" bf16x6 opt={sp}"), 2.0 * M * N * K)
 
     def group_flops(M, N, K, As, akm, Bs, bkm, *a, **k):
         kind = "NT" if (not akm and not bkm) else ("NN" if not akm else "TN")
@@ -568,11 +569,12 @@ PEAK_BF16_MFMA_TFLOPS = 2500.0             # MI355X_MICROARCH.md: dense bf16 MFM
 
 def split_gemm_block(dev, steps, warmup, default_res):
     """OPT-IN leg (not the headline): the same configs[1] train step with the large weight gradients (the six dW_hh, the two layer-1 dW_ih,
-    the future decoder's two dW_hh: two k-major operands, K = batch x time) on the error-compensated split-bf16 contraction
-    (vame_gemm_group_bf16x6_f32, engine option split_wgrad) instead of the f32-input matrix cores; everything else unchanged.  fp32-equivalent
-    flops against the bf16 dense peak / 6 plane products."""
-    out = dict(arith="large weight gradients: bf16x6 split operands (three exact bf16 planes per fp32 value, six plane products), f32 accumulate; "
-                     "everything else: f32-input MFMA as in the headline",
+    the future decoder's two dW_hh: two k-major operands, K = batch x time; vame_gemm_group_bf16x6_f32, engine option split_wgrad) and the
+    second encoder layer's input projections and data gradients (row-major activations x weights, K = a layer width; vame_gemm_bf16x6_f32,
+    engine option split_proj) on the error-compensated split-bf16 contraction instead of the f32-input matrix cores; everything else
+    unchanged.  fp32-equivalent flops against the bf16 dense peak / 6 plane products."""
+    out = dict(arith="large weight gradients, layer-1 input projections and their data gradients: bf16x6 split operands (three exact bf16 planes per fp32 "
+                     "value, six plane products), f32 accumulate; everything else (the GRU recurrences, BPTT, the small contractions): f32-input MFMA as in the headline",
                peak=round(PEAK_BF16_MFMA_TFLOPS / 6, 1), unit="TFLOP/s (fp32-equivalent)", peak_note="bf16 dense peak 2500 TF / 6 plane products",
                default_ms_per_step=round(default_res["dts"][0] / steps * 1e3, 3),
                error_table="profiles/r05_split_gemm_error_table.txt (max error vs float64: 0.4x the f32-input kernel's with two accumulators per output, "
@@ -583,8 +585,8 @@ def split_gemm_block(dev, steps, warmup, default_res):
         out["default_launch"] = dict(kernel=dom, launch_ms=round(base["ms"] / base["launches"], 4),
                                      tflops=round(base["work"] / base["launches"] / (base["ms"] / base["launches"] * 1e-3) / 1e12, 1))
     for name, optw in (("one_accumulator", 1), ("two_accumulators", 0)):
-        r = train_leg(dev, 256, 30, 4096, steps, warmup, 0, 1, engine_options=dict(split_wgrad=optw))
-        line = dict(engine_option=f"split_wgrad={optw}", value=round(4096 * steps / r["dts"][0], 1), unit="windows/s",
+        r = train_leg(dev, 256, 30, 4096, steps, warmup, 0, 1, engine_options=dict(split_wgrad=optw, split_proj=optw))
+        line = dict(engine_option=f"split_wgrad={optw} split_proj={optw}", value=round(4096 * steps / r["dts"][0], 1), unit="windows/s",
                     ms_per_step=round(r["dts"][0] / steps * 1e3, 3), clock_mhz_timed_region=round(r["mhz"], 0) if r["mhz"] else None)
         launches = {}
         for k, d in (r.get("agg") or {}).items():

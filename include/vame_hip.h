@@ -70,10 +70,20 @@ int vame_gemm_group_f32(int count, int M, int N, int K, const float* const* A, i
  * the library stays on true fp32 matrix instructions.  Same arguments and semantics as vame_gemm_group_f32 (both operands k-major);
  * additional requirements: M, N, lda, ldb, the segment strides, a_gap_at and a_gap even, operands 8-byte aligned, a slab of K / splitk
  * rows spans < 1 GiB.  Inf / NaN inputs give NaN.  opt: bits 0-1 = accumulators per output (0 = default 2: the leading product on its
- * own accumulator; 1 = one for all six products), bit 4 = MFMA waves at raised priority. */
+ * own accumulator; 1 = one for all six products); any other bit is refused. */
 int vame_gemm_group_bf16x6_f32(int count, int M, int N, int K, const float* const* A, int64_t lda, int64_t a_seg, int64_t a_seg_stride,
                                const float* const* B, int64_t ldb, int64_t b_seg, int64_t b_seg_stride, float* const* C, int64_t ldc,
                                int accumulate, int splitk, float* ws, int a_gap_at, int a_gap, int opt, void* stream);
+
+/* The same split contraction for the two large contractions of a step whose K is a layer width instead of batch x time: a ROW-major A
+ * (M = batch x time activation rows with vame_gemm_f32's two-level addressing, K contiguous) times a plain weight matrix B, row-major
+ * (b_kmajor = 0: C = A B^T + bias, the input projection of the second encoder layer, vame/model/rnn_model.py:35 nn.GRU(..., num_layers=2)
+ * -> gi = y W_ih^T + b) or k-major (b_kmajor = 1: C (+)= A B, its data gradient dY = dG W_ih in loss.backward(), rnn_vae.py:141-143).
+ * No split-K.  OPT-IN like the grouped form; same error level (opt bits 0-1 as there).  Requirements: K a multiple of 32; lda, a_seg_stride
+ * multiples of 4 and A 16-byte aligned; B row-major: ldb a multiple of 4, 16-byte aligned -- B k-major: ldb and N even, 8-byte aligned;
+ * 128 rows of A span < 1 GiB. */
+int vame_gemm_bf16x6_f32(int M, int N, int K, const float* A, int64_t lda, int64_t a_seg, int64_t a_seg_stride, const float* B, int64_t ldb,
+                         int b_kmajor, const float* bias, float* C, int64_t ldc, int accumulate, int opt, void* stream);
 
 /* Pack one GRU layer-direction's recurrent weights for the sequence kernels.
  *   W_hh (3H,H), b_ih/b_hh (3H) -> wp_fwd (3H*H, MFMA B-fragment order for h W_hh^T),

@@ -132,6 +132,71 @@ def check_gemm_split(dev, small=True):
         ops.gemm_group(64, 64, K, [Operand(a, 65)], 1, [Operand(b, 64)], 1, C, [0], 64, 8, ws, split=0)
 
 
+def check_gemm_split_rows(dev, small=True):
+    """vame_gemm_bf16x6_f32 (the split-bf16 contraction of a row-major A with a weight matrix, no split-K) against float64: ragged M / N
+    tiles, two-level (batch, time) rows of A inside a wider padded sequence buffer, row-major and k-major B inside wider rows, bias,
+    accumulation, a C with a pitch and an offset, both accumulator options.  Tolerances as check_gemm_split."""
+    rng = np.random.default_rng(12)
+    cases = [  # M, N, K, seg_a, b_kmajor, bias, acc, opt
+        (70, 136, 64, 0, 0, True, False, 0), (128, 72, 96, 0, 1, False, True, 1), (6 * 30, 100, 64, 30, 0, True, False, 1),
+        (9 * 15, 130, 160, 15, 1, False, False, 0), (301, 30, 32, 7, 0, False, True, 0), (257, 258, 128, 0, 1, True, True, 2),
+    ]
+    if not small:
+        cases += [(64 * 30, 768, 512, 30, 0, True, False, 0), (64 * 30, 512, 768, 0, 1, False, True, 0), (4001, 770, 512, 0, 0, True, False, 1),
+                  (48 * 30, 1024, 1536, 30, 1, False, False, 1), (40 * 30, 1536, 1024, 30, 0, True, False, 0)]
+    for (M, Nn, K, sega, bkm, with_bias, acc, opt) in cases:
+        a = (rng.standard_normal((M, K)) * np.exp(rng.uniform(-6, 6, (M, 1)))).astype(np.float32)
+        if sega:        # rows (b, t) stored as (M / seg, seg + 2, K + 8) with the view at slot 1, column 4: the engine's (B, T + 2, 2H) layout
+            st = rng.standard_normal((M // sega, sega + 2, K + 8)).astype(np.float32)
+            st[:, 1:sega + 1, 4:4 + K] = a.reshape(M // sega, sega, K)
+            opA = Operand(T_(st, dev), K + 8, off=(K + 8) + 4, seg=sega, seg_stride=(sega + 2) * (K + 8))
+        else:
+            st = rng.standard_normal((M, K + 4)).astype(np.float32)
+            st[:, :K] = a
+            opA = Operand(T_(st, dev), K + 4)
+        if bkm:         # B[k][n] inside rows of N + 6
+            b = rng.standard_normal((K, Nn)).astype(np.float32)
+            sb = rng.standard_normal((K, Nn + 6)).astype(np.float32)
+            sb[:, 2:2 + Nn] = b
+            opB = Operand(T_(sb, dev), Nn + 6, off=2)
+            bt = b
+        else:           # B[n][k] inside rows of K + 4
+            b = rng.standard_normal((Nn, K)).astype(np.float32)
+            sb = rng.standard_normal((Nn, K + 4)).astype(np.float32)
+            sb[:, 4:] = b
+            opB = Operand(T_(sb, dev), K + 4, off=4)
+            bt = b.T
+        bias = rng.standard_normal(Nn).astype(np.float32) if with_bias else None
+        ldc = Nn + 3
+        C0 = rng.standard_normal((M + 1, ldc)).astype(np.float32)
+        C = T_(C0, dev)
+        assert ops.gemm_split_rows_ok(M, Nn, K, opA, 0, opB, bkm)
+        ops.gemm(M, Nn, K, opA, 0, opB, bkm, C, ldc, c_off=ldc + 1, bias=T_(bias, dev) if with_bias else None, accumulate=acc, split=opt)
+        full = N_(C)
+        out = full[1:, 1:1 + Nn]
+        keep = np.ones_like(C0, dtype=bool)
+        keep[1:, 1:1 + Nn] = False
+        assert np.array_equal(full[keep], C0[keep]), "wrote outside C"
+        base = (C0[1:, 1:1 + Nn].astype(np.float64) if acc else 0.0) + (bias.astype(np.float64)[None, :] if with_bias else 0.0)
+        mag = np.abs(a).astype(np.float64) @ np.abs(bt).astype(np.float64)
+        six = split_reference(np.ascontiguousarray(a.T), np.ascontiguousarray(bt)) + base
+        exact = a.astype(np.float64) @ bt.astype(np.float64) + base
+        tag = str((M, Nn, K, sega, bkm, with_bias, acc, opt))
+        tol = 2.0 ** -21 if (opt & 3) != 1 else 2.0 ** -20
+        assert np.all(np.abs(out - six) <= tol * (mag + np.abs(base)) + 1e-30), tag + f" vs six planes: {np.max(np.abs(out - six) / (mag + 1e-30)):.3e}"
+        assert np.all(np.abs(out - exact) <= 1.5 * tol * (mag + np.abs(base)) + 1e-30), tag + f" vs exact: {np.max(np.abs(out - exact) / (mag + 1e-30)):.3e}"
+    # what it refuses: K not a multiple of 32, a k-major A, misaligned / odd-pitch operands
+    a, b, C = torch.zeros(64, 72, device=dev), torch.zeros(64, 72, device=dev), torch.zeros(64, 64, device=dev)
+    assert not ops.gemm_split_rows_ok(64, 64, 40, Operand(a, 72), 0, Operand(b, 72), 0)
+    assert not ops.gemm_split_rows_ok(64, 64, 64, Operand(a, 72), 1, Operand(b, 72), 0)
+    assert not ops.gemm_split_rows_ok(64, 64, 64, Operand(a, 72, off=2), 0, Operand(b, 72), 0)
+    assert not ops.gemm_split_rows_ok(64, 63, 64, Operand(a, 72), 0, Operand(b, 71), 1)
+    with pytest.raises(Exception):
+        ops.gemm(64, 64, 40, Operand(a, 72), 0, Operand(b, 72), 0, C, 64, split=0)
+    with pytest.raises(Exception):
+        ops.gemm(64, 64, 64, Operand(a, 72, off=2), 0, Operand(b, 72), 0, C, 64, split=0)
+
+
 def check_gemm_group_shared_output(dev):
     """All problems of a group naming one C: C (+)= sum_g A_g B_g (dz of the decoders), against float64."""
     rng = np.random.default_rng(4)

@@ -240,7 +240,7 @@ def check_adam_trajectory(dev):
         np.testing.assert_allclose(sd[k].cpu().numpy(), v, atol=2e-5, err_msg=k)
 
 
-def check_odd_dims_vs_oracle(dev, F=10, Z=7, H=32, T=9, FS=4, B=5, expect=None):
+def check_odd_dims_vs_oracle(dev, F=10, Z=7, H=32, T=9, FS=4, B=5, expect=None, engine_options=None):
     """Unaligned shapes (F, Z not multiples of 4; egocentric_data=False gives F = num_features - 2): exercises the scalar-load
     GEMM paths and the non-fused layer-0 input projection, against the numpy oracle (no golden needed)."""
     from oracle import vame_oracle as vo
@@ -248,6 +248,7 @@ def check_odd_dims_vs_oracle(dev, F=10, Z=7, H=32, T=9, FS=4, B=5, expect=None):
     model = RNN_VAE(2 * T, Z, F, 1, FS, H, H, H, H, 0, 0, 0, False)
     p = {k: v.numpy().copy() for k, v in model.state_dict().items()}
     model = model.to(dev).train()
+    model.engine_options = dict(engine_options or {})
     rng = np.random.default_rng(9)
     win = rng.standard_normal((B, T + FS, F)).astype(np.float32)
     eps = rng.standard_normal((B, Z)).astype(np.float32)

@@ -5,7 +5,7 @@ the CPU; the same checks run on the real GPU in test_kernels_gpu.py.
 """
 import pytest
 
-from kernel_cases import (check_head_fused, check_gemm_group_shared_output, check_gru_wide, check_gru_wide_small, check_hmm, check_adam, check_adam_abort_and_mask_scale, check_colsum, check_colsum_batch, check_kmeans, check_gather, check_gemm_cases, check_gemm_group, check_gemm_split, check_gemm_pipelined_shapes, check_gru_bwd, check_gru_skew_fwd, check_gru_wide_skew_fwd, check_gru_ws_bwd, check_gru_kernel_option_is_an_argument, check_gru_coop_bwd, check_gru_coop_fwd, check_gru_fwd, check_gru_fwd_fused,
+from kernel_cases import (check_head_fused, check_gemm_group_shared_output, check_gru_wide, check_gru_wide_small, check_hmm, check_adam, check_adam_abort_and_mask_scale, check_colsum, check_colsum_batch, check_kmeans, check_gather, check_gemm_cases, check_gemm_group, check_gemm_split, check_gemm_split_rows, check_gemm_pipelined_shapes, check_gru_bwd, check_gru_skew_fwd, check_gru_wide_skew_fwd, check_gru_ws_bwd, check_gru_kernel_option_is_an_argument, check_gru_coop_bwd, check_gru_coop_fwd, check_gru_fwd, check_gru_fwd_fused,
                           check_latent, check_latent_draw, check_loss_finish, check_mse, check_nuclear, check_prep_fill_rules, check_prepare_series_golden,
                           check_prepare_series_vs_oracle)
 
@@ -116,6 +116,11 @@ def test_gemm_group(emu):
 def test_gemm_group_split_bf16x6(emu):
     """the opt-in error-compensated split-bf16 contraction (index math, LDS image, plane split, k-tile ring) on the host emulator"""
     check_gemm_split("cpu")
+
+
+def test_gemm_split_bf16x6_row_major_a(emu):
+    """the split-bf16 contraction of a row-major A with a weight matrix (input projections, data gradients): row producer, rotated image slots"""
+    check_gemm_split_rows("cpu")
 
 
 @pytest.mark.parametrize("N,K,D,chunk", [(700, 4, 6, 64), (300, 3, 5, 7), (130, 17, 4, 16), (3000, 5, 8, None)])

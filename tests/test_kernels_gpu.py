@@ -1,7 +1,7 @@
 """The kernel checks of test_kernels_emu.py on the real MI355X through libvame_hip.so (C ABI)."""
 import pytest
 
-from kernel_cases import (check_head_fused, check_gemm_group_shared_output, check_gru_wide, check_gru_wide_small, check_hmm, check_adam, check_adam_abort_and_mask_scale, check_colsum, check_colsum_batch, check_kmeans, check_gather, check_gemm_cases, check_gemm_group, check_gemm_split, check_gru_bwd, check_gru_skew_fwd, check_gru_wide_skew_fwd, check_gru_fwd_ring_stress, check_gru_ws_bwd, check_gru_kernel_option_is_an_argument, check_gru_coop_bwd, check_gru_coop_fwd, check_gru_fwd, check_gru_fwd_fused,
+from kernel_cases import (check_head_fused, check_gemm_group_shared_output, check_gru_wide, check_gru_wide_small, check_hmm, check_adam, check_adam_abort_and_mask_scale, check_colsum, check_colsum_batch, check_kmeans, check_gather, check_gemm_cases, check_gemm_group, check_gemm_split, check_gemm_split_rows, check_gru_bwd, check_gru_skew_fwd, check_gru_wide_skew_fwd, check_gru_fwd_ring_stress, check_gru_ws_bwd, check_gru_kernel_option_is_an_argument, check_gru_coop_bwd, check_gru_coop_fwd, check_gru_fwd, check_gru_fwd_fused,
                           check_latent, check_latent_draw, check_loss_finish, check_mse, check_nuclear, check_prep_fill_rules, check_prepare_series_golden,
                           check_prepare_series_vs_oracle)
 
@@ -108,6 +108,11 @@ def test_gemm_group(hip):
 def test_gemm_group_split_bf16x6(hip):
     """opt-in split-bf16 (bf16x6 planes, fp32 accumulate) contraction vs float64 incl. the weight-gradient shapes of the headline step"""
     check_gemm_split(DEV, small=False)
+
+
+def test_gemm_split_bf16x6_row_major_a(hip):
+    """the split-bf16 contraction of a row-major A with a weight matrix vs float64 incl. the layer-1 projection / data-gradient shapes"""
+    check_gemm_split_rows(DEV, small=False)
 
 
 @pytest.mark.parametrize("N,K,D,chunk", [(700, 4, 6, 64), (300, 3, 5, 7), (130, 17, 4, 16), (20000, 15, 30, 128), (20000, 15, 30, 512), (3000, 5, 8, None)])

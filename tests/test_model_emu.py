@@ -76,6 +76,19 @@ def test_small_batch_cooperative_path_vs_oracle(emu):
     check_odd_dims_vs_oracle("cpu", F=10, Z=7, H=128, T=4, FS=2, B=5)
 
 
+def test_split_bf16_layer1_projection_option_vs_oracle(emu):
+    """engine option split_proj: the second encoder layer's input projections (1024 x 192 x 128) and their data gradients (1024 x 128 x 192)
+    on the split-bf16 contraction, whole train step against the numpy oracle at the unchanged tolerance."""
+    from vame_amd import ops
+    seen, orig = [], ops.gemm
+    ops.gemm = lambda *a, **k: (seen.append((a[0], a[1], a[2], k.get("split"))), orig(*a, **k))[1]
+    try:
+        check_odd_dims_vs_oracle("cpu", F=12, Z=7, H=64, T=16, FS=4, B=64, engine_options=dict(split_proj=0))
+    finally:
+        ops.gemm = orig
+    assert sorted(c[:3] for c in seen if c[3] is not None) == [(1024, 128, 192)] * 2 + [(1024, 192, 128)] * 2
+
+
 @pytest.mark.parametrize("name", ["step_tiny_dropout", "step_tiny_hsizes"])
 def test_reference_model_options(emu, name):
     check_model_options("cpu", name)

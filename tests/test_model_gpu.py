@@ -211,21 +211,25 @@ def test_headline_batch_4096_all_gradients_vs_torch_cpu_reference(hip):
     assert len(rg) == 44
     from vame_amd import ops
     # the default step (f32-input matrix cores everywhere), then the same step with the large weight gradients on the opt-in split-bf16
-    # contraction (engine option split_wgrad: two accumulators per output / one) -- the SAME tolerance for all three
+    # contraction (engine options split_wgrad + split_proj: two accumulators per output / one) -- the SAME tolerance for all three
     for split in (None, 0, 1):
         eng = model._ensure_engine()
-        eng.split_wgrad = split
-        calls, orig = [], ops.gemm_group
+        eng.split_wgrad = eng.split_proj = split
+        calls, rcalls, orig, orig1 = [], [], ops.gemm_group, ops.gemm
         ops.gemm_group = lambda *a, **k: (calls.append((a[0], a[1], a[2], k.get("split"))), orig(*a, **k))[1]
+        ops.gemm = lambda *a, **k: (rcalls.append((a[0], a[1], a[2], k.get("split"))), orig1(*a, **k))[1]
         try:
             out = model.loss_step(win.cuda(), 1.0, beta=1.0, kloss=Z, klmbda=0.1, bsize=B, eps=eps.cuda()).cpu().numpy()
         finally:
-            ops.gemm_group = orig
+            ops.gemm_group, ops.gemm = orig, orig1
         on_split = [c for c in calls if c[3] is not None]
+        rows_split = [c for c in rcalls if c[3] is not None]
         if split is None:
-            assert not on_split
+            assert not on_split and not rows_split
         else:           # the six dW_hh (768 x 256 x 122,880), the two layer-1 dW_ih (768 x 512), the future decoder's two dW_hh (K = 61,440)
             assert sorted(c[:3] for c in on_split) == [(768, 256, 61440), (768, 256, 122880), (768, 512, 122880)] and all(c[3] == split for c in on_split)
+            # option split_proj: the two layer-1 input projections (K = 2H) and the two data gradients behind them (K = 3H)
+            assert sorted(c[:3] for c in rows_split) == [(122880, 512, 768)] * 2 + [(122880, 768, 512)] * 2 and all(c[3] == split for c in rows_split)
         for i, (k, v) in enumerate(zip(["rec", "fut", "kl", "kmeans"], terms)):
             assert_loss_close(out[i], v.item(), name=k)
         mu = eng.buf("mu", B, Z)[:B * Z].view(B, Z).cpu().numpy()

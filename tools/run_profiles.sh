@@ -60,6 +60,7 @@ python tools/split_gemm_bench.py 2>&1 | grep -v amdgpu > $O/split_gemm_error_tab
 VAME_LIB=tools/libvame_hip_ab.so python tools/split_abl.py 20 2>&1 | grep -v amdgpu > $O/split_abl.txt
 ./tools/mfma_valu_overlap_probe > $O/mfma_valu_overlap_probe.txt 2>&1
 python tools/shape_table.py both 2>&1 | grep -v amdgpu > $O/shape_table.txt
+python tools/narrow_gemms.py 2>&1 | grep -v amdgpu > $O/narrow_gemms.txt
 bash tools/traffic_gemm_cfg3.sh ${1:-prof}/gemm3 8 16 32 64 96 > /dev/null 2>&1; cat $O/gemm3/times.txt $O/gemm3/traffic.txt > $O/cfg3_gemm_splitk_traffic.txt; rm -rf $O/gemm3
 bash tools/trace_b256.sh ${1:-prof}/b256_graph 256 --graph > /dev/null 2>&1; cp $O/b256_graph/kernel_trace.csv $O/b256_graph_kernel_trace.csv; rm -rf $O/b256_graph
 cd /tmp && export TMPDIR=/tmp

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Error table and timing of the error-compensated split-bf16 contraction (vame_gemm_group_bf16x6_f32) beside the f32-input MFMA kernel
-(vame_gemm_group_f32) on the weight-gradient shapes, against a float64 product.
+(vame_gemm_group_f32) on the weight-gradient shapes, and of its row-major-A form (vame_gemm_bf16x6_f32 beside vame_gemm_f32) on the layer-1
+projection / data-gradient shapes, against a float64 product.
 
     python tools/split_gemm_bench.py [--reps 10] [--quick]
 
@@ -67,6 +68,43 @@ def run(M, N, K, n, sk, gap, seg, reps, wide=True, dev="cuda"):
     return row
 
 
+def run_rows(M, N, K, seg, bkm, reps, dev="cuda"):
+    """vame_gemm_bf16x6_f32 (row-major A = activations in the engine's sequence layout, B = a weight matrix) beside vame_gemm_f32."""
+    g = torch.Generator(device=dev).manual_seed(9)
+    a = torch.randn(M, K, device=dev, generator=g) * torch.exp2(torch.empty(M, 1, device=dev).uniform_(-8, 8, generator=g))
+    if seg:
+        st = torch.zeros(M // seg, seg + 2, K, device=dev)
+        st[:, 1:seg + 1] = a.view(M // seg, seg, K)
+        opA = Operand(st, K, off=K, seg=seg, seg_stride=(seg + 2) * K)
+    else:                                    # dG: rows of 4H floats, 3H of them read
+        st = torch.zeros(M, K // 3 * 4, device=dev)
+        st[:, :K] = a
+        opA = Operand(st, K // 3 * 4)
+    b = torch.randn((K, N) if bkm else (N, K), device=dev, generator=g) * 0.05
+    bias = None if bkm else torch.randn(N, device=dev, generator=g)
+    C = torch.zeros(M, N, device=dev)
+    rows = slice(0, min(M, 8192))            # the float64 reference on a slice of the rows
+    bt = (b if bkm else b.T).double()
+    ref = a[rows].double() @ bt + (0 if bias is None else bias.double())
+    mag = a[rows].double().abs() @ bt.abs() + (0 if bias is None else bias.double().abs())
+    row = {}
+    for name, split in (("f32", None), ("split2", 0), ("split1", 1)):
+        call = lambda: ops.gemm(M, N, K, opA, 0, Operand(b, b.shape[1]), bkm, C, N, bias=bias, split=split)  # noqa: E731
+        call()
+        torch.cuda.synchronize()
+        err = (C[rows].double() - ref).abs()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        call()
+        e0.record()
+        for _ in range(reps):
+            call()
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / reps
+        row[name] = (float((err / mag).max()), float(err.max() / ref.abs().max()), ms, 2.0 * M * N * K / ms / 1e9)
+    return row
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--reps", type=int, default=10)
@@ -92,6 +130,16 @@ def main():
                 else:
                     e1, e2, ms, tf = r[name]
                     print(f"{tag:44s} {name:8s} {e1:18.3e} {e2:15.3e} {ms:8.3f} {tf:10.1f}")
+    rows = [(122880, 768, 512, 30, 0, "configs[1] layer-1 projection gi = y W_ih^T + b"), (122880, 512, 768, 0, 1, "configs[1] layer-1 dY = dG W_ih"),
+            (7680, 768, 512, 30, 0, "batch 256 layer-1 projection")]
+    if not a.quick:
+        rows += [(245760, 1536, 1024, 60, 0, "configs[3] layer-1 projection"), (245760, 1024, 1536, 0, 1, "configs[3] layer-1 dY")]
+    for (M, N, K, seg, bkm, label) in rows:
+        r = run_rows(M, N, K, seg, bkm, a.reps)
+        tag = f"{label} {M}x{N}x{K}"
+        for name in ("f32", "split2", "split1"):
+            e1, e2, ms, tf = r[name]
+            print(f"{tag:64s} {name:8s} {e1:18.3e} {e2:15.3e} {ms:8.3f} {tf:10.1f}")
     print("peak for frac: f32 MFMA 157.3 TF; bf16 dense 2500 TF / 6 products = 416.7 TF fp32-equivalent")
 
 

@@ -26,6 +26,7 @@ _SIGS = {
                               c_int64, c_int64, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p, c_int, c_int, c_void_p]),
     "vame_gemm_group_f32": (c_int, [c_int, c_int, c_int, c_int, c_void_p, c_int64, c_int, c_int64, c_int64, c_void_p, c_int64, c_int,
                                     c_int64, c_int64, c_void_p, c_int64, c_int, c_int, c_void_p, c_int, c_int, c_void_p]),
+    "vame_gemm_bf16x6_f32": (c_int, [c_int, c_int, c_int, c_void_p, c_int64, c_int64, c_int64, c_void_p, c_int64, c_int, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p]),
     "vame_gemm_group_bf16x6_f32": (c_int, [c_int, c_int, c_int, c_int, c_void_p, c_int64, c_int64, c_int64, c_void_p, c_int64, c_int64, c_int64,
                                            c_void_p, c_int64, c_int, c_int, c_void_p, c_int, c_int, c_int, c_void_p]),
     "vame_gru_pack_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),

@@ -917,6 +917,57 @@ __device__ __forceinline__ void prod_split(const TileRegs& R, char* dst, int slo
     }
 }
 
+// ---- producer of a ROW-major operand (image column = operand row, K contiguous: activations x weights^T and activations x weights).
+// A lane owns four (row, k-octet) units of the k-tile: row = 16 u + (lane >> 2) of its wave's 64, octet = lane & 3 -- four lanes read one
+// 128-byte line of a row -- each unit 2 x 16 B = the eight consecutive k of one MFMA operand.  Rows never change along K: their (two-level)
+// offsets are resolved once, relative to the tile's first row (the buffer range's base; rows outside the matrix are poisoned), and the
+// k-tile is the loads' scalar offset.  In the image the four octets of one row would sit 2 KB apart = on the same banks, so units of this
+// producer are stored at column slot ^ (octet << 1): the 16 lanes of a store pass (4 rows x 4 octets) then cover all 64 banks once, and a
+// fragment read (one octet, 32 columns) sees a fixed permutation of its conflict-free slots.
+struct RowProducer {
+    unsigned voff[4], soff;
+    int slot0;                      // image offset of unit 0; unit u sits at slot0 ^ ((u & 1) << 7 | (u >> 1) << 8) (16 rows on = bits 3, 4 of the column's slot index)
+    __device__ __forceinline__ void init(const GemmOperand& o, int x0, int X, int op, int h, int lane) {
+        const int xr = lane >> 2, oct = lane & 3;
+        const int64_t first = op_row(o, x0);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int x = 64 * h + 16 * u + xr, gx = x0 + x;
+            voff[u] = gx < X ? (unsigned)((op_row(o, gx) - first) * 4 + oct * 32) : 0xC0000000u;
+        }
+        slot0 = (op * 4 + oct) * REGION + (xslot(64 * h + xr) ^ (oct << 5));
+        soff = 0;
+    }
+    __device__ __forceinline__ void load(TileRegs& R, BufRange rng) {          // unit u -> R.r[4u .. 4u+3] = (k0,k1) (k2,k3) (k4,k5) (k6,k7)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const float4 q0 = buf_load_f32x4(rng, voff[u], soff), q1 = buf_load_f32x4(rng, voff[u] + 16u, soff);
+            R.r[4 * u] = f32x2{q0.x, q0.y}; R.r[4 * u + 1] = f32x2{q0.z, q0.w};
+            R.r[4 * u + 2] = f32x2{q1.x, q1.y}; R.r[4 * u + 3] = f32x2{q1.z, q1.w};
+        }
+        soff += BK * 4;
+    }
+    __device__ __forceinline__ void split(const TileRegs& R, char* img) const {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            u32x4 p1, p2, p3;
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+                const f32x2 a = R.r[4 * u + d];
+                const f32x2 ra = a - hi16_of(a);                               // exact
+                const f32x2 sa = ra - hi16_of(ra);                             // exact, <= 8 significant bits
+                p1[d] = pack_hi16(a[0], a[1]);
+                p2[d] = pack_hi16(ra[0], ra[1]);
+                p3[d] = pack_hi16(sa[0], sa[1]);
+            }
+            char* q = img + (slot0 ^ (((u & 1) << 7) | ((u >> 1) << 8)));
+            *reinterpret_cast<u32x4*>(q) = p1;
+            *reinterpret_cast<u32x4*>(q + PLANE) = p2;
+            *reinterpret_cast<u32x4*>(q + 2 * PLANE) = p3;
+        }
+    }
+};
+
 struct Frags { u32x4 a[3][2], b[3][2]; };   // [plane][MFMA tile] operands of one K = 16 step
 
 __device__ __forceinline__ void cons_read(Frags& f, const char* img, int step, const int (&oa)[2], const int (&ob)[2]) {
@@ -1054,9 +1105,142 @@ __global__ __launch_bounds__(256, OCC) void gemm_split_kernel(GemmParams p, int 
         }
 }
 
+// The same contraction for a ROW-major A (activations: M = batch x time rows with two-level addressing, K contiguous) and a row-major
+// (BKM = false: C = A B^T, the input projections) or k-major (BKM = true: C = A B, the data gradients) B = a weight matrix.  K is short
+// here (the layer width): no split-K, the workgroup writes C itself (+ bias, + C when accumulating).  Waves 0, 1 split A's 128 rows, waves
+// 2, 3 B's (RowProducer, or the k-major producer above for BKM); the consumer side is gemm_split_kernel's.
+template <bool BKM, int NACC, int OCC>
+__global__ __launch_bounds__(256, OCC) void gemm_split_rows_kernel(GemmParams p) {
+    using namespace split6;
+    __shared__ __attribute__((aligned(16))) char smem[BUF];
+    int tm_, tn_, z, g;
+    if (!map_tile(p, tm_, tn_, z, g)) return;
+    const int tid = threadIdx.x, lane = tid & 63, wv = uniform(tid >> 6);
+    const int m0 = tm_ * TILE, n0 = tn_ * TILE;
+    const int nt = p.K / BK;
+    const int op = wv >> 1, h = wv & 1;
+    const bool kmaj = BKM && op;                                     // this wave splits the k-major B
+    const GemmOperand& o = op ? p.B : p.A;
+    const int x0 = op ? n0 : m0, X = op ? p.N : p.M;
+    RowProducer rp;
+    RowCursor c;
+    BufRange rng;
+    unsigned voff = 0;
+    int gt = 16 * h;
+    if (kmaj) {
+        const int x = x0 + 2 * lane;
+        voff = x < X ? (unsigned)x * 4u : 0xC0000000u;
+        rng = buf_range(o.p, (uint64_t)p.K * o.ld * 4);
+        c.init(o, 0, 16 * h, p.K);
+    } else {
+        const int xl = x0 + TILE - 1 < X ? x0 + TILE - 1 : X - 1;
+        rng = buf_range(o.p + op_row(o, x0), (uint64_t)(op_row(o, xl) - op_row(o, x0) + p.K) * 4);
+        rp.init(o, x0, X, op, h, lane);
+    }
+    const int li = lane & 31, hh = lane >> 5, wm = wv >> 1, wn = wv & 1;
+    int oa[2][2], ob[2][2];                                          // [K = 16 step][MFMA tile]
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int rot = (2 * s + hh) << 5;
+            oa[s][i] = hh * REGION + (xslot(wm * 64 + i * 32 + li) ^ rot);
+            ob[s][i] = (4 + hh) * REGION + (xslot(wn * 64 + i * 32 + li) ^ (BKM ? 0 : rot));
+        }
+    f32x16 acc[NACC][2][2];
+#pragma unroll
+    for (int a = 0; a < NACC; ++a)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[a][i][j][r] = 0.f;
+    TileRegs R;
+    auto LD = [&]() {
+        if (kmaj) { prod_load(R, c, rng, voff, lane, gt); gt += BK; }
+        else rp.load(R, rng);
+    };
+    LD();
+    for (int it = 0; it < nt; ++it) {
+        if (kmaj) prod_split(R, smem + (4 + 2 * h) * REGION, lane * 16, 1024 + ((lane ^ 8) * 16));    // (recomputed per k-tile: three registers fewer)
+        else rp.split(R, smem);
+        if (it + 1 < nt) LD();
+        LDS_BARRIER();
+        Frags f;
+        cons_read(f, smem, 0, oa[0], ob[0]);
+        cons_mfma<NACC>(f, acc);
+        cons_read(f, smem, 1, oa[1], ob[1]);
+        cons_mfma<NACC>(f, acc);
+        LDS_BARRIER();
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int col = n0 + wn * 64 + j * 32 + li;
+            if (col >= p.N) continue;
+            const float bv = p.bias ? p.bias[col] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wm * 64 + i * 32 + frag_row(r, lane);
+                if (row >= p.M) continue;
+                float v = acc[0][i][j][r];
+                if (NACC > 1) v += acc[NACC - 1][i][j][r];
+                float* cp = p.C + (int64_t)row * p.ldc + col;
+                v += bv;
+                if (p.accumulate) v += *cp;
+                *cp = v;
+            }
+        }
+}
+
 #ifdef VAME_TUNING_BUILD
 #include "../../tools/gemm_split_variants.inc"
 #endif
+
+// vame_gemm_f32's contract for a row-major A (a_kmajor = 0) and a plain weight matrix B, no split-K, evaluated by gemm_split_rows_kernel: the
+// input projections (b_kmajor = 0) and data gradients (b_kmajor = 1) whose K is a layer width.  opt as in vame_gemm_group_bf16x6_f32 (bits 0-1).
+extern "C" int vame_gemm_bf16x6_f32(int M, int N, int K, const float* A, int64_t lda, int64_t a_seg, int64_t a_seg_stride, const float* B, int64_t ldb,
+                                    int b_kmajor, const float* bias, float* C, int64_t ldc, int accumulate, int opt, void* stream) {
+    VAME_CHECK_ARG(A && B && C, VAME_E_BADARG, "gemm_bf16x6: null operand");
+    VAME_CHECK_ARG(M >= 1 && N >= 2 && K >= 32 && K % 32 == 0, VAME_E_SHAPE, "gemm_bf16x6: M=%d N=%d K=%d (K a multiple of 32)", M, N, K);
+    VAME_CHECK_ARG(lda % 4 == 0 && a_seg_stride % 4 == 0 && (uintptr_t)A % 16 == 0 && a_seg >= 0 && a_seg < (1ll << 31) && lda >= K,
+                   VAME_E_BADARG, "gemm_bf16x6: A is read with 16-byte loads (pitch, segment stride multiples of 4 floats, 16-byte aligned)");
+    if (b_kmajor)
+        VAME_CHECK_ARG(ldb % 2 == 0 && N % 2 == 0 && (uintptr_t)B % 8 == 0 && ldb >= N && (int64_t)K * ldb * 4 < (1ll << 30), VAME_E_BADARG,
+                       "gemm_bf16x6: a k-major B is read with 8-byte loads (even pitch and N, 8-byte aligned, < 1 GiB)");
+    else
+        VAME_CHECK_ARG(ldb % 4 == 0 && (uintptr_t)B % 16 == 0 && ldb >= K && 128 * ldb * 4 < (1ll << 30), VAME_E_BADARG,
+                       "gemm_bf16x6: a row-major B is read with 16-byte loads (pitch a multiple of 4 floats, 16-byte aligned)");
+    const int nacc = (opt & 3) == 0 ? 2 : (opt & 3);
+    VAME_CHECK_ARG((nacc == 1 || nacc == 2) && (opt & ~3) == 0, VAME_E_BADARG, "gemm_bf16x6: opt=%d", opt);
+    {       // the 128 rows of a tile are addressed with 32-bit byte offsets from its first row, rows outside the matrix at 3 GiB
+        const int64_t wrap = a_seg ? a_seg_stride - a_seg * lda : 0;
+        VAME_CHECK_ARG(wrap >= 0 && (128 * lda + (a_seg ? 128 / a_seg + 2 : 0) * wrap + K) * 4 < (1ll << 30), VAME_E_UNSUPPORTED,
+                       "gemm_bf16x6: 128 rows of A must span < 1 GiB with non-negative strides");
+    }
+    GemmParams p;
+    p.A = {A, lda, a_seg, a_seg_stride, 1, 0x7fffffff, 0};
+    p.B = {B, ldb, 0, 0, 1, 0x7fffffff, 0};
+    for (int g = 0; g < 8; ++g) { p.gA[g] = A; p.gB[g] = B; }
+    p.bias = bias; p.C = C; p.ldc = ldc; p.ws = nullptr;
+    p.M = M; p.N = N; p.K = K; p.accumulate = accumulate; p.group = 1;
+    p.kper = K; p.splitk = 1;
+    p.tiles_m = (int)cdiv64(M, split6::TILE); p.tiles_n = (int)cdiv64(N, split6::TILE);
+    p.by_z = 0; p.cvec = 0; p.wsvec = 0;
+    dim3 grid((unsigned)(cdiv64(p.tiles_m, 8) * p.tiles_n * 8)), block(256);
+    hipStream_t st = (hipStream_t)stream;
+    if (b_kmajor) {
+        if (nacc == 2) hipLaunchKernelGGL((gemm_split_rows_kernel<true, 2, 2>), grid, block, 0, st, p);
+        else hipLaunchKernelGGL((gemm_split_rows_kernel<true, 1, 3>), grid, block, 0, st, p);
+    } else {
+        if (nacc == 2) hipLaunchKernelGGL((gemm_split_rows_kernel<false, 2, 2>), grid, block, 0, st, p);
+        else hipLaunchKernelGGL((gemm_split_rows_kernel<false, 1, 3>), grid, block, 0, st, p);
+    }
+    VAME_LAUNCH_CHECK("gemm_bf16x6");
+    return VAME_OK;
+}
 
 // vame_gemm_group_f32's contract for two k-major operands, evaluated by gemm_split_kernel.  opt: bits 0-1 = accumulators per output (0 = default:
 // 2 -- the leading plane product on its own, two workgroups per CU; 1 = one accumulator for all six products, three workgroups per CU).

@@ -128,6 +128,8 @@ ENGINE_DEFAULTS = dict(
     split_wgrad=None,      # None = the f32-input matrix cores (default).  An int = the `opt` word of vame_gemm_group_bf16x6_f32 (0 = its
                            # defaults): the large grouped weight gradients (two k-major operands, N > 64, K >= 8192) run as the
                            # error-compensated split-bf16 contraction (bf16x6 planes, fp32 accumulate).  OPT-IN.
+    split_proj=None,       # the same for the two large contractions with a row-major activation operand and K = a layer width: the second
+                           # encoder layer's input projection and its data gradient (vame_gemm_bf16x6_f32; M >= 1024, N, K >= 128).  OPT-IN.
 )
 
 
@@ -176,6 +178,7 @@ class VAEEngine:
         self.wide = bool(opt["wide"])
         self.wide_bwd = bool(opt["wide_bwd"])
         self.split_wgrad = None if opt["split_wgrad"] is None else int(opt["split_wgrad"])
+        self.split_proj = None if opt["split_proj"] is None else int(opt["split_proj"])
         # BPTT / forward kernel choice of the persistent H <= 256 launches (ops.KERNEL_*): an argument of every launch (descriptor field),
         # AUTO = the library's measured default per hidden size; the A/B tests set these attributes
         self.gru_bwd_kernel = ops.KERNEL_AUTO
@@ -546,6 +549,13 @@ class VAEEngine:
             self._coop_state.shared = word
             word.copy_(self._coop_state.status)
 
+    def _split_rows(self, M, N, K, A, Bop, b_kmajor):
+        """The `opt` word of vame_gemm_bf16x6_f32 for this row-major-A contraction (option split_proj), or None = the f32-input kernel:
+        not opted in, too small to pay, or a layout the split form does not take (ops.gemm_split_rows_ok)."""
+        if self.split_proj is None or M < 1024 or N < 128 or K < 128 or not ops.gemm_split_rows_ok(M, N, K, A, 0, Bop, b_kmajor):
+            return None
+        return self.split_proj
+
     def _coop_parts(self, rows, B, tkey=None, H=None):
         """[(streams, (row0, nrows))] cooperative launches that cover this GRU launch, each fitting one workgroup per CU; at
         most two per stream set (beyond that the persistent kernels win).  [] = use the persistent kernels."""
@@ -722,7 +732,8 @@ class VAEEngine:
         rows, jobs = [], []
         for dirn, d in enumerate(self.enc[1]):
             gi = self.buf(f"gi_e1_{dirn}", B, T, 3 * H)
-            jobs.append(lambda d=d, gi=gi: ops.gemm(B * T, 3 * H, 2 * H, y_op, 0, self.P(d.w_ih, 2 * H), 0, gi, 3 * H, bias=d.bias_gi))
+            jobs.append(lambda d=d, gi=gi: ops.gemm(B * T, 3 * H, 2 * H, y_op, 0, self.P(d.w_ih, 2 * H), 0, gi, 3 * H, bias=d.bias_gi,
+                                                    split=self._split_rows(B * T, 3 * H, 2 * H, y_op, self.P(d.w_ih, 2 * H), 0)))
             st = self.buf(f"st_e1_{dirn}", ops.gru_stash_floats(B, T, H)) if training else None
             rows.append(self._gru_fwd_stream(d, gi, T * 3 * H, 3 * H, None, 0, Y1, 2 * H, T, dirn, hn, (2 + dirn) * H, 4 * H, st, T,
                                              write_y=training or coop))
@@ -1065,7 +1076,8 @@ class VAEEngine:
         if self._drop_mask is not None:             # layer 1 saw the dropped sequence: its dW_ih contracts with that one
             y0rows = Operand(self.buf("Y0d", B, T, 2 * H), 2 * H)
         for dirn, (d, dG, dbias) in enumerate(per):
-            ops.gemm(B * T, 2 * H, 3 * H, Operand(dG, 4 * H), 0, self.P(d.w_ih, 2 * H), 1, dY0, 2 * H, accumulate=dirn > 0)
+            ops.gemm(B * T, 2 * H, 3 * H, Operand(dG, 4 * H), 0, self.P(d.w_ih, 2 * H), 1, dY0, 2 * H, accumulate=dirn > 0,
+                     split=self._split_rows(B * T, 2 * H, 3 * H, Operand(dG, 4 * H), self.P(d.w_ih, 2 * H), 1))
             self._gru_param_grads(d, dG, dbias, ntiles, B, T, Y1, dirn, y0rows, 2 * H)
         if self._drop_mask is not None:             # d(Y0 * m / (1-p)) / dY0
             ops.mask_scale(dY0, 0, 2 * H, 0, 0, self._drop_mask, 1.0 / (1.0 - s.dropout), dY0, B * T, 2 * H)

@@ -68,8 +68,16 @@ def _auto_ws(dev, n):
 
 
 def gemm(M, N, K, A, a_kmajor, B, b_kmajor, C, ldc, c_off=0, bias=None, accumulate=False, splitk=1, ws=None, a_gap_at=0,
-         a_gap=0):
+         a_gap=0, split=None):
+    """C (+)= op(A) op(B) (+ bias) (vame_gemm_f32).  split = an `opt` word (0 = defaults): the error-compensated split-bf16 form
+    (vame_gemm_bf16x6_f32: a row-major A times a plain weight matrix, no split-K; see gemm_split_rows_ok)."""
     L = _lib.lib()
+    if split is not None:
+        assert not a_kmajor and splitk in (0, 1) and not a_gap and not B.seg, "the split-bf16 form takes a row-major A, a plain B and no split-K"
+        rc = L.vame_gemm_bf16x6_f32(M, N, K, _ptr(A.t, A.off), A.ld, A.seg, A.seg_stride, _ptr(B.t, B.off), B.ld, int(b_kmajor), _ptr(bias),
+                                    _ptr(C, c_off), ldc, int(accumulate), int(split), _stream())
+        _lib.check(rc, "vame_gemm_bf16x6_f32")
+        return
     if splitk == 0:
         # auto: few output tiles but a long K (Lambda / latent_to_hidden / dz GEMMs, M = batch): spread K over more workgroups
         tiles = ((M + 127) // 128) * ((N + 127) // 128 if N > 64 else 1)
@@ -119,6 +127,18 @@ def gemm_split_ok(M, N, K, As, Bs, splitk, a_gap_at=0, a_gap=0):
     kper = -(-(-(-K // splitk)) // 32) * 32
     span = max(a0.ld, b0.ld, (a0.seg_stride // a0.seg) if a0.seg else 0, (b0.seg_stride // b0.seg) if b0.seg else 0) * 4 * (kper + 64)
     return -(-K // kper) >= 8 and span < (1 << 30)
+
+
+def gemm_split_rows_ok(M, N, K, A, a_kmajor, B, b_kmajor):
+    """Whether vame_gemm_bf16x6_f32 takes this contraction (its layout / alignment rules; which shapes it pays for is the caller's choice)."""
+    if a_kmajor or B.seg or K % 32 or A.ld % 4 or A.seg_stride % 4 or _ptr(A.t, A.off) % 16 or A.ld < K:
+        return False
+    wrap = (A.seg_stride - A.seg * A.ld) if A.seg else 0
+    if wrap < 0 or (128 * A.ld + ((128 // A.seg + 2) if A.seg else 0) * wrap + K) * 4 >= (1 << 30):
+        return False
+    if b_kmajor:
+        return not (B.ld % 2 or N % 2 or _ptr(B.t, B.off) % 8 or B.ld < N or K * B.ld * 4 >= (1 << 30))
+    return not (B.ld % 4 or _ptr(B.t, B.off) % 16 or B.ld < K or 128 * B.ld * 4 >= (1 << 30))
 
 
 class ClockProbe:
