@@ -17,7 +17,7 @@ Prints ONE JSON line (rank 0): metric/value/unit + roofline (dominant kernel, me
 events on the launch stream; HBM-bound kernels of the step next to it) + cpu_baseline
 (reference-equivalent torch-CPU model, oracle/torch_ref.py) + `repeat_spread` (two more timed regions
 of the same length) + `also` (N = 1: BASELINE configs[3] shape, a configs[4]-shape embedding pass with its CPU baseline, the stock batch
-256, each with its own roofline, and `split_gemm`: the opt-in split-bf16 weight-gradient contraction) + `distributed` (N > 1: proof of the RCCL path and a same-run 1-rank leg).
+256, each with its own roofline, and `split_gemm`: the opt-in split-bf16 contractions -- weight gradients, layer-1 projections and their data gradients) + `distributed` (N > 1: proof of the RCCL path and a same-run 1-rank leg).
 """
 import argparse
 import json
@@ -514,12 +514,13 @@ def collective_block(model, step, steps, rank, world, sync, dev, dt_n, one_rank_
     return out
 
 
-def embed_leg(dev, n_win_per_rank, rank, world, H=256, T=30):
+def embed_leg(dev, n_win_per_rank, rank, world, H=256, T=30, engine_options=None):
     """Encoder-only latent embedding of a synthetic series, window index range sharded over ranks (no collective on the data path)."""
     from vame_amd.analysis.pose_segmentation import embed_series
     from vame_amd.model.rnn_model import RNN_VAE
     torch.manual_seed(19)
     model = RNN_VAE(2 * T, Z, F, 1, FS, H, H, H, H, 0, 0, 0, False).to(dev).eval()
+    model.engine_options = dict(engine_options or {})
     n_win = n_win_per_rank * world
     data = synth_series(n_win + T)
     embed_series(model, data[:, :70000], batch=16384)                      # warm-up (allocations, clocks)
@@ -596,6 +597,10 @@ def split_gemm_block(dev, steps, warmup, default_res):
                                    clock_mhz=round(d["mhz"], 0) if d.get("mhz") else None)
         line["launches"] = launches
         out[name] = line
+    # the embedding leg with its one large contraction (the layer-1 input projection, two directions) on the split form
+    e = embed_leg(dev, 2_000_000, 0, 1, engine_options=dict(split_proj=1))
+    out["embed_one_accumulator"] = dict(engine_option="split_proj=1", value=e["value"], unit="windows/s", seconds=e["seconds"], windows=e["windows"],
+                                        clock_mhz=e["roofline"]["clock_mhz"])
     return out
 
 

@@ -117,6 +117,32 @@ def test_embedding_matches_reference_loop(hip):
     np.testing.assert_allclose(lat2.cpu().numpy(), g["latent"][lo:hi], atol=1e-5)
 
 
+def test_embedding_with_split_projection_option(hip):
+    """engine option split_proj on the embedding path (configs[4] shape: H 256, T 30): the layer-1 input projection of every 16,384-window batch runs
+    the split-bf16 form and the latents stay within BASELINE.json's 1e-4 of the default path's (measured ~1e-6: both are fp32-grade)."""
+    from vame_amd import ops
+    from vame_amd.analysis.pose_segmentation import embed_series
+    from vame_amd.model.rnn_model import RNN_VAE
+    T, F, Z, H = 30, 24, 30, 256
+    data = np.random.default_rng(3).standard_normal((F, 40000 + T)).astype(np.float32)
+    lats = []
+    for opt in (None, 1):
+        torch.manual_seed(5)
+        model = RNN_VAE(2 * T, Z, F, 1, 15, H, H, H, H, 0, 0, 0, False).cuda().eval()
+        model.engine_options = dict(split_proj=opt)
+        seen, orig = [], ops.gemm
+        ops.gemm = lambda *a, **k: (seen.append((a[0], a[1], a[2], k.get("split"))), orig(*a, **k))[1]
+        try:
+            lat, _ = embed_series(model, data, batch=16384)
+        finally:
+            ops.gemm = orig
+        took = [c for c in seen if c[3] is not None]
+        assert (not took) if opt is None else (len(took) >= 4 and all(c[1:] == (768, 512, 1) for c in took)), took[:3]
+        lats.append(lat.cpu().numpy())
+    d = np.abs(lats[0] - lats[1]).max()
+    assert 0 < d < 1e-4, d
+
+
 def test_noise_option_separate_encoder_input(hip):
     check_noise_input("cuda")
 
