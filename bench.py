@@ -281,7 +281,9 @@ def pmc_traffic(dom_key):
     number measured on an older kernel says nothing about the current one."""
     import glob
     sha = lib_source_id()
-    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_hbm_traffic*.json")), reverse=True):
+    # newest round first; a summary tools/run_profiles.sh has just collected in this very call (profiles/_this_run_*) before the committed ones
+    paths = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_hbm_traffic*.json")), reverse=True)
+    for path in sorted(paths, key=lambda p: not os.path.basename(p).startswith("_this_run_")):
         try:
             with open(path) as f:
                 j = json.load(f)
