@@ -599,6 +599,10 @@ def split_gemm_block(dev, steps, warmup, default_res):
                                    clock_mhz=round(d["mhz"], 0) if d.get("mhz") else None)
         line["launches"] = launches
         out[name] = line
+    # the stock batch (256) as a replayed hipGraph with both options (K = 7,680 for the weight gradients, M = 7,680 for the projections)
+    r = train_leg(dev, 256, 30, 256, 200, 30, 0, 1, profile=False, engine_options=dict(split_wgrad=1, split_proj=1), graph=True)
+    out["batch256_one_accumulator"] = dict(engine_option="split_wgrad=1 split_proj=1", execution="one replayed hipGraph per step", value=round(256 * 200 / r["dts"][0], 1),
+                                           unit="windows/s", ms_per_step=round(r["dts"][0] / 200 * 1e3, 3))
     # the embedding leg with its one large contraction (the layer-1 input projection, two directions) on the split form
     e = embed_leg(dev, 2_000_000, 0, 1, engine_options=dict(split_proj=1))
     out["embed_one_accumulator"] = dict(engine_option="split_proj=1", value=e["value"], unit="windows/s", seconds=e["seconds"], windows=e["windows"],

@@ -87,3 +87,6 @@ def test_bench_line_contract(hip):
         leg = sg[name]
         assert leg["value"] > 50_000 and len(leg["launches"]) == 5, leg       # three grouped weight-gradient shapes + the layer-1 projection and its data gradient
         assert all(0 < v["frac"] <= 1 and v["tflops"] > 60 for v in leg["launches"].values()), leg["launches"]
+    # ... and the embedding leg / the stock batch as a replayed graph with the options on, beside their default-path lines
+    assert sg["embed_one_accumulator"]["value"] > 0.9 * also["configs4_embed_1gpu"]["value"]
+    assert sg["batch256_one_accumulator"]["value"] > 0.9 * also["batch256"]["value"] and sg["batch256_one_accumulator"]["ms_per_step"] > 0

@@ -289,6 +289,24 @@ def test_small_batch_cooperative_path_vs_oracle(hip, H, B, T, FS):
     check_odd_dims_vs_oracle("cuda", F=10, Z=7, H=H, T=T, FS=FS, B=B)
 
 
+def test_stock_shape_small_batch_with_split_contractions_vs_oracle(hip):
+    """The stock shape (H 256, T 30, FS 15, F 24, Z 30) at batch 160 -- cooperative GRU kernels, K = M = 4,800 -- with both split-bf16 options on:
+    the weight-gradient groups and the layer-1 projections / data gradients take the split kernels and the whole step matches the numpy oracle at
+    the unchanged tolerance."""
+    from vame_amd import ops
+    seen, orig, orig1 = [], ops.gemm_group, ops.gemm
+    ops.gemm_group = lambda *a, **k: (seen.append(("group", a[0], a[1], a[2], k.get("split"))), orig(*a, **k))[1]
+    ops.gemm = lambda *a, **k: (seen.append(("rows", a[0], a[1], a[2], k.get("split"))), orig1(*a, **k))[1]
+    try:
+        check_odd_dims_vs_oracle("cuda", F=24, Z=30, H=256, T=30, FS=15, B=160, engine_options=dict(split_wgrad=1, split_proj=0),
+                                 expect=lambda eng: eng._coop_state is not None or pytest.fail("cooperative kernels expected at batch 160"))
+    finally:
+        ops.gemm_group, ops.gemm = orig, orig1
+    took = sorted(c[:4] for c in seen if c[4] is not None)
+    # (the future decoder's two dW_hh contract over K = 160 x 15 = 2,400 < 4,096: f32-input kernel)
+    assert took == [("group", 768, 256, 4800), ("group", 768, 512, 4800)] + [("rows", 4800, 512, 768)] * 2 + [("rows", 4800, 768, 512)] * 2, took
+
+
 @pytest.mark.parametrize("name", ["step_tiny_dropout", "step_tiny_hsizes"])
 def test_reference_model_options(hip, name):
     check_model_options("cuda", name)

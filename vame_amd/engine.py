@@ -126,7 +126,7 @@ ENGINE_DEFAULTS = dict(
     skinny_side=False,     # narrow weight gradients (an output dimension <= 32) on a side stream beside the wide ones: measured +-0 at batch 256 /
                            # 1024 / 4096 in round 5 (tools/step_ab.py: 14.387 vs 14.392 ms) while it doubles both kernels' durations in every trace -> off
     split_wgrad=None,      # None = the f32-input matrix cores (default).  An int = the `opt` word of vame_gemm_group_bf16x6_f32 (0 = its
-                           # defaults): the large grouped weight gradients (two k-major operands, N > 64, K >= 8192) run as the
+                           # defaults): the large grouped weight gradients (two k-major operands, N > 64, K >= 4096) run as the
                            # error-compensated split-bf16 contraction (bf16x6 planes, fp32 accumulate).  OPT-IN.
     split_proj=None,       # the same for the two large contractions with a row-major activation operand and K = a layer width: the second
                            # encoder layer's input projection and its data gradient (vame_gemm_bf16x6_f32; M >= 1024, N, K >= 128).  OPT-IN.
@@ -300,7 +300,7 @@ class VAEEngine:
             def run(ws_name_=ws_name):
                 ws = self.ws.get(ws_name_, len(idx) * sk * M * N, self.dev)
                 As, Bs = [jobs[i][3] for i in idx], [jobs[i][4] for i in idx]
-                split = self.split_wgrad if (self.split_wgrad is not None and N > 64 and M >= 128 and K >= 8192
+                split = self.split_wgrad if (self.split_wgrad is not None and N > 64 and M >= 128 and K >= 4096
                                              and ops.gemm_split_ok(M, N, K, As, Bs, sk, gap_at, gap)) else None
                 ops.gemm_group(M, N, K, As, 1, Bs, 1, self.g, c_offs, N, sk, ws, a_gap_at=gap_at, a_gap=gap, split=split)
             return (float(M) * N * K * len(idx), run)
