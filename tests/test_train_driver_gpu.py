@@ -63,7 +63,8 @@ def test_parameterization_with_gpu_kmeans_option(hip):
 
 
 
-def test_graphed_step_is_bit_identical_to_eager(hip):
+@pytest.mark.parametrize("engine_options", [{}, dict(split_wgrad=1, split_proj=1)], ids=["default", "split-bf16"])
+def test_graphed_step_is_bit_identical_to_eager(hip, engine_options):
     """round 5: the stock-batch train step (gather -> loss_step -> fused Adam) captured once as a hipGraph and replayed (rnn_vae.GraphedTrainStep)
     against the same ten steps enqueued launch by launch: the weights after every step, the Adam state and the device-side counters (Philox
     step, Adam step, cooperative launch epoch) are the same bits; the loss terms agree to the rounding of their atomic sums."""
@@ -87,6 +88,7 @@ def test_graphed_step_is_bit_identical_to_eager(hip):
     for graphed in (False, True):
         torch.manual_seed(19)
         model = RNN_VAE(2 * T, Z, F, 1, FS, H, H, H, H, 0, 0, 0, False).to(dev).train()
+        model.engine_options = dict(engine_options)          # (second case: the opt-in split-bf16 contractions inside the captured step)
         opt = FusedAdamAMSGrad(model, lr=5e-4)
         loader = DeviceWindowLoader(DS(), B, T + FS, dev)
         acc = torch.zeros(6, dtype=torch.float64, device=dev)
