@@ -119,6 +119,8 @@ ENGINE_DEFAULTS = dict(
                            # chip each take twice as long, which makes per-kernel durations unreadable); 1 = caller's stream only
     coop=True,             # column-split GRU kernels for batches that leave most CUs idle (_coop_parts); False keeps the persistent ones
     coop_rounds=3,         # at most this many cooperative launches (row ranges) per stream set before the batch-tile-persistent kernels take over
+    coop_cover=0,          # decoder + future decoder (four streams) as cooperative launches: 0 = whichever cover has fewer (launch x step) slots,
+                           # 1 = all four streams per launch, 2 = one pair of directions per launch
     wide=True,             # 256 < H <= 512: persistent two-blocks-per-wave kernels (gru_wide.hip) instead of the per-step GEMM path
     wide_bwd=True,         # ... for BPTT too (False: step by step: per-step GEMM + gate kernel)
     nuc_side=True,         # nuclear-norm solve on a side stream next to the output heads
@@ -175,6 +177,7 @@ class VAEEngine:
         self.wgrad_streams = int(opt["wgrad_streams"])
         self.coop = bool(opt["coop"])
         self.coop_rounds = int(opt["coop_rounds"])
+        self.coop_cover = int(opt["coop_cover"])
         self.wide = bool(opt["wide"])
         self.wide_bwd = bool(opt["wide_bwd"])
         self.split_wgrad = None if opt["split_wgrad"] is None else int(opt["split_wgrad"])
@@ -564,7 +567,7 @@ class VAEEngine:
             return []
         steps = lambda r: int(r[tkey]) if (r and tkey is not None) else 1                    # noqa: E731
         # the cover depends on (stream count, their lengths, batch, hidden size) only: decided once per signature
-        sig = (len(rows), tuple(steps(r) for r in rows), B, H, self.coop_rounds)
+        sig = (len(rows), tuple(steps(r) for r in rows), B, H, self.coop_rounds, self.coop_cover)
         cover = self._coop_covers.get(sig)
         if cover is None:
             idx = list(range(len(rows)))
@@ -572,9 +575,12 @@ class VAEEngine:
             if len(rows) > 2 and len(rows) % 2 == 0:                   # decoder + future decoder: one pair of directions each
                 options.append(([idx[i:i + 2] for i in range(0, len(rows), 2)], ops.coop_row_chunks(2, B, H, self.coop_rounds)))
             options = [(sets, ch) for sets, ch in options if ch]
+            if self.coop_cover and len(options) > 1:
+                options = [options[self.coop_cover - 1]]
             if options:
-                # every launch lasts as long as its longest sequence: pick the cover with the fewest (launch x step) slots
-                sets, chunks = min(options, key=lambda o: len(o[1]) * sum(max(steps(rows[i]) for i in st) for st in o[0]))
+                # every launch lasts as long as its longest sequence: pick the cover with the fewest (launch x step) slots; on a tie the pairs
+                # (their last row range is more often small enough for 16-row groups: batch 768 4.77 -> 4.65 ms per step)
+                sets, chunks = min(reversed(options), key=lambda o: len(o[1]) * sum(max(steps(rows[i]) for i in st) for st in o[0]))
                 cover = [(st, ch) for st in sets for ch in chunks]
             else:
                 cover = []
