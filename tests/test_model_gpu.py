@@ -434,6 +434,15 @@ def test_odd_multiples_of_32_between_256_and_512_run_the_wide_kernels(hip):
     check_odd_dims_vs_oracle("cuda", F=12, Z=7, H=288, T=3, FS=2, B=5, expect=wide)
 
 
+def test_cooperative_cover_tie_goes_to_pairs_of_directions(hip):
+    """H 128, batch 1,100, T 6, FS 3: the decoders' four streams as [all four] x 3 row ranges or [one pair of directions] x 2 row ranges x 2 are both
+    18 (launch x step) slots -- the engine takes the pairs (two row ranges of 1,024 + 76 rows, every sequence launch two streams), whole step vs the oracle."""
+    def expect(eng):
+        four = [cover for sig, cover in eng._coop_covers.items() if sig[0] == 4]
+        assert four and all(len(st) == 2 for cover in four for st, _ in cover) and all(len(cover) == 4 for cover in four), four
+    check_odd_dims_vs_oracle("cuda", F=12, Z=30, H=128, T=6, FS=3, B=1100, expect=expect)
+
+
 @pytest.mark.parametrize("B,T", [(128, 30), (768, 6), (1100, 6)])
 def test_weight_gradient_flush_forms_by_batch(hip, B, T):
     """The three forms of the weight-gradient flush (engine._flush_wgrads) on the device, each a whole train step against the numpy oracle: up to batch 512
