@@ -139,7 +139,7 @@ def check_gemm_split_rows(dev, small=True):
     rng = np.random.default_rng(12)
     cases = [  # M, N, K, seg_a, b_kmajor, bias, acc, opt
         (70, 136, 64, 0, 0, True, False, 0), (128, 72, 96, 0, 1, False, True, 1), (6 * 30, 100, 64, 30, 0, True, False, 1),
-        (9 * 15, 130, 160, 15, 1, False, False, 0), (301, 30, 32, 7, 0, False, True, 0), (257, 258, 128, 0, 1, True, True, 2),
+        (9 * 15, 130, 160, 15, 1, False, False, 0), (301, 30, 32, 7, 0, False, True, 0), (257, 258, 128, 0, 1, True, True, 2), (33, 137, 64, 0, 0, True, False, 1),
     ]
     if not small:
         cases += [(64 * 30, 768, 512, 30, 0, True, False, 0), (64 * 30, 512, 768, 0, 1, False, True, 0), (4001, 770, 512, 0, 0, True, False, 1),
