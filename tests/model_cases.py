@@ -240,6 +240,74 @@ def check_adam_trajectory(dev):
         np.testing.assert_allclose(sd[k].cpu().numpy(), v, atol=2e-5, err_msg=k)
 
 
+def check_optimizer_checkpoint(dev):
+    """FusedAdamAMSGrad.state_dict() / load_state_dict() (torch's Optimizer API, what checkpointing code calls): a run interrupted after two
+    steps and resumed in a NEW model + optimizer ends on the golden three-step trajectory's weights, like the uninterrupted run."""
+    import io
+    from vame_amd.model.rnn_vae import FusedAdamAMSGrad
+    g = load_golden("step_tiny")
+    win = torch.cat([torch.from_numpy(g["x"]), torch.from_numpy(g["xfut"])], 1).contiguous().to(dev)
+    B, n = win.shape[0], g["adam/eps"].shape[0]
+
+    def run(model, opt, steps):
+        for s_ in steps:
+            model.loss_step(win, 1.0, beta=1.0, kloss=model.spec.Z, klmbda=0.1, bsize=B, eps=torch.from_numpy(g["adam/eps"][s_]).to(dev))
+            opt.step()
+    model, _ = build_model(g, dev)
+    model.train()
+    opt = FusedAdamAMSGrad(model, lr=5e-4)
+    run(model, opt, range(n - 1))
+    blob = io.BytesIO()
+    torch.save(dict(model=model.state_dict(), opt=opt.state_dict()), blob)       # (what a user's checkpoint code does)
+    blob.seek(0)
+    ck = torch.load(blob, map_location=dev, weights_only=False)
+    assert ck["opt"]["fused"]["t"] == n - 1 and ck["opt"]["param_groups"][0]["lr"] == 5e-4
+    model2, _ = build_model(g, dev)
+    model2.train()
+    model2.load_state_dict(ck["model"])
+    opt2 = FusedAdamAMSGrad(model2, lr=1.0)                 # (a wrong rate on purpose: load_state_dict brings the saved one back)
+    opt2.load_state_dict(ck["opt"])
+    run(model2, opt2, range(n - 1, n))
+    sd = model2.state_dict()
+    for k, v in golden_weights(g, "adam/w/").items():
+        np.testing.assert_allclose(sd[k].cpu().numpy(), v, atol=2e-5, err_msg=k)
+
+
+def check_failed_step_leaves_no_sums(dev):
+    """A step that raises between the loss kernels and vame_loss_finish_f32 must not leak its partial sums into the next step's terms."""
+    import pytest
+    g = load_golden("step_tiny")
+    model, (T, F, Z, H, FS, fut, sp) = build_model(g, dev)
+    model.train()
+    win = torch.cat([torch.from_numpy(g["x"]), torch.from_numpy(g["xfut"])], 1).contiguous().to(dev)
+    B = win.shape[0]
+    eps = torch.from_numpy(g["adam/eps"][0]).to(dev)
+    kw = dict(beta=1.0, kloss=Z, klmbda=0.1, bsize=B, eps=eps)
+    good = model.loss_step(win, 1.0, **kw).cpu().numpy()
+    eng = model._engine
+    real = eng.backward
+
+    def boom(*a, **k):
+        raise RuntimeError("injected")
+    eng.backward = boom
+    with pytest.raises(RuntimeError, match="injected"):
+        model.loss_step(win, 1.0, **kw)
+    eng.backward = real
+    assert float(eng.loss_sums().abs().sum()) == 0.0
+    again = model.loss_step(win, 1.0, **kw).cpu().numpy()
+    np.testing.assert_array_equal(good, again)
+
+
+def check_engine_option_validation(dev):
+    import pytest
+    g = load_golden("step_tiny")
+    for bad in (dict(coop_cover=3), dict(coop_cover=-1), dict(coop_rounds=0), dict(small_streams=-1), dict(wgrad_streams=-2), dict(no_such=1)):
+        model, _ = build_model(g, dev)
+        model.engine_options = bad
+        with pytest.raises(ValueError, match=next(iter(bad))):
+            model._ensure_engine()
+
+
 def check_odd_dims_vs_oracle(dev, F=10, Z=7, H=32, T=9, FS=4, B=5, expect=None, engine_options=None):
     """Unaligned shapes (F, Z not multiples of 4; egocentric_data=False gives F = num_features - 2): exercises the scalar-load
     GEMM paths and the non-fused layer-0 input projection, against the numpy oracle (no golden needed)."""
@@ -357,7 +425,7 @@ def check_model_options(dev, name):
 
 
 def check_fused_heads_match(dev):
-    """VAME_AMD_FUSE_HEADS=1 (one kernel per decoder for output Linear + MSE + their backward) gives the losses and gradients of the
+    """engine option fuse_heads (one kernel per decoder for output Linear + MSE + their backward) gives the losses and gradients of the
     default three-launch path."""
     rng = np.random.default_rng(31)
     T, F, Z, H, FS, B = 7, 12, 6, 32, 3, 37

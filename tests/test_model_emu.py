@@ -2,7 +2,7 @@
 reference's golden vectors (tiny model).  The same bodies run on the GPU in test_model_gpu.py."""
 import pytest
 
-from model_cases import check_legacy_padded_hidden, check_decoder_inputs, check_padded_hidden_sizes, check_fused_heads_match, check_adam_trajectory, check_coop_failure_is_contained, check_odd_dims_vs_oracle, check_eval_and_submodules, check_evaluate_and_generative_cores, check_h0_view, check_device_window_loader, check_legacy_step, check_model_options, check_noise_input, check_stale_backward_guard, check_step
+from model_cases import check_legacy_padded_hidden, check_decoder_inputs, check_padded_hidden_sizes, check_fused_heads_match, check_adam_trajectory, check_optimizer_checkpoint, check_failed_step_leaves_no_sums, check_engine_option_validation, check_coop_failure_is_contained, check_odd_dims_vs_oracle, check_eval_and_submodules, check_evaluate_and_generative_cores, check_h0_view, check_device_window_loader, check_legacy_step, check_model_options, check_noise_input, check_stale_backward_guard, check_step
 
 
 @pytest.mark.parametrize("name,kw,mse", [("step_tiny", 1.0, "sum"), ("step_tiny", 0.25, "sum"), ("step_tiny_oddB", 1.0, "sum"),
@@ -59,6 +59,18 @@ def test_stepwise_large_h_path_matches_reference(emu, name, kw):
 
 def test_three_step_adam_trajectory_matches_reference(emu):
     check_adam_trajectory("cpu")
+
+
+def test_optimizer_state_dict_round_trip_resumes_the_trajectory(emu):
+    check_optimizer_checkpoint("cpu")
+
+
+def test_failed_step_leaves_no_partial_loss_sums(emu):
+    check_failed_step_leaves_no_sums("cpu")
+
+
+def test_engine_option_values_are_validated(emu):
+    check_engine_option_validation("cpu")
 
 
 def test_unaligned_feature_and_latent_dims(emu):

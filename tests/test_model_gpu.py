@@ -6,7 +6,7 @@ import torch
 
 from conftest import load_golden
 from tolerances import BIG_REL, assert_grad_close, assert_loss_close, step_scale_of
-from model_cases import check_legacy_padded_hidden, check_decoder_inputs, check_padded_hidden_sizes, check_fused_heads_match, check_adam_trajectory, check_coop_failure_is_contained, check_odd_dims_vs_oracle, check_eval_and_submodules, check_evaluate_and_generative_cores, check_h0_view, check_device_window_loader, check_legacy_step, check_model_options, check_noise_input, check_stale_backward_guard, check_step
+from model_cases import check_legacy_padded_hidden, check_decoder_inputs, check_padded_hidden_sizes, check_fused_heads_match, check_adam_trajectory, check_optimizer_checkpoint, check_failed_step_leaves_no_sums, check_engine_option_validation, check_coop_failure_is_contained, check_odd_dims_vs_oracle, check_eval_and_submodules, check_evaluate_and_generative_cores, check_h0_view, check_device_window_loader, check_legacy_step, check_model_options, check_noise_input, check_stale_backward_guard, check_step
 from oracle import vame_oracle as vo
 from vame_amd.model.rnn_model import RNN_VAE
 
@@ -270,6 +270,18 @@ def test_headline_batch_4096_all_gradients_vs_torch_cpu_reference(hip):
 
 def test_three_step_adam_trajectory_matches_reference(hip):
     check_adam_trajectory("cuda")
+
+
+def test_optimizer_state_dict_round_trip_resumes_the_trajectory(hip):
+    check_optimizer_checkpoint("cuda")
+
+
+def test_failed_step_leaves_no_partial_loss_sums(hip):
+    check_failed_step_leaves_no_sums("cuda")
+
+
+def test_engine_option_values_are_validated(hip):
+    check_engine_option_validation("cuda")
 
 
 def test_unaligned_feature_and_latent_dims(hip):

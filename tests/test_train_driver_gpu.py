@@ -97,8 +97,10 @@ def test_graphed_step_is_bit_identical_to_eager(hip, engine_options):
         g = GraphedTrainStep(model, opt, loader, acc, warmup=3 if graphed else 10 ** 9, **kw)
         snaps, terms = [], []
         for i in range(10):
+            if i == 3:
+                opt.param_groups[0]["lr"] = 4e-4               # a cut exactly between the last eager step and the capture: its fill must stay OUTSIDE the graph
             if i == 6:
-                opt.param_groups[0]["lr"] = 2e-4               # a scheduler's cut between two replays: the kernel reads the rate from the device word
+                opt.param_groups[0]["lr"] = 1.6e-4             # a scheduler's cut between two replays: the kernel reads the rate from the device word
             t = g(starts[i])
             terms.append(t.cpu().numpy().copy())
             snaps.append(model.flat_parameters()[0].cpu().numpy().copy())
@@ -118,7 +120,7 @@ def test_graphed_step_is_bit_identical_to_eager(hip, engine_options):
         assert eng._coop_state is not None                     # batch 256: the cooperative GRU kernels (their epoch counter lives on the device)
         eng.check_async_errors()
         runs.append(dict(snaps=snaps, terms=terms, acc=acc.cpu().numpy(), m=opt.m.cpu().numpy(), vmax=opt.vmax.cpu().numpy(),
-                         adam=opt.state.cpu().numpy()[1:3], rng=eng._rng.cpu().numpy(), epoch=eng._coop_state.epoch.cpu().numpy(), t=opt.t))
+                         adam=opt.dev_state.cpu().numpy()[1:3], rng=eng._rng.cpu().numpy(), epoch=eng._coop_state.epoch.cpu().numpy(), t=opt.t))
     a, b = runs
     for i in range(13):
         np.testing.assert_array_equal(a["snaps"][i], b["snaps"][i], err_msg=f"weights after step {i}")
@@ -129,4 +131,4 @@ def test_graphed_step_is_bit_identical_to_eager(hip, engine_options):
     np.testing.assert_allclose(a["acc"], b["acc"], rtol=1e-6)
     assert not np.array_equal(a["snaps"][0], a["snaps"][9])
     step5, step6 = (np.abs(a["snaps"][i + 1] - a["snaps"][i]).mean() for i in (4, 6))
-    assert step6 < 0.6 * step5                                 # 2e-4 / 5e-4 = 0.4 of the update size
+    assert step6 < 0.6 * step5                                 # 1.6e-4 / 4e-4 = 0.4 of the update size

@@ -178,6 +178,12 @@ class VAEEngine:
         self.coop = bool(opt["coop"])
         self.coop_rounds = int(opt["coop_rounds"])
         self.coop_cover = int(opt["coop_cover"])
+        # (these arrive from the user's config.yaml, `vame_amd_engine:` -- refuse values that would only fail deep inside a launch plan)
+        for name, ok, want in (("coop_cover", self.coop_cover in (0, 1, 2), "0 (by cost), 1 (all streams per launch) or 2 (pairs of directions)"),
+                               ("coop_rounds", self.coop_rounds >= 1, ">= 1"), ("small_streams", self.small_streams >= 0, ">= 0"),
+                               ("wgrad_streams", self.wgrad_streams >= 0, ">= 0")):
+            if not ok:
+                raise ValueError(f"engine option {name} = {opt[name]!r}: expected {want}")
         self.wide = bool(opt["wide"])
         self.wide_bwd = bool(opt["wide_bwd"])
         self.split_wgrad = None if opt["split_wgrad"] is None else int(opt["split_wgrad"])

@@ -382,6 +382,22 @@ class RNN_VAE(nn.Module):
         training = self.training
         eng.poll_async_errors()
         _check(F == s.F and L >= s.T + (s.FS if (training and s.future) else 0), f"window batch {tuple(win.shape)} too short")
+        try:
+            return self._loss_step(eng, win, kl_weight, beta, kloss, klmbda, bsize, mse_red, mse_pred, eps, backward, enc_in, drop_mask, weights, acc)
+        except BaseException:
+            # the loss kernels ADD into the 8-float sum buffer and only vame_loss_finish_f32 -- the last launch of a step -- zeroes it: a step that
+            # raised in between (a shape check, a VameHipError, an out-of-memory the caller catches) must not leak its partial sums into the next
+            if not eng.capturing:
+                try:
+                    eng.loss_sums().zero_()
+                except Exception:
+                    pass
+            raise
+
+    def _loss_step(self, eng, win, kl_weight, beta, kloss, klmbda, bsize, mse_red, mse_pred, eps, backward, enc_in, drop_mask, weights, acc):
+        s = self.spec
+        B, L, F = win.shape
+        training = self.training
         with torch.no_grad():
             if enc_in is not None:
                 enc_in = enc_in.to(device=eng.dev, dtype=torch.float32).contiguous()

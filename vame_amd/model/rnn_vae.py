@@ -104,7 +104,8 @@ class FusedAdamAMSGrad(torch.optim.Optimizer):
         self.dropped = torch.zeros(1, dtype=torch.int32, device=self.flat_p.device)   # launches the abort word turned into no-ops
         # {learning rate (float bits), updates applied, ticket, -}: the kernel reads lr and the bias-correction step from here and counts itself,
         # so its argument list never changes (vame_adam_amsgrad_f32 `state`; a captured step graph replays it, GraphedTrainStep)
-        self.state = torch.zeros(4, dtype=torch.int32, device=self.flat_p.device)
+        # (named dev_state: torch.optim.Optimizer owns `self.state`, the per-parameter dict that state_dict() walks)
+        self.dev_state = torch.zeros(4, dtype=torch.int32, device=self.flat_p.device)
         self._lr_on_device = None
         self._hooked = None
 
@@ -112,7 +113,7 @@ class FusedAdamAMSGrad(torch.optim.Optimizer):
         """Write the current learning rate to the device word the kernel reads (one tiny fill, only when a scheduler changed it)."""
         lr = float(self.param_groups[0]["lr"])
         if lr != self._lr_on_device:
-            self.state.view(torch.float32)[0:1].fill_(lr)
+            self.dev_state.view(torch.float32)[0:1].fill_(lr)
             self._lr_on_device = lr
 
     def _forget_dropped_steps(self):
@@ -136,10 +137,28 @@ class FusedAdamAMSGrad(torch.optim.Optimizer):
             self._hooked = eng._coop_state
         ops.adam_amsgrad(flat_p, flat_g, self.m, self.v, self.vmax, flat_p.numel(), g["lr"], self.t, gscale=gscale,
                          beta1=g["betas"][0], beta2=g["betas"][1], eps=g["eps"], abort_flag=flag,
-                         dropped=self.dropped if flag is not None else None, state=self.state)
+                         dropped=self.dropped if flag is not None else None, state=self.dev_state)
 
     def zero_grad(self, set_to_none=False):
         pass  # every backward overwrites the whole bucket
+
+    def state_dict(self):
+        """The moments live in three flat buffers beside the parameter bucket, not in torch's per-parameter `state`: a checkpoint
+        carries them (and the step count, read back from the device word the kernel counts in) under "fused"."""
+        sd = super().state_dict()
+        sd["fused"] = dict(m=self.m.clone(), v=self.v.clone(), vmax=self.vmax.clone(), t=int(self.dev_state[1].item()))
+        return sd
+
+    def load_state_dict(self, state_dict):
+        state_dict = dict(state_dict)
+        fused = state_dict.pop("fused", None)
+        super().load_state_dict(state_dict)
+        if fused is not None:
+            for dst, key in ((self.m, "m"), (self.v, "v"), (self.vmax, "vmax")):
+                dst.copy_(fused[key].to(dst.device))
+            self.t = int(fused["t"])
+            self.dev_state[1:2].fill_(self.t)
+        self._lr_on_device = None                            # param_groups may carry another learning rate: upload it before the next launch
 
 
 class GraphedTrainStep:
@@ -169,6 +188,7 @@ class GraphedTrainStep:
 
     def _capture(self):
         eng = self.model._ensure_engine(touch=False)
+        self.opt.sync_lr()                               # outside the capture: a learning-rate fill baked into the graph would undo every later change
         self.graph = torch.cuda.CUDAGraph()
         eng.capturing = True
         try:

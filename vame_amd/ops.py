@@ -329,8 +329,8 @@ class CoopState:
             for cb in self.on_error:
                 cb()
             raise _lib.VameHipError(f"cooperative GRU kernel: {n} hand-off wait(s) timed out (workgroups of a group were not co-resident); "
-                                    "the affected optimizer step was dropped on the device; set engine.coop = False "
-                                    "(VAME_AMD_COOP=0) to use the batch-tile-persistent kernels")
+                                    "the affected optimizer step was dropped on the device; pass engine_options={'coop': False} "
+                                    "(config.yaml: `vame_amd_engine: {coop: false}`) to use the batch-tile-persistent kernels")
 
     def check(self, reduce=None):
         """Host sync: raise if a cooperative launch ever gave up waiting for a group member (its results were undefined).
