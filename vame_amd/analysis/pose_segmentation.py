@@ -95,11 +95,6 @@ def embedd_latent_vectors(cfg, files, model, fixed):
     return latent_vector_files
 
 
-def consecutive(data, stepsize=1):
-    data = data[:]
-    return np.split(data, np.where(np.diff(data) != stepsize)[0] + 1)
-
-
 def get_motif_usage(label):
     """Counts per motif id with zero-filled gaps (pose_segmentation.py:109-126)."""
     ids, counts = np.unique(label, return_counts=True)
