@@ -261,8 +261,9 @@ def roofline_block(agg, value_per_gpu, mflop_per_window, ms_per_step, dump=False
                 timer_outliers=sum(d.get("outliers", 0) for d in agg.values()),
                 by_class=by_class, timed_kernel_ms_per_step=round(sum(d["ms"] for d in agg.values()), 3),
                 mfma_kernel_ms_per_step=round(mfma_ms, 3), non_mfma_ms_per_step=round(max(0.0, ms_per_step - mfma_ms), 3),
-                # serial sum of every timed kernel minus the step time of the timed region: what the side-stream overlaps hide (positive) or what
-                # the host adds between launches (negative: a host-bound step)
+                # serial sum of every TIMED kernel minus the step time of the timed region: what the side-stream overlaps hide (positive).  Negative: the
+                # launches this table does not time (split-K reductions, column sums, nuclear-norm solve, latent / loss / Adam kernels) plus launch gaps
+                # outweigh what is hidden -- a host-bound small batch, or a wide shape (H > 256), where the engine runs without side streams at all
                 hidden_by_overlaps_ms_per_step=round(sum(d["ms"] for d in agg.values()) - ms_per_step, 3),
                 note="per-kernel times: 3 separate steps with the side-stream overlaps off (serial); ms_per_step: timed region with them on; "
                      "non_mfma_ms_per_step = max(0, ms_per_step - mfma_kernel_ms_per_step) understates the non-MFMA time by what the overlaps hide")

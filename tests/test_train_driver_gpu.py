@@ -132,3 +132,44 @@ def test_graphed_step_is_bit_identical_to_eager(hip, engine_options):
     assert not np.array_equal(a["snaps"][0], a["snaps"][9])
     step5, step6 = (np.abs(a["snaps"][i + 1] - a["snaps"][i]).mean() for i in (4, 6))
     assert step6 < 0.6 * step5                                 # 1.6e-4 / 4e-4 = 0.4 of the update size
+
+
+def test_hip_graph_auto_times_both_forms_and_keeps_one(hip):
+    """round 6: `vame_amd_hip_graph: auto` decides by measurement (GraphedTrainStep._measure): 20 eager steps and 20 replays after the warm-up, each span
+    between two events, the faster form kept per batch size.  Whatever it picks, the trajectory is the eager one's bits."""
+    import numpy as np
+    import torch
+    from vame_amd.model.dataloader import DeviceWindowLoader
+    from vame_amd.model.rnn_model import RNN_VAE
+    from vame_amd.model.rnn_vae import FusedAdamAMSGrad, GraphedTrainStep
+    T, F, Z, H, FS, B, N = 30, 12, 30, 256, 15, 256, 40000
+
+    class DS:
+        data_points, X, temporal_window = N, np.empty((F, 1)), 2 * T
+
+        @staticmethod
+        def normalised_f32():
+            return np.random.default_rng(5).standard_normal((F, N)).astype(np.float32)
+    dev = torch.device("cuda", 0)
+    kw = dict(kl_weight=0.5, beta=1.0, kloss=Z, klmbda=0.1, bsize=B, weights=(1.0, 1.0, 0.5, 0.5))
+    steps = 3 + 2 * GraphedTrainStep.MEASURE_STEPS + 2 + 4
+    starts = np.random.default_rng(6).integers(0, N - 2 * T, size=(steps, B))
+    finals, choice = [], {}
+    for auto in (False, True):
+        torch.manual_seed(19)
+        model = RNN_VAE(2 * T, Z, F, 1, FS, H, H, H, H, 0, 0, 0, False).to(dev).train()
+        opt = FusedAdamAMSGrad(model, lr=5e-4)
+        loader = DeviceWindowLoader(DS(), B, T + FS, dev)
+        acc = torch.zeros(6, dtype=torch.float64, device=dev)
+        model._ensure_engine().seed_rng(777)
+        g = GraphedTrainStep(model, opt, loader, acc, warmup=3 if auto else 10 ** 9, choice=choice if auto else None, **kw)
+        for i in range(steps):
+            g(starts[i])
+        model._engine.check_async_errors()
+        finals.append(model.flat_parameters()[0].cpu().numpy().copy())
+    assert choice.get(B) in ("graph", "eager"), choice
+    t_eager, t_graph = choice[("ms_per_step", B)]
+    assert 0.5 < t_eager < 20 and 0.5 < t_graph < 20, (t_eager, t_graph)
+    assert (choice[B] == "graph") == (t_graph <= t_eager)
+    np.testing.assert_array_equal(finals[0], finals[1])
+    print(f"hip_graph auto at batch {B}: eager {t_eager:.3f} ms/step, replay {t_graph:.3f} ms/step -> {choice[B]}")

@@ -198,7 +198,10 @@ class VAEEngine:
         # when the decoders' GRU launch has finished and runs beside the HBM-bound head / MSE / dY kernels, which leave most of a
         # CU's registers and LDS free -- unlike the GRU launches, which need whole CUs (a solve beside them was measured to cost
         # as much as it saves).  Joined before dz reads Minv and before the loss terms are handed out.
-        self.nuc_side = bool(opt["nuc_side"])
+        # (wide shapes, H > 256: the side streams were measured to COST time -- configs[3], batch 8192: 202.6 ms per step with them, 201.5 without,
+        # profiles/r06_cfg3_overlap_ab.txt -- their partners there are the LDS-filling wide GRU launches and contractions that already fill the chip)
+        wide_shape = max(H, Hd, Hf) > 256
+        self.nuc_side = bool(opt["nuc_side"]) and not wide_shape
         # Small batches: the decoders' BPTT launch is the cooperative column-split kernel, one workgroup on EVERY CU, and the solve's single
         # workgroup still holds a CU when it starts (their LDS footprints exclude each other: 153 KB + 98 KB), so one 8-member group of the
         # launch starts late.  Measured at batch 256 (tools/step_ab.py, profiles/r04_b256_overlap.txt): joining the solve in front of that
@@ -206,7 +209,7 @@ class VAEEngine:
         # serialisation, and its members' waits are bounded polls of 0.3 s against a 0.2 ms solve.  True = join (diagnostics).
         self.nuc_join_before_coop = False
         # the future decoder's two dW_hh contractions beside the small-kernel chain that follows the decoders' BPTT launch (_early_wgrads)
-        self.bwd_overlap = bool(opt["bwd_overlap"])
+        self.bwd_overlap = bool(opt["bwd_overlap"]) and not wide_shape
         self.skinny_side = bool(opt["skinny_side"])
         self._wgrad_plans = {}
         self._coop_covers = {}
@@ -360,6 +363,11 @@ class VAEEngine:
                 rounds = self.wgrad_min_rounds or (1 if K < (1 << 18) else 2)
                 full = [k for k in cands if tiles * k >= rounds * 768 and (tiles * k) % 768 == 0]
                 sk = full[0] if full else next((k for k in cands if tiles * k >= rounds * 768), cands[-1] if cands else 8)
+                if K >= (1 << 18) and full:
+                    # long slabs (configs[3]: K = 491,520, 288 tiles per slab): the workgroups that share an operand panel drift apart and re-fetch it -- 56.9 GB per
+                    # launch against 24.2 GB of operands at split-K 8, 47.7 GB at 96 for the same time within 1 % (profiles/r05_cfg3_gemm_splitk_traffic.txt):
+                    # the shortest slabs that still fill whole rounds, up to 96
+                    sk = max(k for k in full if k <= 96)
                 launches.append((grp, part, M, N, K, sk, key[9], key[10], [self.table.off(jobs[i][5]) for i in part]))
         return launches, rest
 
@@ -873,6 +881,14 @@ class VAEEngine:
             self.cluster_terms(*args)
             self._nuc_event = torch.cuda.Event()
             self._nuc_event.record(self._nuc_stream)
+
+    def abandon_step(self):
+        """A step raised between its first loss kernel and vame_loss_finish_f32 (the only launch that zeroes the sums): drop a solve that was deferred but not
+        issued, wait for one that is running on the side stream (it still adds its term), then zero the sums so that the next step starts clean."""
+        self._nuc_pending = None
+        self.join_cluster()
+        self._join_early()
+        self.loss_sums().zero_()
 
     def join_cluster(self):
         """Before Minv / losses[KMEANS] are read on the caller's stream."""

@@ -389,7 +389,7 @@ class RNN_VAE(nn.Module):
             # raised in between (a shape check, a VameHipError, an out-of-memory the caller catches) must not leak its partial sums into the next
             if not eng.capturing:
                 try:
-                    eng.loss_sums().zero_()
+                    eng.abandon_step()
                 except Exception:
                     pass
             raise

@@ -171,7 +171,12 @@ class GraphedTrainStep:
     Single rank only (the gradient all-reduce stays outside a graph).  Results are bit-identical to the eager step
     (tests/test_train_driver_gpu.py::test_graphed_step_is_bit_identical_to_eager)."""
 
-    def __init__(self, model, optimizer, loader, acc, warmup=3, **loss_kwargs):
+    MEASURE_STEPS = 20
+
+    def __init__(self, model, optimizer, loader, acc, warmup=3, choice=None, **loss_kwargs):
+        """choice: None = always replay (hip_graph: true).  A dict = hip_graph "auto": the first MEASURE_STEPS steps after the warm-up run eagerly and the
+        next MEASURE_STEPS as replays, each span between two events; the faster form is kept and remembered in the dict under the loader's batch size
+        (both forms give the same bits, so the mix changes nothing but the time)."""
         assert isinstance(optimizer, FusedAdamAMSGrad) and not _dist_active()
         self.model, self.opt, self.loader, self.acc, self.kw = model, optimizer, loader, acc, loss_kwargs
         self.dev = model.flat_parameters()[0].device
@@ -179,12 +184,33 @@ class GraphedTrainStep:
         self.terms = None
         self._seen = None
         self.warmup = warmup
+        self.choice = choice
+        self._ev, self._n = [], 0
 
     def _eager(self):
         win = self.loader.gather_static()
         terms = self.model.loss_step(win, acc=self.acc, **self.kw)
         self.opt.step()
         return terms
+
+    def _measure(self):
+        """hip_graph "auto": which form this call takes while the decision is open -- MEASURE_STEPS eager steps, then MEASURE_STEPS replays (the
+        capture in between is outside both spans), then the comparison (the one host synchronisation of the protocol)."""
+        n, N = self._n, self.MEASURE_STEPS
+        self._n += 1
+        if n in (0, N, N + 1, 2 * N + 1):
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record()
+            self._ev.append(ev)
+        if n < N:
+            return "eager"
+        if n <= 2 * N:                                   # (n == N: this call captures and replays once, untimed)
+            return "graph"
+        self._ev[3].synchronize()
+        t_eager, t_graph = self._ev[0].elapsed_time(self._ev[1]), self._ev[2].elapsed_time(self._ev[3])
+        self.choice[self.loader.B] = "graph" if t_graph <= t_eager else "eager"
+        self.choice[("ms_per_step", self.loader.B)] = (t_eager / N, t_graph / N)
+        return self.choice[self.loader.B]
 
     def _capture(self):
         eng = self.model._ensure_engine(touch=False)
@@ -207,6 +233,12 @@ class GraphedTrainStep:
         if self.warmup > 0 or self.dev.type != "cuda":   # the first steps run eagerly: workspaces, plans and caches settle before the capture
             self.warmup -= 1
             return self._eager()
+        if self.choice is not None:
+            mode = self.choice.get(self.loader.B)
+            if mode is None:
+                mode = self._measure()
+            if mode == "eager":
+                return self._eager()
         if self.graph is not None and self._seen != (eng, ops.ALLOC_GEN[0], self.model._flat_p.data_ptr()):
             # a buffer the captured launches point into was reallocated since (another batch size grew a workspace, the model moved):
             # run this step eagerly -- which settles the buffers for this shape again -- and capture afresh on the next call
@@ -276,7 +308,8 @@ def _to_windows(item, keep, dev):
 def _graphed_step_for(model, optimizer, loader, noise, hip_graph, kw):
     """The cached GraphedTrainStep of this (model, optimizer, loader, loss arguments), or None where the step runs eagerly: several ranks (the
     all-reduce stays outside a graph), options that draw with torch inside the step (input noise, encoder dropout), a loader that is not the
-    device batcher, hip_graph = False, or -- hip_graph = None, "auto" -- a batch above 1024, where the step is GPU-bound anyway."""
+    device batcher, hip_graph = False, or -- hip_graph = None, "auto" -- a batch above 1024, where the step is GPU-bound anyway.  Up to 1024 "auto" times
+    both forms in the first epoch and keeps the faster (GraphedTrainStep._measure): which one wins differs between boxes (2.04 vs 2.11 ms at batch 256)."""
     from .dataloader import DeviceWindowLoader
     dev = model.flat_parameters()[0].device
     if (hip_graph is False or dev.type != "cuda" or _dist_active() or noise == True or model.spec.dropout > 0  # noqa: E712
@@ -291,7 +324,9 @@ def _graphed_step_for(model, optimizer, loader, noise, hip_graph, kw):
         if len(cache) >= 8:                  # (KL annealing makes a few distinct weights, then one for the rest of the run)
             cache.pop(next(iter(cache)))
         acc = optimizer.__dict__.setdefault("_epoch_acc", torch.zeros(6, device=dev, dtype=torch.float64))
-        g = cache[key] = GraphedTrainStep(model, optimizer, loader, acc, **kw)
+        # "auto": decided by timing both forms once per batch size (kept across the loss-weight changes of KL annealing, which make new step objects)
+        choice = optimizer.__dict__.setdefault("_graph_choice", {}) if hip_graph in (None, "auto") else None
+        g = cache[key] = GraphedTrainStep(model, optimizer, loader, acc, choice=choice, **kw)
     return g
 
 
