@@ -202,7 +202,7 @@ def test_model_options_dropout_and_hidden_sizes(name):
 
 
 def test_hmm_oracle_vs_sklearn_mixture_in_the_iid_limit():
-    """A second, third-party anchor at a realistic length (hmmlearn itself cannot be obtained here, DESIGN section 4): an HMM whose
+    """A second, third-party anchor at a realistic length (hmmlearn itself cannot be obtained here, DESIGN.md section 5): an HMM whose
     transition rows all equal its start distribution w emits i.i.d. draws from the mixture sum_k w_k N(mu_k, S_k), so its
     log-likelihood and state posteriors over 3000 frames must equal scikit-learn's GaussianMixture with the same parameters --
     which exercises the log-domain forward / backward recursions, the density and the posterior normalisation far beyond the

@@ -119,7 +119,7 @@ def _kmeans_cls(cfg):
 def _hmm_cls(cfg):
     """hmmlearn's GaussianHMM (the reference's exact behaviour, pose_segmentation.py:20,145-158) unless cfg['amd_gpu_hmm'] is set;
     then the same Baum-Welch / Viterbi on the MI355X (vame_amd/analysis/hmm_hip.py).  The GPU model is never chosen silently: its
-    parity with hmmlearn is unpinned (DESIGN.md section 4) and its pickle is not loadable by the reference."""
+    parity with hmmlearn is unpinned (DESIGN.md section 5) and its pickle is not loadable by the reference."""
     if cfg.get('amd_gpu_hmm', False):
         from .hmm_hip import GaussianHMMHIP
         return GaussianHMMHIP

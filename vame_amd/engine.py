@@ -197,7 +197,7 @@ class VAEEngine:
         # nuclear-norm solve (one workgroup, ~0.2 ms, nothing else on the chip) on a side stream NEXT TO THE OUTPUT HEADS: it starts
         # when the decoders' GRU launch has finished and runs beside the HBM-bound head / MSE / dY kernels, which leave most of a
         # CU's registers and LDS free -- unlike the GRU launches, which need whole CUs (a solve beside them was measured to cost
-        # as much as it saves).  Joined before dz reads Minv and before the loss terms are handed out.
+        # as much as it saves, profiles/NOTES.md section 8).  Joined before dz reads Minv and before the loss terms are handed out.
         # (wide shapes, H > 256: the side streams were measured to COST time -- configs[3], batch 8192: 202.6 ms per step with them, 201.5 without,
         # profiles/r06_cfg3_overlap_ab.txt -- their partners there are the LDS-filling wide GRU launches and contractions that already fill the chip)
         wide_shape = max(H, Hd, Hf) > 256
