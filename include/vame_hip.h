@@ -187,17 +187,20 @@ int vame_latent_bwd_f32(const float* dz, const float* mu, const float* logvar, c
 int vame_mse_fwd_bwd_f32(const float* pred, const float* target, int64_t tgt_row, int B, int TF,
                          float gscale, float* dpred, float* loss_out, void* stream);
 
-/* Output head of a decoder in the training step, fused (vame/model/rnn_model.py:107-108,139-140 hidden_to_output; rnn_vae.py:35-43
- * MSE with reduction "sum"; and their backward): for the M = B*T rows m = (b,t), b = m / y_seg,
- *   y_m = Y + b*y_seg_stride + t*y_ld (K floats);  pred[m,f] = y_m . W[f,:] + bias[f]  (F <= 32, K % 32 == 0);
+/* Output head of a decoder in the training step as ONE pass over the decoder's states (vame/model/rnn_model.py:107-108,139-140
+ * hidden_to_output; rnn_vae.py:35-43 MSE with reduction "sum"; rnn_vae.py:141-143 loss.backward() through both): for the M = B*T rows
+ * m = (b,t), b = m / y_seg,
+ *   y_m = Y + b*y_seg_stride + t*y_ld (K floats);  pred[m,f] = y_m . W[f,:] + bias[f];
  *   e = pred - tgt[b*tgt_row + tgt_off + t*F + f];  loss[0] += sum e^2;  dpred[m,f] = gscale*e;
- *   dY[m*dy_ld + n] = sum_f dpred[m,f] W[f,n], n < K.
- * pred may be null.  Replaces vame_gemm_f32 (N = F) + vame_mse_fwd_bwd_f32 + vame_gemm_f32 (K = F) on the training path; the
- * stand-alone decoder calls keep the GEMM.  State rows and W must be 16-byte aligned.  vame_head_fused_lds_bytes(F, K) <= 160 KiB. */
-int64_t vame_head_fused_lds_bytes(int F, int K);
-int vame_head_fused_f32(const float* Y, int64_t y_ld, int64_t y_seg, int64_t y_seg_stride, int M, int F, int K, const float* W,
-                        const float* bias, const float* tgt, int64_t tgt_row, int64_t tgt_off, float gscale, float* pred,
-                        float* dpred, float* dY, int64_t dy_ld, float* loss, void* stream);
+ *   dY[m*dy_ld + n] = sum_f dpred[m,f] W[f,n], n < K;   dW[f,n] = sum_m dpred[m,f] y_m[n]  (overwritten; deterministic order).
+ * pred may be null.  Replaces vame_gemm_f32 (N = F) + vame_mse_fwd_bwd_f32 + vame_gemm_f32 (K = F) + the split-K weight-gradient
+ * vame_gemm_f32 (M = F, K = B*T) and its reduction on the training path; the stand-alone decoder calls keep the GEMM.
+ * Shapes: 1 <= F <= 32, K a multiple of 64 up to 512; state rows, W and dY rows 16-byte aligned.  ws: vame_head_stream_ws_floats(M, F, K)
+ * floats of scratch (per-workgroup dW sums); that function returns -1 for a shape the kernel does not cover. */
+int64_t vame_head_stream_ws_floats(int M, int F, int K);
+int vame_head_stream_f32(const float* Y, int64_t y_ld, int64_t y_seg, int64_t y_seg_stride, int M, int F, int K, const float* W,
+                         const float* bias, const float* tgt, int64_t tgt_row, int64_t tgt_off, float gscale, float* pred,
+                         float* dpred, float* dY, int64_t dy_ld, float* loss, float* dW, float* ws, void* stream);
 
 /* cluster_loss (vame/model/rnn_vae.py:45-50) from the (Z,Z) Gram G = z^T z (un-normalised, from vame_gemm_f32):
  *   loss_out[0] = lmbda * sum_{i<k} sqrt(eig_i(G/bsize)),  Minv (Z,Z) = gscale*(lmbda/bsize) V_k S_k^-1 V_k^T

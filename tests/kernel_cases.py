@@ -860,8 +860,9 @@ def check_mse(dev):
 
 
 def check_head_fused(dev, B=7, T=9, F=24, K=64, pad=2):
-    """Fused output head (Linear -> MSE(sum) -> dpred -> dY) vs float64 numpy, on the decoder-state layout (B, T+pad, K) with a row
-    offset, a ragged last 32-row tile and a target window inside a wider row."""
+    """Streaming output head (Linear -> MSE(sum) -> dpred -> dY, and the Linear's weight gradient, one pass over the states) vs float64 numpy, on the
+    decoder-state layout (B, T+pad, K) with a row offset, a ragged last 16-row tile, a target window inside a wider row, dY rows wider than K and
+    dW at an offset inside a larger gradient bucket."""
     rng = np.random.default_rng(21)
     Y = rng.standard_normal((B, T + pad, K)).astype(np.float32)
     W = (rng.standard_normal((F, K)) / np.sqrt(K)).astype(np.float32)
@@ -873,21 +874,29 @@ def check_head_fused(dev, B=7, T=9, F=24, K=64, pad=2):
     pred, dpred = torch.zeros(B * T, F, device=dev), torch.zeros(B * T, F, device=dev)
     dY = torch.full((B * T, K + 8), 7.0, device=dev)
     loss = torch.full((3,), 0.5, device=dev)
-    assert ops.head_fused_ok(F, K)
+    bucket = torch.full((F * K + 24,), 3.0, device=dev)
+    n_ws = ops.head_stream_ws_floats(B * T, F, K)
+    assert n_ws > 0 and ops.head_stream_ws_floats(B * T, 33, K) == -1 and ops.head_stream_ws_floats(B * T, F, K + 32) == -1
+    ws = torch.full((n_ws,), float("nan"), device=dev)              # (every word the reduction reads must have been written by the kernel)
     o1 = 1 if pad else 0
-    ops.head_fused(Operand(Yt, K, off=o1 * K, seg=T, seg_stride=(T + pad) * K), B * T, F, K, Operand(Wt, K), T_(bias, dev), T_(win, dev), off, row, gs,
-                   pred, dpred, dY, K + 8, loss, 1)
+    for _ in range(2):                                              # (a second call on the same buffers: dW is overwritten, the loss slot adds)
+        ops.head_stream(Operand(Yt, K, off=o1 * K, seg=T, seg_stride=(T + pad) * K), B * T, F, K, Operand(Wt, K), T_(bias, dev), T_(win, dev), off, row, gs,
+                        pred, dpred, dY, K + 8, loss, 1, bucket, 16, ws)
     y = Y[:, o1:o1 + T].reshape(B * T, K).astype(np.float64)
     p = y @ W.astype(np.float64).T + bias
     tgt = win[:, off:off + T * F].reshape(B * T, F)
     e = p - tgt
     np.testing.assert_allclose(N_(pred), p, atol=2e-5)
     np.testing.assert_allclose(N_(dpred), gs * e, atol=5e-5)
-    np.testing.assert_allclose(N_(loss)[1], 0.5 + (e ** 2).sum(), rtol=2e-5)
+    np.testing.assert_allclose(N_(loss)[1], 0.5 + 2 * (e ** 2).sum(), rtol=2e-5)
     assert N_(loss)[0] == 0.5 and N_(loss)[2] == 0.5
     out = N_(dY)
     np.testing.assert_allclose(out[:, :K], (gs * e) @ W.astype(np.float64), atol=1e-4)
     assert (out[:, K:] == 7.0).all()
+    dW_ref = (gs * e).T @ y
+    got = N_(bucket)
+    np.testing.assert_allclose(got[16:16 + F * K].reshape(F, K), dW_ref, atol=3e-5 * max(1.0, float(np.abs(dW_ref).max())))
+    assert (got[:16] == 3.0).all() and (got[16 + F * K:] == 3.0).all()
 
 
 def check_colsum(dev):

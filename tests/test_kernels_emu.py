@@ -142,6 +142,6 @@ def test_gemm_group_shared_output(emu):
     check_gemm_group_shared_output(DEV)
 
 
-@pytest.mark.parametrize("B,T,F,K,pad", [(7, 9, 24, 64, 2), (3, 50, 10, 32, 0), (5, 31, 32, 96, 2)])
+@pytest.mark.parametrize("B,T,F,K,pad", [(7, 9, 24, 64, 2), (3, 50, 10, 128, 0), (5, 31, 32, 192, 2), (290, 30, 24, 64, 2)])
 def test_fused_output_head(emu, B, T, F, K, pad):
     check_head_fused(DEV, B, T, F, K, pad)

@@ -46,9 +46,9 @@ _SIGS = {
     "vame_loss_finish_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
     "vame_latent_bwd_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_void_p,
                                     c_void_p, c_void_p]),
-    "vame_head_fused_lds_bytes": (c_int64, [c_int, c_int]),
-    "vame_head_fused_f32": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int64, c_int64,
-                            c_float, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
+    "vame_head_stream_ws_floats": (c_int64, [c_int, c_int, c_int]),
+    "vame_head_stream_f32": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int64, c_int64,
+                             c_float, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
     "vame_mse_fwd_bwd_f32": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p]),
     "vame_nuclear_state_doubles": (c_int64, [c_int]),
     "vame_nuclear_f32": (c_int, [c_void_p, c_int, c_int, c_int, c_float, c_float, c_float, c_void_p, c_void_p, c_void_p, c_void_p]),

@@ -1,19 +1,29 @@
-// Output head of a decoder in the TRAINING step, one kernel: hidden_to_output Linear -> MSE(sum) -> its gradient -> back through the
-// Linear to the decoder's output sequence.
+// Output head of a decoder in the TRAINING step as ONE pass over the decoder's states: hidden_to_output Linear -> MSE(sum) -> its gradient ->
+// back through the Linear to the state sequence, AND the Linear's weight gradient.
 //
 //   reference: prediction = hidden_to_output(decoder_states)                      vame/model/rnn_model.py:107-108, 139-140
 //              rec_loss = mse_loss(x_tilde, x, reduction)  (and the future one)   vame/model/rnn_vae.py:35-43, 124-125
-//              their backward: d loss / d prediction, d prediction / d states
+//              loss.backward(): d loss / d prediction, d prediction / d states, d loss / d hidden_to_output.weight   rnn_vae.py:141-143
 //
-// As separate launches this was a (B*T x 24 x 512) GEMM, the MSE kernel and a (B*T x 512 x 24) GEMM: the first reads the 252 MB of
-// decoder states, the last writes 252 MB of state gradients, each at 2.6-3.3 TB/s inside the step because a tile of either has almost
-// no arithmetic to hide its memory time behind.  Here a wave owns 32 rows (b,t): it contracts their states with W (F x K, resident in
-// LDS) into a 32 x 32 accumulator tile = prediction, forms error / loss / dpred in registers, turns the tile from the MFMA C layout into
-// the A layout through a 4.6 KB LDS scratch and contracts it with W again into the 32 x K gradient rows, which leave through the same
-// scratch as full 128-byte row segments (16 bytes per lane).  Reads and writes of the two big streams overlap in one kernel; pred and dpred (12 MB each) are still written
-// (dpred feeds the weight / bias gradients of the Linear, pred is part of the engine's observable state).
+// As separate launches this is a (B*T x F x K) GEMM, the MSE kernel, a (B*T x K x F) GEMM and a split-K (F x K x B*T) GEMM + its reduction
+// (F = 24, K = 512, B*T = 122,880 at the headline shape): the 252 MB of states are read twice and the 252 MB of state gradients written once,
+// each launch at 2.4-3.5 TB/s because a tile of any of them has almost no arithmetic to hide its memory time behind (profiles/r05_narrow_gemms.txt).
+// Here a workgroup streams 16-row tiles of the states through LDS ONCE:
+//   P1  pred partials = tile x W^T        16x16x4 f32 MFMAs, K split over the four waves (W^T fragments re-read from L2 per tile)
+//   --  pred = bias + partials (fixed order), error, loss, dpred -> global + a zero-padded LDS tile
+//   P3  dW += dpred^T x tile              M = F (two 16-row MFMA tiles), N = the wave's K/4 state columns, K = the 16 rows; accumulators live
+//                                         in registers across all tiles of the workgroup
+//   P2  dY tile = dpred x W               written over the state tile in LDS, then copied out as full 128-byte row segments (16 B per lane)
+// while the next tile's global loads (issued behind the dpred phase) are in flight; two workgroups per CU overlap each other's phases.  The per-workgroup dW
+// sums go to a workspace and a second launch adds them in a fixed order (deterministic; no float atomics except the scalar loss sum, as in mse_kernel).
+// Both f32 MFMA shapes, plain loads and stores only: the host emulator runs this file as is.
 #include "vame_common.h"
 #include "gru_desc.h"
+
+namespace {
+constexpr int HS_ROWS = 16;
+constexpr int HS_MAX_WGS = 512;            // two per CU (registers: 242 of 256 at K = 512)
+constexpr int HS_DLD = 48;                 // dpred tile row stride: rows 4s + q land 16 q banks apart (conflict-free A^T reads in P3)
 
 struct HeadParams {
     const float* Y; int64_t y_ld, y_seg, y_seg_stride;      // row m = (b,t), b = m / y_seg: Y + b*y_seg_stride + t*y_ld, K floats
@@ -22,146 +32,252 @@ struct HeadParams {
     float* pred; float* dpred;                              // (M, F) each; pred may be null
     float* dY; int64_t dy_ld;                               // (M, dy_ld), columns [0, K) written
     float* loss;                                            // loss[0] += sum of squared errors
-    int M, F, K, Fp;                                        // Fp = F rounded up to 8 (rows of W kept in LDS)
+    float* ws;                                              // (gridDim.x, F, K) per-workgroup dW sums
+    int M, F, K, ntiles;
     float gscale;
 };
 
-// LDS: W as Fp rows of (K + 4) floats (the +4 makes the 16-byte row-strided reads of phase 1 conflict-free), then one 32 x 36 scratch
-// per wave for the C -> A layout turn.
-__global__ __launch_bounds__(256) void head_fused_kernel(HeadParams P) {
+// NT = K / 64: 16-column MFMA tiles per wave (a wave owns K/4 state columns in P2 / P3 and K/4 of the contraction in P1); NFS = ceil(F / 4)
+// k-steps of P2 (6 covers F <= 24, 8 covers F <= 32)
+template <int NT, int NFS>
+__global__ __launch_bounds__(256, 2) void head_stream_kernel(HeadParams P) {
     VAME_DYN_SMEM(smem_raw);
-    float* wl = reinterpret_cast<float*>(smem_raw);
-    const int K = P.K, LDW = K + 4, F = P.F;
-    const int tid = threadIdx.x, lane = tid & 63, li = lane & 31, hh = lane >> 5;
+    constexpr int K = 64 * NT, LD = K + 16;                    // LD = 16 (mod 32): rows 4s + q of a column sit 16 q banks apart
+    float* yt = reinterpret_cast<float*>(smem_raw);            // [16][LD]   state tile, later the dY tile
+    float* part = yt + HS_ROWS * LD;                           // [4][16][32] P1 partial sums per wave
+    float* db = part + 4 * HS_ROWS * 32;                       // [16][HS_DLD] dpred tile (0 for f >= F and rows >= M)
+    const int tid = threadIdx.x, lane = tid & 63, l16 = lane & 15, q = lane >> 4;
     const int w = UNIFORM(tid >> 6);
-    float* sc = wl + (size_t)P.Fp * LDW + w * (32 * 36);
-    for (int i = tid; i < P.Fp * (K / 4); i += 256) {
-        const int f = i / (K / 4), k4 = i % (K / 4);
-        const float4 v = f < F ? reinterpret_cast<const float4*>(P.W + (int64_t)f * K)[k4] : make_float4(0.f, 0.f, 0.f, 0.f);
-        *reinterpret_cast<float4*>(&wl[f * LDW + 4 * k4]) = v;
+    const int F = P.F, seg = (int)P.y_seg;
+    const int kw = w * (K / 4);                                // P1: this wave's k range; P2 / P3: this wave's state columns
+    // ---- W fragments.  P1 (B operand of tile x W^T: column n = 16 nt + l16, k = kw + 16 c + 4 q + e) is 8 NT registers per lane: re-read from
+    // L2 for every tile (requested at the top of the iteration, consumed by P1) -- with P2's fragments, the dW accumulators and the next tile in
+    // flight, keeping them resident as well spills, and a spilled register costs a scratch round trip in the middle of a phase.  Rows n >= F of
+    // the padded 32-column prediction tile read row F - 1; their partial sums are zeroed by the mask.
+    int w1i[2];                                                // (32-bit element indices into W: one scalar base + a register per row)
+    float w1m[2];
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+        const int n = 16 * nt + l16;
+        w1i[nt] = (n < F ? n : F - 1) * K + kw + 4 * q;
+        w1m[nt] = n < F ? 1.f : 0.f;
     }
-    __syncthreads();
-    const int m0 = (blockIdx.x * 4 + w) * 32;                    // (M < 2^31: 32-bit row arithmetic, no 64-bit divisions)
-    const int seg = (int)P.y_seg;
-    float part = 0.f;
-    if (m0 < P.M) {
-        // ---- phase 1: prediction tile = states (A: row li, k = 8c + 4hh + e) x W^T (B: column n = li, same k)
-        const int ma = m0 + li;
-        const bool arow = ma < P.M;
-        const int ba = arow ? ma / seg : 0;
-        const float* yrow = P.Y + (int64_t)ba * P.y_seg_stride + (int64_t)(arow ? ma - ba * seg : 0) * P.y_ld + 4 * hh;
-        const float* wrow = wl + (li < P.Fp ? li : 0) * LDW + 4 * hh;
-        const bool bcol = li < P.Fp;
-        f32x16 acc;
+    // P2 (B operand of dpred x W): k = f = 4 s + q, column kw + 16 nt + l16; resident
+    float w2[NT][NFS];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-        // passes of four chunks; the loads of two passes ahead are in flight while a pass feeds the MFMAs (a wave has nobody to hide
-        // its HBM latency behind but itself and one neighbour on the SIMD)
-        constexpr int PC = 4, PD = 3;
-        const int npass = K / (8 * PC);                                          // K % 32 == 0
-        float4 a[PD][PC];
-        auto fetch = [&](int p, float4 (&dst)[PC]) {
+    for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-            for (int j = 0; j < PC; ++j)
-                dst[j] = (arow && p < npass) ? *reinterpret_cast<const float4*>(yrow + 8 * (p * PC + j)) : make_float4(0.f, 0.f, 0.f, 0.f);
-        };
-        auto feed = [&](int p, const float4 (&src)[PC]) {
-#pragma unroll
-            for (int j = 0; j < PC; ++j) {
-                const float4 b = bcol ? *reinterpret_cast<const float4*>(wrow + 8 * (p * PC + j)) : make_float4(0.f, 0.f, 0.f, 0.f);
-                acc = MFMA_32x32x2(src[j].x, b.x, acc); acc = MFMA_32x32x2(src[j].y, b.y, acc);
-                acc = MFMA_32x32x2(src[j].z, b.z, acc); acc = MFMA_32x32x2(src[j].w, b.w, acc);
-            }
-        };
-        fetch(0, a[0]); fetch(1, a[1]);
-        for (int p0 = 0; p0 < npass; p0 += PD) {                                 // unrolled by PD so that the buffer index is static
-            fetch(p0 + 2, a[2]); feed(p0, a[0]);
-            if (p0 + 1 < npass) { fetch(p0 + 3, a[0]); feed(p0 + 1, a[1]); }
-            if (p0 + 2 < npass) { fetch(p0 + 4, a[1]); feed(p0 + 2, a[2]); }
+        for (int s = 0; s < NFS; ++s) {
+            const int f = 4 * s + q;
+            w2[nt][s] = P.W[(f < F ? f : F - 1) * K + kw + 16 * nt + l16] * (f < F ? 1.f : 0.f);
         }
-        // ---- error, loss, dpred: the lane holds column li of rows CR(r) + 4hh
-        const float bl = li < F ? P.bias[li] : 0.f;
+    f32x4 acc3[2][NT];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = CR(r) + 4 * hh;
-            const int m = m0 + row;
-            float g = 0.f;
-            if (m < P.M && li < F) {
-                const int b = m / seg, t = m - b * seg;
-                const float p = acc[r] + bl;
-                const float e = p - P.tgt[(int64_t)b * P.tgt_row + P.tgt_off + t * F + li];
-                part += e * e;
-                g = P.gscale * e;
-                if (P.pred) P.pred[(int64_t)m * F + li] = p;
-                P.dpred[(int64_t)m * F + li] = g;
-            }
-            sc[row * 36 + li] = g;
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc3[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // loader / copy-out / dpred role of a thread: row tid / 16, 16-byte column units c0 + 16 j
+    const int lrow = tid >> 4, c0 = tid & 15;
+    const float bA = c0 < F ? P.bias[c0] : 0.f, bB = c0 + 16 < F ? P.bias[c0 + 16] : 0.f;
+    float lsum = 0.f;
+    f32x4 nxt[NT];
+    auto fetch = [&](int tile) {
+        const int m = tile * HS_ROWS + lrow;
+        const bool ok = tile < P.ntiles && m < P.M;
+        const int b = ok ? m / seg : 0;
+        const float* yrow = P.Y + (int64_t)b * P.y_seg_stride + (int64_t)(ok ? m - b * seg : 0) * P.y_ld + 4 * c0;
+#pragma unroll
+        for (int j = 0; j < NT; ++j) nxt[j] = ok ? *reinterpret_cast<const f32x4*>(yrow + 64 * j) : f32x4{0.f, 0.f, 0.f, 0.f};
+    };
+    int tile = blockIdx.x;
+    fetch(tile);
+    for (; tile < P.ntiles; tile += gridDim.x) {
+#pragma unroll
+        for (int j = 0; j < NT; ++j) *reinterpret_cast<f32x4*>(&yt[lrow * LD + 4 * c0 + 64 * j]) = nxt[j];
+#ifndef VAME_EMU
+        asm volatile("" ::: "memory");      // (the tile's registers are free before P1's fragments are requested: both live at once would spill)
+#endif
+        f32x4 w1[NT][2];
+#pragma unroll
+        for (int c = 0; c < NT; ++c)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) w1[c][nt] = *reinterpret_cast<const f32x4*>(P.W + (w1i[nt] + 16 * c));
+        // this tile's targets: requested before P1, used behind it (thread = (row lrow, features c0 and c0 + 16))
+        const int m_t = tile * HS_ROWS + lrow;
+        const bool ok_t = m_t < P.M;
+        float tgA = 0.f, tgB = 0.f;
+        {
+            const int b = ok_t ? m_t / seg : 0, t = ok_t ? m_t - b * seg : 0;
+            const float* tg = P.tgt + (int64_t)b * P.tgt_row + P.tgt_off + (int64_t)t * F;
+            if (ok_t && c0 < F) tgA = tg[c0];
+            if (ok_t && c0 + 16 < F) tgB = tg[c0 + 16];
         }
-        WAVE_SYNC();
-        // ---- phase 2: gradient rows = dpred (A from the scratch: row li, k = f) x W (B: column n, row f of the LDS copy)
-        float4 ga[4];
+        __syncthreads();
+        // ---- P1: partial prediction of the wave's quarter of K.  A: row l16, k = kw + 16 c + 4 q + e
+        {
+            f32x4 a1[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
-        for (int c = 0; c < 4; ++c)
-            ga[c] = 8 * c < P.Fp ? *reinterpret_cast<const float4*>(&sc[li * 36 + 8 * c + 4 * hh]) : make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int nb = 0; nb < K / 32; ++nb) {
-            f32x16 o;
+            for (int c = 0; c < NT; ++c) {
+                const f32x4 a = *reinterpret_cast<const f32x4*>(&yt[l16 * LD + kw + 16 * c + 4 * q]);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) o[r] = 0.f;
-            const float* wc = wl + nb * 32 + li;
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                if (8 * c >= P.Fp) break;
-                const float* wf = wc + (8 * c + 4 * hh) * LDW;
-                const float av[4] = {ga[c].x, ga[c].y, ga[c].z, ga[c].w};
-#pragma unroll
-                for (int e = 0; e < 4; ++e) o = MFMA_32x32x2(av[e], wf[e * LDW], o);
+                for (int e = 0; e < 4; ++e) {
+                    a1[0] = MFMA_16x16x4(a[e], w1[c][0][e], a1[0]);
+                    a1[1] = MFMA_16x16x4(a[e], w1[c][1][e], a1[1]);
+                }
             }
-            // the tile leaves as full 128-byte rows: C layout -> scratch -> 16 bytes per lane (row 8i + lane/8, columns 4 (lane % 8) ...)
-            WAVE_SYNC();
 #pragma unroll
-            for (int r = 0; r < 16; ++r) sc[(CR(r) + 4 * hh) * 36 + li] = o[r];
-            WAVE_SYNC();
+            for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int row = 8 * i + (lane >> 3), m = m0 + row;
-                const float4 v = *reinterpret_cast<const float4*>(&sc[row * 36 + 4 * (lane & 7)]);
-                if (m < P.M) *reinterpret_cast<float4*>(P.dY + (int64_t)m * P.dy_ld + nb * 32 + 4 * (lane & 7)) = v;
+                for (int r = 0; r < 4; ++r) part[(w * HS_ROWS + 4 * q + r) * 32 + 16 * nt + l16] = a1[nt][r] * w1m[nt];      // (columns >= F: 0)
+        }
+        __syncthreads();
+        // ---- prediction, error, loss, dpred
+        {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int f = c0 + 16 * h;
+                const float* pp = part + lrow * 32 + f;
+                const float p = (h ? bB : bA) + ((pp[0] + pp[HS_ROWS * 32]) + (pp[2 * HS_ROWS * 32] + pp[3 * HS_ROWS * 32]));
+                float g = 0.f;
+                if (ok_t && f < F) {
+                    const float e = p - (h ? tgB : tgA);
+                    lsum += e * e;
+                    g = P.gscale * e;
+                    if (P.pred) P.pred[(int64_t)m_t * F + f] = p;
+                    P.dpred[(int64_t)m_t * F + f] = g;
+                }
+                db[lrow * HS_DLD + f] = g;
+            }
+        }
+        __syncthreads();
+        // the next tile's states: requested here, behind the last load of this iteration that anything waits for (vmcnt retires in order: a wait
+        // on a younger load would wait for these too), in flight during P3, P2 and the copy-out -- and during the CU's other workgroup's phases
+        fetch(tile + gridDim.x);
+        // ---- P3: dW (F x the wave's K/4 columns) += dpred^T (A: row f = 16 mt + l16, k = tile row 4 s + q) x tile (B: column kw + 16 nt + l16)
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const float a0 = db[(4 * s + q) * HS_DLD + l16], a1v = db[(4 * s + q) * HS_DLD + 16 + l16];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const float y = yt[(4 * s + q) * LD + kw + 16 * nt + l16];
+                acc3[0][nt] = MFMA_16x16x4(a0, y, acc3[0][nt]);
+                acc3[1][nt] = MFMA_16x16x4(a1v, y, acc3[1][nt]);
+            }
+        }
+        __syncthreads();                                               // every wave is done with the state tile
+        // ---- P2: gradient tile = dpred (A: row l16, k = f = 4 s + q) x W, written over the state tile
+        {
+            float a2[NFS];
+#pragma unroll
+            for (int s = 0; s < NFS; ++s) a2[s] = db[l16 * HS_DLD + 4 * s + q];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                f32x4 o = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int s = 0; s < NFS; ++s) o = MFMA_16x16x4(a2[s], w2[nt][s], o);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) yt[(4 * q + r) * LD + kw + 16 * nt + l16] = o[r];
+            }
+        }
+        __syncthreads();
+        // ---- copy-out: full row segments, 16 bytes per lane (the same thread refills these words with the next tile: no barrier in between)
+        {
+            const int m = tile * HS_ROWS + lrow;
+            if (m < P.M) {
+                float* drow = P.dY + (int64_t)m * P.dy_ld + 4 * c0;
+#pragma unroll
+                for (int j = 0; j < NT; ++j) *reinterpret_cast<f32x4*>(drow + 64 * j) = *reinterpret_cast<const f32x4*>(&yt[lrow * LD + 4 * c0 + 64 * j]);
             }
         }
     }
+    // ---- this workgroup's dW sums -> workspace (f = 16 mt + 4 q + r, column kw + 16 nt + l16)
+    float* wsb = P.ws + (int64_t)blockIdx.x * F * K;
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int f = 16 * mt + 4 * q + r;
+                if (f < F) wsb[(int64_t)f * K + kw + 16 * nt + l16] = acc3[mt][nt][r];
+            }
     // one float atomic per workgroup (atomics on one address serialise)
     __shared__ float red[4];
-    part = wave_sum(part);
-    if (lane == 0) red[w] = part;
+    lsum = wave_sum(lsum);
+    if (lane == 0) red[w] = lsum;
     __syncthreads();
     if (tid == 0) atomicAdd(P.loss, (red[0] + red[1]) + (red[2] + red[3]));
 }
 
-extern "C" int64_t vame_head_fused_lds_bytes(int F, int K) {
-    const int Fp = (F + 7) / 8 * 8;
-    return ((int64_t)Fp * (K + 4) + 4 * 32 * 36) * 4;
+// dW[i] = sum over the workgroups' partial sums, four interleaved chains then (p0 + p1) + (p2 + p3): the order depends on nothing but nwg
+__global__ __launch_bounds__(256) void head_dw_reduce_kernel(const float* ws, int nwg, int n, float* dW) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float p[4] = {0.f, 0.f, 0.f, 0.f};
+    int g = 0;
+    for (; g + 4 <= nwg; g += 4) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) p[u] += ws[(int64_t)(g + u) * n + i];
+    }
+    for (int u = 0; g < nwg; ++g, ++u) p[u] += ws[(int64_t)g * n + i];
+    dW[i] = (p[0] + p[1]) + (p[2] + p[3]);
 }
 
-extern "C" int vame_head_fused_f32(const float* Y, int64_t y_ld, int64_t y_seg, int64_t y_seg_stride, int M, int F, int K, const float* W,
-                                   const float* bias, const float* tgt, int64_t tgt_row, int64_t tgt_off, float gscale, float* pred,
-                                   float* dpred, float* dY, int64_t dy_ld, float* loss, void* stream) {
-    VAME_CHECK_ARG(Y && W && bias && tgt && dpred && dY && loss, VAME_E_BADARG, "head_fused: null pointer");
-    VAME_CHECK_ARG(M >= 1 && F >= 1 && F <= 32 && K >= 32 && K % 32 == 0 && y_seg >= 1, VAME_E_SHAPE,
-                   "head_fused: M=%d F=%d (1..32) K=%d (multiple of 32)", M, F, K);
+int head_nwg(int M) {
+    const int tiles = (int)cdiv64(M, HS_ROWS);
+    return tiles < HS_MAX_WGS ? tiles : HS_MAX_WGS;
+}
+
+template <int NT, int NFS>
+int head_launch(const HeadParams& P, int nwg, hipStream_t st) {
+    const size_t lds = ((size_t)HS_ROWS * (64 * NT + 16) + 4 * HS_ROWS * 32 + HS_ROWS * HS_DLD) * sizeof(float);
+#ifndef VAME_EMU
+    VAME_CHECK_ARG(hipFuncSetAttribute(reinterpret_cast<const void*>(&head_stream_kernel<NT, NFS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess,
+                   VAME_E_HIP, "head_stream: cannot reserve %d bytes of LDS", (int)lds);
+#endif
+    hipLaunchKernelGGL((head_stream_kernel<NT, NFS>), dim3((unsigned)nwg), dim3(256), lds, st, P);
+    return VAME_OK;
+}
+
+template <int NFS>
+int head_dispatch(const HeadParams& P, int nwg, hipStream_t st) {
+    switch (P.K / 64) {
+        case 1: return head_launch<1, NFS>(P, nwg, st);
+        case 2: return head_launch<2, NFS>(P, nwg, st);
+        case 3: return head_launch<3, NFS>(P, nwg, st);
+        case 4: return head_launch<4, NFS>(P, nwg, st);
+        case 5: return head_launch<5, NFS>(P, nwg, st);
+        case 6: return head_launch<6, NFS>(P, nwg, st);
+        case 7: return head_launch<7, NFS>(P, nwg, st);
+        default: return head_launch<8, NFS>(P, nwg, st);
+    }
+}
+}  // namespace
+
+extern "C" int64_t vame_head_stream_ws_floats(int M, int F, int K) {
+    if (M < 1 || F < 1 || F > 32 || K < 64 || K > 512 || K % 64) return -1;      // -1: shape not covered (callers keep the separate launches)
+    return (int64_t)head_nwg(M) * F * K;
+}
+
+extern "C" int vame_head_stream_f32(const float* Y, int64_t y_ld, int64_t y_seg, int64_t y_seg_stride, int M, int F, int K, const float* W,
+                                    const float* bias, const float* tgt, int64_t tgt_row, int64_t tgt_off, float gscale, float* pred,
+                                    float* dpred, float* dY, int64_t dy_ld, float* loss, float* dW, float* ws, void* stream) {
+    VAME_CHECK_ARG(Y && W && bias && tgt && dpred && dY && loss && dW && ws, VAME_E_BADARG, "head_stream: null pointer");
+    VAME_CHECK_ARG(vame_head_stream_ws_floats(M, F, K) > 0 && y_seg >= 1, VAME_E_SHAPE,
+                   "head_stream: M=%d F=%d (1..32) K=%d (a multiple of 64 up to 512)", M, F, K);
     VAME_CHECK_ARG(y_ld % 4 == 0 && y_seg_stride % 4 == 0 && (uintptr_t)Y % 16 == 0 && (uintptr_t)W % 16 == 0 && dy_ld >= K && dy_ld % 4 == 0 &&
                        (uintptr_t)dY % 16 == 0, VAME_E_SHAPE,
-                   "head_fused: state rows and W must be 16-byte aligned (y_ld=%lld, y_seg_stride=%lld)", (long long)y_ld, (long long)y_seg_stride);
-    const int64_t lds = vame_head_fused_lds_bytes(F, K);
-    VAME_CHECK_ARG(lds <= 160 * 1024, VAME_E_UNSUPPORTED, "head_fused: F=%d K=%d needs %lld bytes of LDS", F, K, (long long)lds);
-#ifndef VAME_EMU
-    VAME_CHECK_ARG(hipFuncSetAttribute(reinterpret_cast<const void*>(&head_fused_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess,
-                   VAME_E_HIP, "head_fused: cannot reserve %d bytes of LDS", (int)lds);
-#endif
+                   "head_stream: state rows, W and dY rows must be 16-byte aligned (y_ld=%lld, y_seg_stride=%lld, dy_ld=%lld)", (long long)y_ld,
+                   (long long)y_seg_stride, (long long)dy_ld);
     HeadParams P;
     P.Y = Y; P.y_ld = y_ld; P.y_seg = y_seg; P.y_seg_stride = y_seg_stride; P.W = W; P.bias = bias; P.tgt = tgt; P.tgt_row = tgt_row;
-    P.tgt_off = tgt_off; P.pred = pred; P.dpred = dpred; P.dY = dY; P.dy_ld = dy_ld; P.loss = loss; P.M = M; P.F = F; P.K = K;
-    P.Fp = (F + 7) / 8 * 8; P.gscale = gscale;
-    hipLaunchKernelGGL(head_fused_kernel, dim3((unsigned)cdiv64(M, 128)), dim3(256), (size_t)lds, (hipStream_t)stream, P);
-    VAME_LAUNCH_CHECK("head_fused");
+    P.tgt_off = tgt_off; P.pred = pred; P.dpred = dpred; P.dY = dY; P.dy_ld = dy_ld; P.loss = loss; P.ws = ws; P.M = M; P.F = F; P.K = K;
+    P.ntiles = (int)cdiv64(M, HS_ROWS); P.gscale = gscale;
+    const int nwg = head_nwg(M);
+    const int rc = F <= 24 ? head_dispatch<6>(P, nwg, (hipStream_t)stream) : head_dispatch<8>(P, nwg, (hipStream_t)stream);
+    if (rc != VAME_OK) return rc;
+    VAME_LAUNCH_CHECK("head_stream");
+    hipLaunchKernelGGL(head_dw_reduce_kernel, dim3((unsigned)cdiv64((int64_t)F * K, 256)), dim3(256), 0, (hipStream_t)stream, ws, nwg, F * K, dW);
+    VAME_LAUNCH_CHECK("head_dw_reduce");
     return VAME_OK;
 }

@@ -112,8 +112,8 @@ class Workspace:
 # the measured best; the A/B tools set them by name (tools/step_ab.py B name=option:value,...; tools/shape_table.py SHAPE_ENGINE=option:value).
 ENGINE_DEFAULTS = dict(
     group_wgrads=True,     # same-shape weight-gradient contractions leave as grouped launches (_group_wgrads)
-    fuse_heads=False,      # output Linear + MSE + their backward per decoder in ONE kernel (vame_head_fused_f32): measured 159 us against
-                           # 149 us for the three launches it replaces at batch 4096 (tools/head_bench.py) and +-0 on the whole step
+    fuse_heads=True,       # output Linear + MSE + dY + the Linear's weight gradient per decoder in ONE pass over the decoder states
+                           # (vame_head_stream_f32, round 6) instead of four contractions + the MSE kernel; shapes it does not cover keep those
     small_streams=3,       # HIP streams for the independent small GEMMs before the decoders' launch
     wgrad_streams=0,       # 0 = auto: 4 streams up to batch 1024, ONE above (two give +1.5 % at batch 4096, but two large GEMMs sharing the
                            # chip each take twice as long, which makes per-kernel durations unreadable); 1 = caller's stream only
@@ -834,7 +834,7 @@ class VAEEngine:
         pred = None
         self._heads_deferred = not heads
         self._dY_ready = False
-        if not heads:          # loss() runs the fused output heads (ops.head_fused): prediction, loss, dpred and dY in one pass over Y
+        if not heads:          # loss() runs the streaming output heads (ops.head_stream): prediction, loss, dpred, dY and dW in one pass over Y
             return self.buf("pred", B, T, F) if want_d else None, self.buf("futp", B, FS, F) if want_f else None
         if want_d:
             pred = self.buf("pred", B, T, F)
@@ -912,7 +912,7 @@ class VAEEngine:
             else:
                 self.cluster_terms(B, *cluster)
         self._cluster_done = cluster is not None
-        pred, fut = self.decode(z, B, training, heads=not (defer_heads and training and self._heads_fusable()))
+        pred, fut = self.decode(z, B, training, heads=not (defer_heads and training and self._heads_fusable(B)))
         self._issue_pending_cluster()                                 # (decode() did it unless it returned early)
         self._B = B
         self._win, self._win_row, self._eps = xin, xin_row, eps
@@ -921,18 +921,23 @@ class VAEEngine:
                 sh(logvar, B, s.Z))
 
     # ------------------------------------------------------------------ loss (fused fwd + grad seeds)
-    def _heads_fusable(self):
+    def _heads_fusable(self, B):
+        """The streaming output head (vame_head_stream_f32) covers both decoders' Linear layers at this batch (F <= 32, state width a multiple of 64 up to 512)."""
         s = self.spec
-        return (self.fuse_heads and ops.head_fused_ok(s.F, len(self.dec) * s.Hd) and (not s.future or ops.head_fused_ok(s.F, 2 * s.Hf)))
+        return (self.fuse_heads and ops.head_stream_ws_floats(B * s.T, s.F, len(self.dec) * s.Hd) > 0
+                and (not s.future or ops.head_stream_ws_floats(B * s.FS, s.F, 2 * s.Hf) > 0))
 
     def _head(self, tag, name, dirs, steps, B, tgt, tgt_off, tgt_row, gscale, pred, dpred, losses, slot):
-        """One decoder's output head on the training path: hidden_to_output, MSE(sum), dpred and dY = dpred W in one kernel."""
+        """One decoder's output head on the training path in one pass over its states: hidden_to_output, MSE(sum), dpred, dY = dpred W and the
+        Linear's weight gradient dW = dpred^T Y (straight into the gradient bucket: _decoder_backward then skips both contractions)."""
         H, F = dirs[0].H, self.spec.F
         Ko = len(dirs) * H
         Y = self.buf(f"Y_{tag}", B, steps + 2, 2 * H)
-        ops.head_fused(Operand(Y, 2 * H, off=2 * H, seg=steps, seg_stride=(steps + 2) * 2 * H), B * steps, F, Ko,
-                       self.P(f"{name}.hidden_to_output.weight", Ko), self._pv(f"{name}.hidden_to_output.bias"), tgt, tgt_off, tgt_row, gscale,
-                       pred, dpred, self.buf(f"dY_{tag}", B, steps, 2 * H), 2 * H, losses, slot)
+        wo = f"{name}.hidden_to_output.weight"
+        ws = self.ws.get(f"head_ws_{tag}", ops.head_stream_ws_floats(B * steps, F, Ko), self.dev)
+        ops.head_stream(Operand(Y, 2 * H, off=2 * H, seg=steps, seg_stride=(steps + 2) * 2 * H), B * steps, F, Ko,
+                        self.P(wo, Ko), self._pv(f"{name}.hidden_to_output.bias"), tgt, tgt_off, tgt_row, gscale,
+                        pred, dpred, self.buf(f"dY_{tag}", B, steps, 2 * H), 2 * H, losses, slot, self.g, self.table.off(wo), ws)
 
     def loss(self, B, tgt, tgt_row, fut_tgt_off, kl_weight, kloss, klmbda, bsize, mse_red="sum", mse_pred="sum", with_future=True):
         """rnn_vae.py:124-129.  Fills losses[REC,FUT,KLSUM,KMEANS] and the gradient seeds dpred/dfut/Minv."""
@@ -1007,9 +1012,9 @@ class VAEEngine:
         dY = self.buf(f"dY_{tag}", B, steps, 2 * H)
         wo = f"{name}.hidden_to_output.weight"
         Ko = len(dirs) * H
-        if not getattr(self, "_dY_ready", False):             # (the fused head of loss() already wrote dY)
+        if not getattr(self, "_dY_ready", False):             # (the streaming head of loss() already wrote dY and the Linear's weight gradient)
             ops.gemm(B * steps, Ko, F, Operand(dpred, F), 0, self.P(wo, Ko), 1, dY, 2 * H)
-        self._gemm_wgrad(F, Ko, B * steps, Operand(dpred, F), Yrows, wo)
+            self._gemm_wgrad(F, Ko, B * steps, Operand(dpred, F), Yrows, wo)
         ops.colsum(dpred, 0, B * steps, F, F, self.g, t.off(f"{name}.hidden_to_output.bias"))
         dhid = self.buf(f"dhid_{tag}", B, 2 * H) if self.h0_from_z else None
         rows, per = [], []

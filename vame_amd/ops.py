@@ -473,17 +473,19 @@ def mse_fwd_bwd(pred, target, tgt_off, tgt_row, B, TF, gscale, dpred, loss_out, 
     _lib.check(rc, "vame_mse_fwd_bwd_f32")
 
 
-def head_fused_ok(F, K):
-    """Whether the fused output head covers this Linear (F outputs from K state columns)."""
-    return 1 <= F <= 32 and K >= 32 and K % 32 == 0 and int(_lib.lib().vame_head_fused_lds_bytes(F, K)) <= 160 * 1024
+def head_stream_ws_floats(M, F, K):
+    """Scratch floats the streaming output head needs for M rows (per-workgroup dW sums), or -1 when it does not cover the shape
+    (F > 32, K not a multiple of 64 or above 512): the caller then keeps the separate launches."""
+    return int(_lib.lib().vame_head_stream_ws_floats(int(M), int(F), int(K)))
 
 
-def head_fused(Y, M, F, K, W, bias, tgt, tgt_off, tgt_row, gscale, pred, dpred, dY, dy_ld, loss_out, loss_off):
-    """Y: Operand over the decoder states (two-level rows (b,t): seg = T, seg_stride); W: Operand (F x K); see vame_head_fused_f32."""
-    rc = _lib.lib().vame_head_fused_f32(_ptr(Y.t, Y.off), Y.ld, Y.seg, Y.seg_stride, M, F, K, _ptr(W.t, W.off), _ptr(bias), _ptr(tgt),
-                                        tgt_row, tgt_off, float(gscale), _ptr(pred), _ptr(dpred), _ptr(dY), dy_ld, _ptr(loss_out, loss_off),
-                                        _stream())
-    _lib.check(rc, "vame_head_fused_f32")
+def head_stream(Y, M, F, K, W, bias, tgt, tgt_off, tgt_row, gscale, pred, dpred, dY, dy_ld, loss_out, loss_off, dW, dW_off, ws):
+    """Y: Operand over the decoder states (two-level rows (b,t): seg = T, seg_stride); W: Operand (F x K); dW: (F, K) at float offset dW_off of
+    a gradient bucket; see vame_head_stream_f32."""
+    rc = _lib.lib().vame_head_stream_f32(_ptr(Y.t, Y.off), Y.ld, Y.seg, Y.seg_stride, M, F, K, _ptr(W.t, W.off), _ptr(bias), _ptr(tgt),
+                                         tgt_row, tgt_off, float(gscale), _ptr(pred), _ptr(dpred), _ptr(dY), dy_ld, _ptr(loss_out, loss_off),
+                                         _ptr(dW, dW_off), _ptr(ws), _stream())
+    _lib.check(rc, "vame_head_stream_f32")
 
 
 def nuclear_state_doubles(Z):
