@@ -14,11 +14,27 @@
 //   P3  dW += dpred^T x tile              M = F (two 16-row MFMA tiles), N = the wave's K/4 state columns, K = the 16 rows; accumulators live
 //                                         in registers across all tiles of the workgroup
 //   P2  dY tile = dpred x W               written over the state tile in LDS, then copied out as full 128-byte row segments (16 B per lane)
-// while the next tile's global loads (issued behind the dpred phase) are in flight; two workgroups per CU overlap each other's phases.  The per-workgroup dW
+// while the next tile's global loads (issued behind P1) are in flight; two workgroups per CU overlap each other's phases.  The per-workgroup dW
 // sums go to a workspace and a second launch adds them in a fixed order (deterministic; no float atomics except the scalar loss sum, as in mse_kernel).
 // Both f32 MFMA shapes, plain loads and stores only: the host emulator runs this file as is.
 #include "vame_common.h"
 #include "gru_desc.h"
+
+#if defined(VAME_PROBE) && !defined(VAME_EMU)   // tuning build (make probe): per-wave phase cycle sums, tools/head_probe.py
+__device__ long long* g_head_probe;
+extern "C" int vame_probe_set_head(long long* p) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_head_probe), &p, sizeof(p)); }
+#define HS_PHASE_DECL() long long pp_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, pa_ = (long long)__builtin_amdgcn_s_memtime()
+#define HS_PHASE(i) do { const long long t_ = (long long)__builtin_amdgcn_s_memtime(); pp_[i] += t_ - pa_; pa_ = t_; } while (0)
+#define HS_PHASE_END()                                                                          \
+    if ((threadIdx.x & 63) == 0 && g_head_probe) {                                               \
+        long long* o_ = g_head_probe + ((long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * 8;     \
+        for (int i_ = 0; i_ < 8; ++i_) o_[i_] = pp_[i_];                                         \
+    }
+#else
+#define HS_PHASE_DECL()
+#define HS_PHASE(i)
+#define HS_PHASE_END()
+#endif
 
 namespace {
 constexpr int HS_ROWS = 16;
@@ -32,7 +48,7 @@ struct HeadParams {
     float* pred; float* dpred;                              // (M, F) each; pred may be null
     float* dY; int64_t dy_ld;                               // (M, dy_ld), columns [0, K) written
     float* loss;                                            // loss[0] += sum of squared errors
-    float* ws;                                              // (gridDim.x, F, K) per-workgroup dW sums
+    float* ws;                                              // (gridDim.x, 2, 4, NT, 64) float4: per-workgroup dW sums in accumulator order
     int M, F, K, ntiles;
     float gscale;
 };
@@ -51,9 +67,9 @@ __global__ __launch_bounds__(256, 2) void head_stream_kernel(HeadParams P) {
     const int F = P.F, seg = (int)P.y_seg;
     const int kw = w * (K / 4);                                // P1: this wave's k range; P2 / P3: this wave's state columns
     // ---- W fragments.  P1 (B operand of tile x W^T: column n = 16 nt + l16, k = kw + 16 c + 4 q + e) is 8 NT registers per lane: re-read from
-    // L2 for every tile (requested at the top of the iteration, consumed by P1) -- with P2's fragments, the dW accumulators and the next tile in
-    // flight, keeping them resident as well spills, and a spilled register costs a scratch round trip in the middle of a phase.  Rows n >= F of
-    // the padded 32-column prediction tile read row F - 1; their partial sums are zeroed by the mask.
+    // L2 for every tile (requested at the top of the iteration, consumed by P1) -- all of {P1 fragments, P2 fragments, dW accumulators, next tile
+    // in flight} resident at once spills, and a spilled register costs a scratch round trip in the middle of a phase.  Rows n >= F of the padded
+    // 32-column prediction tile read row F - 1; their partial sums are zeroed by the mask.
     int w1i[2];                                                // (32-bit element indices into W: one scalar base + a register per row)
     float w1m[2];
 #pragma unroll
@@ -62,7 +78,7 @@ __global__ __launch_bounds__(256, 2) void head_stream_kernel(HeadParams P) {
         w1i[nt] = (n < F ? n : F - 1) * K + kw + 4 * q;
         w1m[nt] = n < F ? 1.f : 0.f;
     }
-    // P2 (B operand of dpred x W): k = f = 4 s + q, column kw + 16 nt + l16; resident
+    // P2 (B operand of dpred x W): k = f = 4 s + q, column kw + 16 nt + l16; resident (rows f >= F: 0)
     float w2[NT][NFS];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
@@ -91,6 +107,7 @@ __global__ __launch_bounds__(256, 2) void head_stream_kernel(HeadParams P) {
     };
     int tile = blockIdx.x;
     fetch(tile);
+    HS_PHASE_DECL();
     for (; tile < P.ntiles; tile += gridDim.x) {
 #pragma unroll
         for (int j = 0; j < NT; ++j) *reinterpret_cast<f32x4*>(&yt[lrow * LD + 4 * c0 + 64 * j]) = nxt[j];
@@ -113,6 +130,7 @@ __global__ __launch_bounds__(256, 2) void head_stream_kernel(HeadParams P) {
             if (ok_t && c0 + 16 < F) tgB = tg[c0 + 16];
         }
         __syncthreads();
+        HS_PHASE(0);                                                   // tile -> LDS (waits for the prefetch), requests, barrier
         // ---- P1: partial prediction of the wave's quarter of K.  A: row l16, k = kw + 16 c + 4 q + e
         {
             f32x4 a1[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
@@ -131,6 +149,10 @@ __global__ __launch_bounds__(256, 2) void head_stream_kernel(HeadParams P) {
                 for (int r = 0; r < 4; ++r) part[(w * HS_ROWS + 4 * q + r) * 32 + 16 * nt + l16] = a1[nt][r] * w1m[nt];      // (columns >= F: 0)
         }
         __syncthreads();
+        HS_PHASE(1);                                                   // P1 + barrier
+        // the next tile's states: the YOUNGEST loads of the iteration (vmcnt retires in order: the wait for the targets leaves these in flight),
+        // covered by the dpred phase, P3, P2 and the copy-out; not in front of P1: its fragments + these would spill
+        fetch(tile + gridDim.x);
         // ---- prediction, error, loss, dpred
         {
 #pragma unroll
@@ -150,9 +172,7 @@ __global__ __launch_bounds__(256, 2) void head_stream_kernel(HeadParams P) {
             }
         }
         __syncthreads();
-        // the next tile's states: requested here, behind the last load of this iteration that anything waits for (vmcnt retires in order: a wait
-        // on a younger load would wait for these too), in flight during P3, P2 and the copy-out -- and during the CU's other workgroup's phases
-        fetch(tile + gridDim.x);
+        HS_PHASE(2);                                                   // dpred phase + barrier
         // ---- P3: dW (F x the wave's K/4 columns) += dpred^T (A: row f = 16 mt + l16, k = tile row 4 s + q) x tile (B: column kw + 16 nt + l16)
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
@@ -165,6 +185,7 @@ __global__ __launch_bounds__(256, 2) void head_stream_kernel(HeadParams P) {
             }
         }
         __syncthreads();                                               // every wave is done with the state tile
+        HS_PHASE(3);                                                   // P3 + barrier
         // ---- P2: gradient tile = dpred (A: row l16, k = f = 4 s + q) x W, written over the state tile
         {
             float a2[NFS];
@@ -180,6 +201,7 @@ __global__ __launch_bounds__(256, 2) void head_stream_kernel(HeadParams P) {
             }
         }
         __syncthreads();
+        HS_PHASE(4);                                                   // P2 + barrier
         // ---- copy-out: full row segments, 16 bytes per lane (the same thread refills these words with the next tile: no barrier in between)
         {
             const int m = tile * HS_ROWS + lrow;
@@ -189,18 +211,16 @@ __global__ __launch_bounds__(256, 2) void head_stream_kernel(HeadParams P) {
                 for (int j = 0; j < NT; ++j) *reinterpret_cast<f32x4*>(drow + 64 * j) = *reinterpret_cast<const f32x4*>(&yt[lrow * LD + 4 * c0 + 64 * j]);
             }
         }
+        HS_PHASE(5);                                                   // copy-out
     }
-    // ---- this workgroup's dW sums -> workspace (f = 16 mt + 4 q + r, column kw + 16 nt + l16)
-    float* wsb = P.ws + (int64_t)blockIdx.x * F * K;
+    HS_PHASE_END();
+    // ---- this workgroup's dW sums -> workspace in ACCUMULATOR order: [mt][wave][nt][lane] float4 units (one coalesced 1 KB store per
+    // accumulator tile); head_dw_reduce_kernel maps unit (mt, wave, nt, lane = 16 q + l16), element r to dW[16 mt + 4 q + r][wave K/4 + 16 nt + l16]
+    f32x4* wsb = reinterpret_cast<f32x4*>(P.ws) + (int64_t)blockIdx.x * (2 * 4 * NT * 64);
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int f = 16 * mt + 4 * q + r;
-                if (f < F) wsb[(int64_t)f * K + kw + 16 * nt + l16] = acc3[mt][nt][r];
-            }
+        for (int nt = 0; nt < NT; ++nt) wsb[((mt * 4 + w) * NT + nt) * 64 + lane] = acc3[mt][nt];
     // one float atomic per workgroup (atomics on one address serialise)
     __shared__ float red[4];
     lsum = wave_sum(lsum);
@@ -209,18 +229,38 @@ __global__ __launch_bounds__(256, 2) void head_stream_kernel(HeadParams P) {
     if (tid == 0) atomicAdd(P.loss, (red[0] + red[1]) + (red[2] + red[3]));
 }
 
-// dW[i] = sum over the workgroups' partial sums, four interleaved chains then (p0 + p1) + (p2 + p3): the order depends on nothing but nwg
-__global__ __launch_bounds__(256) void head_dw_reduce_kernel(const float* ws, int nwg, int n, float* dW) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    float p[4] = {0.f, 0.f, 0.f, 0.f};
-    int g = 0;
-    for (; g + 4 <= nwg; g += 4) {
-#pragma unroll
-        for (int u = 0; u < 4; ++u) p[u] += ws[(int64_t)(g + u) * n + i];
+// dW = sum over the workgroups' partial sums, read in the accumulator order they were stored in.  A block = 64 consecutive float4 units x 16
+// segments of the workgroup range (1024 threads; a unit's 16 segment sums meet in LDS and are added as a fixed tree), so 0.4 M loads are in
+// flight and the order of the additions depends on nothing but nwg.
+__global__ __launch_bounds__(1024) void head_dw_reduce_kernel(const f32x4* ws, int nwg, int NT, int F, int K, float* dW) {
+    __shared__ f32x4 seg[16][64];
+    const int u = blockIdx.x * 64 + (threadIdx.x & 63), sg = threadIdx.x >> 6, units = 2 * 4 * NT * 64;
+    f32x4 a = {0.f, 0.f, 0.f, 0.f}, b = {0.f, 0.f, 0.f, 0.f};
+    // unit -> (mt, wave, nt, lane); rows 16 mt + 4 q + r >= F are padding: never read
+    const int lane = u & 63, nt = (u >> 6) % NT, wv = (u >> 6) / NT % 4, mt = (u >> 6) / NT / 4, q = lane >> 4, l16 = lane & 15;
+    const int f0 = 16 * mt + 4 * q;
+    const bool live = u < units && f0 < F;
+    if (live) {
+        const int per = (nwg + 15) / 16, g0 = sg * per, g1 = g0 + per < nwg ? g0 + per : nwg;
+        int g = g0;
+        for (; g + 2 <= g1; g += 2) { a += ws[(int64_t)g * units + u]; b += ws[(int64_t)(g + 1) * units + u]; }
+        if (g < g1) a += ws[(int64_t)g * units + u];
     }
-    for (int u = 0; g < nwg; ++g, ++u) p[u] += ws[(int64_t)g * n + i];
-    dW[i] = (p[0] + p[1]) + (p[2] + p[3]);
+    seg[sg][threadIdx.x & 63] = a + b;
+    __syncthreads();
+    if (sg == 0 && live) {
+        f32x4 t[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) t[i] = seg[i][threadIdx.x & 63];
+#pragma unroll
+        for (int st = 1; st < 16; st *= 2)
+#pragma unroll
+            for (int i = 0; i < 16; i += 2 * st) t[i] += t[i + st];
+        const int col = wv * (K / 4) + 16 * nt + l16;
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (f0 + r < F) dW[(int64_t)(f0 + r) * K + col] = t[0][r];
+    }
 }
 
 int head_nwg(int M) {
@@ -256,7 +296,7 @@ int head_dispatch(const HeadParams& P, int nwg, hipStream_t st) {
 
 extern "C" int64_t vame_head_stream_ws_floats(int M, int F, int K) {
     if (M < 1 || F < 1 || F > 32 || K < 64 || K > 512 || K % 64) return -1;      // -1: shape not covered (callers keep the separate launches)
-    return (int64_t)head_nwg(M) * F * K;
+    return (int64_t)head_nwg(M) * (2 * 4 * (K / 64) * 64 * 4);               // accumulator-order units incl. the padding rows f >= F
 }
 
 extern "C" int vame_head_stream_f32(const float* Y, int64_t y_ld, int64_t y_seg, int64_t y_seg_stride, int M, int F, int K, const float* W,
@@ -277,7 +317,7 @@ extern "C" int vame_head_stream_f32(const float* Y, int64_t y_ld, int64_t y_seg,
     const int rc = F <= 24 ? head_dispatch<6>(P, nwg, (hipStream_t)stream) : head_dispatch<8>(P, nwg, (hipStream_t)stream);
     if (rc != VAME_OK) return rc;
     VAME_LAUNCH_CHECK("head_stream");
-    hipLaunchKernelGGL(head_dw_reduce_kernel, dim3((unsigned)cdiv64((int64_t)F * K, 256)), dim3(256), 0, (hipStream_t)stream, ws, nwg, F * K, dW);
+    hipLaunchKernelGGL(head_dw_reduce_kernel, dim3((unsigned)(2 * 4 * (K / 64))), dim3(1024), 0, (hipStream_t)stream, reinterpret_cast<const f32x4*>(ws), nwg, K / 64, F, K, dW);
     VAME_LAUNCH_CHECK("head_dw_reduce");
     return VAME_OK;
 }
