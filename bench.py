@@ -183,6 +183,9 @@ def profile_kernels(model, loader, B, steps=3):
     def mse_bytes(pred, target, tgt_off, tgt_row, B_, TF, *a, **k):
         return ("hbm mse_kernel", 3.0 * 4 * B_ * TF)                       # prediction + target in, dpred out
 
+    def head_bytes(Yop, M, F_, K, *a, **k):
+        return ("hbm head_stream_kernel", 4.0 * (2.0 * M * K + 3.0 * M * F_))      # states in, state gradients out, target in, pred + dpred out (dW: F x K)
+
     def timesum_bytes(inp, B_, T_, C, ld, out):
         return ("hbm timesum_kernel", 4.0 * B_ * C * (T_ + 1))             # C of ld columns of every (b, t) row in, (B, C) out
 
@@ -190,7 +193,8 @@ def profile_kernels(model, loader, B, steps=3):
                                                   ("gru_wide_fwd", gru_flops("fwd")), ("gru_wide_bwd", gru_flops("bwd")),
                                                   ("gru_coop_fwd", coop_flops("fwd")), ("gru_coop_bwd", coop_flops("bwd")),
                                                   ("gemm", gemm_flops), ("gemm_group", group_flops),
-                                                  ("window_gather", gather_bytes), ("mse_fwd_bwd", mse_bytes), ("timesum", timesum_bytes))}
+                                                  ("window_gather", gather_bytes), ("mse_fwd_bwd", mse_bytes), ("timesum", timesum_bytes),
+                                                  ("head_stream", head_bytes))}
     # per-kernel durations are taken with the step's side-stream overlaps OFF (engine.set_overlap): a kernel that shares the chip with
     # another one is slower for reasons that are not its own.  The timed region above runs with them on.
     prev = model._engine.set_overlap(False)

@@ -59,7 +59,7 @@ def test_bench_line_contract(hip):
     assert abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-3
     for c in ("gru_seq_fwd_kernel<256>", "gru_seq_bwd_kernel<256>", "gemm_kernel TN", "gemm_kernel NT", "gemm_kernel NN"):
         assert roof["by_class"][c]["tflops"] > 20, c
-    for c in ("window_gather_kernel", "mse_kernel", "timesum_kernel"):
+    for c in ("window_gather_kernel", "head_stream_kernel", "timesum_kernel"):      # (round 6: the streaming output head replaces the MSE launch)
         assert roof["by_class"][c]["bound"] == "hbm" and 0 < roof["by_class"][c]["frac"] < 1, c
     assert j["repeat_spread"]["regions"] == 3 and j["repeat_spread"]["min"] <= j["value"] <= j["repeat_spread"]["max"] * 1.0001
     also = j["also"]
