@@ -257,6 +257,13 @@ int vame_index_copy_f32(float* dst, const int64_t* dst_idx, const float* src, co
 int vame_mask_scale_f32(const float* x, int64_t off, int64_t ld, int64_t seg, int64_t seg_stride, const float* mask, float scale,
                         float* out, int64_t R, int C, void* stream);
 
+/* `count` (1..8) Linear layers of ONE narrow input in one launch: C[g] (M, N[g]; row stride ldc[g]) = A (M, K; row stride lda) W[g]^T + bias[g],
+ * W[g] (N[g], K) row-major contiguous, bias[g] (N[g]) or null, K <= 32.  W, bias, C, ldc, N are HOST arrays.  Replaces the six vame_gemm_f32
+ * launches that apply the decoders' latent_to_hidden layers and GRU input weights to the time-constant input z
+ * (vame/model/rnn_model.py:103-106, 136-140; nn.GRU's W_ih x_t with x_t = z for every t, rnn_model.py:169-170). */
+int vame_linear_group_f32(int count, int M, int K, const float* A, int64_t lda, const float* const* W, const float* const* bias,
+                          float* const* C, const int64_t* ldc, const int* N, void* stream);
+
 /* y = a*x + y style helpers for the host orchestration */
 int vame_axpy_f32(const float* x, float a, float* y, int64_t n, void* stream);
 

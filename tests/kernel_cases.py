@@ -899,6 +899,28 @@ def check_head_fused(dev, B=7, T=9, F=24, K=64, pad=2):
     assert (got[:16] == 3.0).all() and (got[16 + F * K:] == 3.0).all()
 
 
+def check_linear_group(dev):
+    """vame_linear_group_f32: several Linear layers of one narrow (K <= 32) input in one launch vs float64 numpy -- ragged row and column tiles,
+    problems wider than one 256-column tile, a missing bias, an output with a wider row stride, odd K and N (scalar-store path)."""
+    rng = np.random.default_rng(44)
+    for (M, K, Ns) in ((37, 30, (768, 512, 768)), (300, 7, (33, 256, 257, 5)), (64, 32, (96,) * 8), (5, 1, (3,))):
+        A = rng.standard_normal((M, K + 3)).astype(np.float32)
+        At = T_(A, dev)
+        probs, refs = [], []
+        for i, N in enumerate(Ns):
+            W = rng.standard_normal((N, K)).astype(np.float32)
+            b = rng.standard_normal(N).astype(np.float32) if i != 1 else None
+            ldc = N + (4 if i == 0 else 0)
+            C = torch.full((M, ldc), 9.0, device=dev)
+            probs.append((Operand(T_(W, dev), K), T_(b, dev) if b is not None else None, C, ldc, N))
+            refs.append(A[:, :K].astype(np.float64) @ W.astype(np.float64).T + (b if b is not None else 0.0))
+        ops.linear_group(Operand(At, K + 3), M, K, probs)
+        for (W, b, C, ldc, N), ref in zip(probs, refs):
+            out = N_(C)
+            np.testing.assert_allclose(out[:, :N], ref, atol=3e-5)
+            assert (out[:, N:] == 9.0).all()
+
+
 def check_colsum(dev):
     rng = np.random.default_rng(6)
     a = rng.standard_normal((13, 300)).astype(np.float32)

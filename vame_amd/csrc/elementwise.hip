@@ -499,6 +499,90 @@ extern "C" int vame_index_copy_f32(float* dst, const int64_t* dst_idx, const flo
     return VAME_OK;
 }
 
+// Up to 8 Linear layers of ONE narrow input in one launch: C_g (M, N_g) = A (M, K) W_g^T (N_g, K) + bias_g, K <= 32.  The decoders' projections of z
+// (rnn_model.py:103-106, 136-140: latent_to_hidden and the GRUs' W_ih applied to the time-constant input z -- six Linear layers of the same
+// (B, zdims) matrix) were six launches of the MFMA GEMM whose k loop is a single short tile: 17-23 us each for 5-13 MB of output.  With K <= 32 an
+// output needs <= 32 FMAs: this is a store stream.  Workgroup = 32 rows x 256 columns of one problem (A tile and W tile in LDS, k-major), thread =
+// 8 rows x 4 columns; k-ordered fmaf chains from 0, bias added last.
+struct LinGroupParams {
+    const float* A; int64_t lda; int M, K, count;
+    const float* W[8]; const float* bias[8]; float* C[8]; int64_t ldc[8]; int N[8];
+    int tile0[9];                      // first 256-column tile of problem g in blockIdx.x
+};
+
+__global__ __launch_bounds__(256) void linear_group_kernel(LinGroupParams P) {
+    __shared__ float As[32][32 + 4];           // [k][row]
+    __shared__ float Ws[32][256 + 4];          // [k][column]
+    const int tid = threadIdx.x;
+    int g = 0;
+    while (g + 1 < P.count && (int)blockIdx.x >= P.tile0[g + 1]) ++g;
+    const int n0 = ((int)blockIdx.x - P.tile0[g]) * 256, m0 = blockIdx.y * 32, K = P.K, N = P.N[g];
+    for (int i = tid; i < 32 * K; i += 256) {                       // A tile: consecutive threads walk a row
+        const int r = i / K, k = i - r * K, m = m0 + r;
+        As[k][r] = m < P.M ? P.A[(int64_t)m * P.lda + k] : 0.f;
+    }
+    {
+        const int n = n0 + tid;                                     // W tile: one row (K contiguous floats) per thread
+        const float* wr = P.W[g] + (int64_t)(n < N ? n : N - 1) * K;
+        for (int k = 0; k < K; ++k) Ws[k][tid] = wr[k];
+    }
+    __syncthreads();
+    const int tx = tid & 63, ty = tid >> 6;
+    float acc[8][4];
+#pragma unroll
+    for (int r = 0; r < 8; ++r)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[r][c] = 0.f;
+    for (int k = 0; k < K; ++k) {
+        const float4 w = *reinterpret_cast<const float4*>(&Ws[k][4 * tx]);
+        const float4 a0 = *reinterpret_cast<const float4*>(&As[k][8 * ty]), a1 = *reinterpret_cast<const float4*>(&As[k][8 * ty + 4]);
+        const float av[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w}, wv[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+        for (int r = 0; r < 8; ++r)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) acc[r][c] = fmaf(av[r], wv[c], acc[r][c]);
+    }
+    const int n = n0 + 4 * tx;
+    if (n >= N) return;
+    float b[4] = {0.f, 0.f, 0.f, 0.f};
+    if (P.bias[g]) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) b[c] = n + c < N ? P.bias[g][n + c] : 0.f;
+    }
+    const int64_t ldc = P.ldc[g];
+    const bool vec = n + 4 <= N && ldc % 4 == 0 && (reinterpret_cast<uintptr_t>(P.C[g]) & 15) == 0;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        const int m = m0 + 8 * ty + r;
+        if (m >= P.M) break;
+        float* out = P.C[g] + (int64_t)m * ldc + n;
+        if (vec) *reinterpret_cast<float4*>(out) = make_float4(acc[r][0] + b[0], acc[r][1] + b[1], acc[r][2] + b[2], acc[r][3] + b[3]);
+        else
+            for (int c = 0; c < 4 && n + c < N; ++c) out[c] = acc[r][c] + b[c];
+    }
+}
+
+extern "C" int vame_linear_group_f32(int count, int M, int K, const float* A, int64_t lda, const float* const* W, const float* const* bias,
+                                     float* const* C, const int64_t* ldc, const int* N, void* stream) {
+    VAME_CHECK_ARG(count >= 1 && count <= 8 && M >= 1 && K >= 1 && K <= 32 && A && W && bias && C && ldc && N && lda >= K, VAME_E_SHAPE,
+                   "linear_group: count=%d (1..8) M=%d K=%d (1..32)", count, M, K);
+    LinGroupParams P;
+    P.A = A; P.lda = lda; P.M = M; P.K = K; P.count = count;
+    int tiles = 0;
+    for (int g = 0; g < 8; ++g) {
+        const bool on = g < count;
+        VAME_CHECK_ARG(!on || (W[g] && C[g] && N[g] >= 1 && ldc[g] >= N[g]), VAME_E_BADARG, "linear_group: problem %d: null operand or ldc < N", g);
+        P.W[g] = on ? W[g] : nullptr; P.bias[g] = on ? bias[g] : nullptr; P.C[g] = on ? C[g] : nullptr; P.ldc[g] = on ? ldc[g] : 0; P.N[g] = on ? N[g] : 0;
+        P.tile0[g] = tiles;
+        if (on) tiles += (N[g] + 255) / 256;
+    }
+    P.tile0[8] = tiles;
+    for (int g = count; g < 8; ++g) P.tile0[g] = tiles;
+    hipLaunchKernelGGL(linear_group_kernel, dim3((unsigned)tiles, (unsigned)cdiv64(M, 32)), dim3(256), 0, (hipStream_t)stream, P);
+    VAME_LAUNCH_CHECK("linear_group");
+    return VAME_OK;
+}
+
 __global__ __launch_bounds__(256) void axpy_kernel(const float* __restrict__ x, float a, float* __restrict__ y, int64_t n) {
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
         y[i] += a * x[i];

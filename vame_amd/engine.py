@@ -794,17 +794,24 @@ class VAEEngine:
     def _decode_one(self, tag, name, dirs, steps, z, B, training, rows, jobs, inputs=None):
         H, Z = dirs[0].H, self.spec.Z
         hid = None
+        narrow = inputs is None and Z <= 32         # the projections of the time-constant z leave as ONE launch (decode(): ops.linear_group)
         if self.h0_from_z:
             hid = self.buf(f"hid_{tag}", B, 2 * H)
-            jobs.append(lambda: ops.gemm(B, 2 * H, Z, Operand(z, Z), 0, self.P(f"{name}.latent_to_hidden.weight", Z), 0, hid, 2 * H,
-                                         bias=self._pv(f"{name}.latent_to_hidden.bias")))
+            if narrow:
+                jobs.append((self.P(f"{name}.latent_to_hidden.weight", Z), self._pv(f"{name}.latent_to_hidden.bias"), hid, 2 * H, 2 * H))
+            else:
+                jobs.append(lambda: ops.gemm(B, 2 * H, Z, Operand(z, Z), 0, self.P(f"{name}.latent_to_hidden.weight", Z), 0, hid, 2 * H,
+                                             bias=self._pv(f"{name}.latent_to_hidden.bias")))
         Y = self.buf(f"Y_{tag}", B, steps + 2, 2 * H)
         for dirn, d in enumerate(dirs):
             st = self.buf(f"st_{tag}_{dirn}", ops.gru_stash_floats(B, steps, H)) if training else None
             h0_off = dirn * B * H          # hidden.view(2,B,H) (rnn_model.py:104,137): direction d, row b lives at flat offset (d*B+b)*H
             if inputs is None:             # z at every step (rnn_model.py:169-170): one projection, constant in time
                 gi = self.buf(f"gi_{tag}_{dirn}", B, 3 * H)
-                jobs.append(lambda d=d, gi=gi: ops.gemm(B, 3 * H, Z, Operand(z, Z), 0, self.P(d.w_ih, Z), 0, gi, 3 * H, bias=d.bias_gi))
+                if narrow:
+                    jobs.append((self.P(d.w_ih, Z), d.bias_gi, gi, 3 * H, 3 * H))
+                else:
+                    jobs.append(lambda d=d, gi=gi: ops.gemm(B, 3 * H, Z, Operand(z, Z), 0, self.P(d.w_ih, Z), 0, gi, 3 * H, bias=d.bias_gi))
                 rows.append(self._gru_fwd_stream(d, gi, 3 * H, 0, hid, h0_off, Y, 2 * H, steps, dirn, None, 0, 0, st, steps))
             else:                          # the caller's own sequence (B, L >= steps, Z): a projection per step, like encoder layer 1
                 ins, L = inputs
@@ -827,7 +834,11 @@ class VAEEngine:
         want_d, want_f = which in ("both", "dec"), s.future and which in ("both", "fut")
         Yd = self._decode_one("dec", "decoder", self.dec, T, z, B, training, rows, jobs, inputs) if want_d else None
         Yf = self._decode_one("fut", "decoder_future", self.fut, FS, z, B, training, rows, jobs, inputs) if want_f else None
-        self._parallel(jobs, self.small_streams)      # <= 6 independent (B x 3H|2H x Z) projections of z
+        # <= 6 independent (B x 3H|2H x Z) projections of z: one launch for zdims <= 32 (K <= 32: a store stream, no matrix cores), else GEMMs on streams
+        lin = [j for j in jobs if isinstance(j, tuple)]
+        for i in range(0, len(lin), 8):
+            ops.linear_group(Operand(z, self.spec.Z), B, self.spec.Z, lin[i:i + 8])
+        self._parallel([j for j in jobs if not isinstance(j, tuple)], self.small_streams)
         self._gru_fwd(rows, B)
         self._issue_pending_cluster()                 # the solve runs beside the output heads below
         H, Hf = s.Hd, s.Hf

@@ -116,6 +116,18 @@ def gemm_group(M, N, K, As, a_kmajor, Bs, b_kmajor, C, c_offs, ldc, splitk, ws, 
     _lib.check(rc, "vame_gemm_group_f32")
 
 
+def linear_group(A, M, K, problems):
+    """Up to 8 Linear layers of one narrow input in one launch (vame_linear_group_f32): A = Operand (M, K) with K <= 32; problems =
+    [(W Operand (N, K) contiguous, bias tensor or None, C tensor, ldc, N)], C (M, N) with row stride ldc."""
+    n = len(problems)
+    assert 1 <= n <= 8 and K <= 32 and not A.seg and all(W.ld == K and not W.seg for W, *_ in problems)
+    vp, i64, i32 = ctypes.c_void_p * n, ctypes.c_int64 * n, ctypes.c_int * n
+    rc = _lib.lib().vame_linear_group_f32(n, M, K, _ptr(A.t, A.off), A.ld, vp(*[_ptr(W.t, W.off) for W, *_ in problems]),
+                                          vp(*[_ptr(b) for _, b, *_ in problems]), vp(*[_ptr(C) for _, _, C, *_ in problems]),
+                                          i64(*[p[3] for p in problems]), i32(*[p[4] for p in problems]), _stream())
+    _lib.check(rc, "vame_linear_group_f32")
+
+
 def gemm_split_ok(M, N, K, As, Bs, splitk, a_gap_at=0, a_gap=0):
     """Whether vame_gemm_group_bf16x6_f32 takes this group (its alignment rules; shapes it is worth using for are the caller's choice)."""
     a0, b0 = As[0], Bs[0]
