@@ -452,22 +452,41 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
     }
     int t = 0;
     if (state) {
-        t = state[1] + 1;
-        const double bc1 = 1.0 - pow((double)beta1, (double)t), bc2 = 1.0 - pow((double)beta2, (double)t);
-        step_size = (float)((double)__builtin_bit_cast(float, state[0]) / bc1);
-        inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
+        // the two double-precision pow() of the bias corrections once per workgroup (every thread doing them cost more than the update itself)
+        __shared__ float sc[2];
+        if (threadIdx.x == 0) {
+            t = state[1] + 1;
+            const double bc1 = 1.0 - pow((double)beta1, (double)t), bc2 = 1.0 - pow((double)beta2, (double)t);
+            sc[0] = (float)((double)__builtin_bit_cast(float, state[0]) / bc1);
+            sc[1] = (float)(1.0 / sqrt(bc2));
+        }
+        __syncthreads();
+        step_size = sc[0];
+        inv_sqrt_bc2 = sc[1];
     }
-    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-        const float gi = g[i] * gscale;
-        const float mi = beta1 * m[i] + (1.0f - beta1) * gi;
-        const float vi = beta2 * v[i] + (1.0f - beta2) * gi * gi;
-        const float vm = fmaxf(vmax[i], vi);
-        m[i] = mi; v[i] = vi; vmax[i] = vm;
-        const float denom = sqrtf(vm) * inv_sqrt_bc2 + eps;
-        p[i] -= step_size * (mi / denom);
+    auto upd = [&](float& pi, float gi, float& mi, float& vi, float& vmi) {
+        gi *= gscale;
+        mi = beta1 * mi + (1.0f - beta1) * gi;
+        vi = beta2 * vi + (1.0f - beta2) * gi * gi;
+        vmi = fmaxf(vmi, vi);
+        const float denom = sqrtf(vmi) * inv_sqrt_bc2 + eps;
+        pi -= step_size * (mi / denom);
+    };
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x, i0 = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    const bool vec = ((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(m) | reinterpret_cast<uintptr_t>(v) |
+                       reinterpret_cast<uintptr_t>(vmax)) & 15) == 0;
+    const int64_t n4 = vec ? n / 4 : 0;
+    for (int64_t i = i0; i < n4; i += stride) {           // 16 bytes per lane and stream; the same arithmetic per element
+        float4 pp = reinterpret_cast<float4*>(p)[i], mm = reinterpret_cast<float4*>(m)[i], vv = reinterpret_cast<float4*>(v)[i],
+               vx = reinterpret_cast<float4*>(vmax)[i];
+        const float4 gg = reinterpret_cast<const float4*>(g)[i];
+        upd(pp.x, gg.x, mm.x, vv.x, vx.x); upd(pp.y, gg.y, mm.y, vv.y, vx.y); upd(pp.z, gg.z, mm.z, vv.z, vx.z); upd(pp.w, gg.w, mm.w, vv.w, vx.w);
+        reinterpret_cast<float4*>(m)[i] = mm; reinterpret_cast<float4*>(v)[i] = vv; reinterpret_cast<float4*>(vmax)[i] = vx;
+        reinterpret_cast<float4*>(p)[i] = pp;
     }
+    for (int64_t i = 4 * n4 + i0; i < n; i += stride) upd(p[i], g[i], m[i], v[i], vmax[i]);
     if (state) {
-        __syncthreads();                                   // every thread of this workgroup has read the step number
+        __syncthreads();
         if (threadIdx.x == 0 && atomicAdd(state + 2, 1) == (int)gridDim.x - 1) { state[2] = 0; state[1] = t; }
     }
 }
