@@ -264,17 +264,6 @@ int vame_mask_scale_f32(const float* x, int64_t off, int64_t ld, int64_t seg, in
 int vame_linear_group_f32(int count, int M, int K, const float* A, int64_t lda, const float* const* W, const float* const* bias,
                           float* const* C, const int64_t* ldc, const int* N, void* stream);
 
-/* Narrow-OUTPUT Linear layers and sums of them in one launch: for j < n_out (<= 4)
- *   C[j] (M, N; row stride ldc[j]) (+)= sum over terms t in [first_term[j], first_term[j+1]) of A[t] (M, K[t]; row stride lda[t]) x W[t]  + bias[j],
- * N <= 32, at most 8 terms in all; W[t] is (K[t], N) row-major if w_kmajor[t] (row stride ldw[t] >= N) else (N, K[t]) row-major (a torch Linear
- * weight, ldw[t] >= K[t]); bias[j] (N) or null; accumulate[j] != 0 adds to C[j].  All array arguments are HOST arrays.  Replaces, per train step,
- * Lambda's two Linear layers (vame/model/rnn_model.py:56-57, 63-66: two vame_gemm_f32 with split-K + two reductions) and the chain that forms
- * d loss / d z (loss.backward(), rnn_vae.py:141-143: two grouped vame_gemm_group_f32 + reductions + the K = zdims product with the nuclear-norm
- * matrix). */
-int vame_linear_narrow_f32(int M, int N, int n_out, const int* first_term, float* const* C, const int64_t* ldc, const float* const* bias,
-                           const int* accumulate, const float* const* A, const int64_t* lda, const float* const* W, const int64_t* ldw,
-                           const int* K, const int* w_kmajor, void* stream);
-
 /* y = a*x + y style helpers for the host orchestration */
 int vame_axpy_f32(const float* x, float a, float* y, int64_t n, void* stream);
 

@@ -921,40 +921,6 @@ def check_linear_group(dev):
             assert (out[:, N:] == 9.0).all()
 
 
-def check_linear_narrow(dev):
-    """vame_linear_narrow_f32: narrow-output (N <= 32) Linear layers and sums of them in one launch vs float64 numpy -- two outputs with one n-major
-    term each and biases (Lambda's heads), one accumulated output with seven k-major terms of different K incl. K = N = 30 (d loss / d z), ragged
-    8-row tiles, K not a multiple of 4 or of the 256-k chunk, unaligned operand rows."""
-    rng = np.random.default_rng(45)
-    f64 = np.float64
-    for (M, N, Ks) in ((37, 30, (1024, 1024)), (260, 30, (768, 768, 768, 768, 512, 512, 30)), (9, 7, (5, 300, 257)), (8, 32, (256,))):
-        # (a) every term its own output, n-major W, bias, overwrite
-        outs, refs = [], []
-        for i, K in enumerate(Ks[:4]):
-            A = rng.standard_normal((M, K + (3 if i == 1 else 0))).astype(np.float32)
-            W = (rng.standard_normal((N, K + (5 if i == 0 else 0))) / np.sqrt(K)).astype(np.float32)
-            b = rng.standard_normal(N).astype(np.float32) if i != 2 else None
-            C = torch.full((M, N + 2), 9.0, device=dev)
-            outs.append((C, N + 2, T_(b, dev) if b is not None else None, False, [(Operand(T_(A, dev), A.shape[1]), Operand(T_(W, dev), W.shape[1]), K, False)]))
-            refs.append(A[:, :K].astype(f64) @ W[:, :K].astype(f64).T + (b if b is not None else 0.0))
-        ops.linear_narrow(M, N, outs)
-        for (C, *_), ref in zip(outs, refs):
-            out = N_(C)
-            np.testing.assert_allclose(out[:, :N], ref, atol=3e-5)
-            assert (out[:, N:] == 9.0).all()
-        # (b) all terms summed into ONE accumulated output, k-major W
-        C0 = rng.standard_normal((M, N)).astype(np.float32)
-        C = T_(C0, dev)
-        terms, ref = [], C0.astype(f64)
-        for K in Ks:
-            A = rng.standard_normal((M, K)).astype(np.float32)
-            W = (rng.standard_normal((K, N + 2)) / np.sqrt(K)).astype(np.float32)
-            terms.append((Operand(T_(A, dev), K), Operand(T_(W, dev), N + 2), K, True))
-            ref = ref + A.astype(f64) @ W[:, :N].astype(f64)
-        ops.linear_narrow(M, N, [(C, N, None, True, terms)])
-        np.testing.assert_allclose(N_(C), ref, atol=5e-5)
-
-
 def check_colsum(dev):
     rng = np.random.default_rng(6)
     a = rng.standard_normal((13, 300)).astype(np.float32)

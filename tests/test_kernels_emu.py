@@ -5,7 +5,7 @@ the CPU; the same checks run on the real GPU in test_kernels_gpu.py.
 """
 import pytest
 
-from kernel_cases import (check_linear_narrow, check_linear_group, check_head_fused, check_gemm_group_shared_output, check_gru_wide, check_gru_wide_small, check_hmm, check_adam, check_adam_abort_and_mask_scale, check_colsum, check_colsum_batch, check_kmeans, check_gather, check_gemm_cases, check_gemm_group, check_gemm_split, check_gemm_split_rows, check_gemm_pipelined_shapes, check_gru_bwd, check_gru_skew_fwd, check_gru_wide_skew_fwd, check_gru_ws_bwd, check_gru_kernel_option_is_an_argument, check_gru_coop_bwd, check_gru_coop_fwd, check_gru_fwd, check_gru_fwd_fused,
+from kernel_cases import (check_linear_group, check_head_fused, check_gemm_group_shared_output, check_gru_wide, check_gru_wide_small, check_hmm, check_adam, check_adam_abort_and_mask_scale, check_colsum, check_colsum_batch, check_kmeans, check_gather, check_gemm_cases, check_gemm_group, check_gemm_split, check_gemm_split_rows, check_gemm_pipelined_shapes, check_gru_bwd, check_gru_skew_fwd, check_gru_wide_skew_fwd, check_gru_ws_bwd, check_gru_kernel_option_is_an_argument, check_gru_coop_bwd, check_gru_coop_fwd, check_gru_fwd, check_gru_fwd_fused,
                           check_latent, check_latent_draw, check_loss_finish, check_mse, check_nuclear, check_prep_fill_rules, check_prepare_series_golden,
                           check_prepare_series_vs_oracle)
 
@@ -140,10 +140,6 @@ def test_gru_wide_kernels_at_small_hidden_sizes(emu, H, B, T):
 
 def test_gemm_group_shared_output(emu):
     check_gemm_group_shared_output(DEV)
-
-
-def test_linear_narrow_outputs_and_sums(emu):
-    check_linear_narrow(DEV)
 
 
 def test_linear_group_of_a_narrow_input(emu):

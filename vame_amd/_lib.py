@@ -61,7 +61,6 @@ _SIGS = {
                                       c_float, c_int, c_float, c_void_p, c_void_p, c_void_p, c_void_p]),
     "vame_mask_scale_f32": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_int64, c_void_p, c_float, c_void_p, c_int64, c_int, c_void_p]),
     "vame_linear_group_f32": (c_int, [c_int, c_int, c_int, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
-    "vame_linear_narrow_f32": (c_int, [c_int, c_int, c_int] + [c_void_p] * 11 + [c_void_p]),
     "vame_axpy_f32": (c_int, [c_void_p, c_float, c_void_p, c_int64, c_void_p]),
     "vame_index_copy_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
     "vame_gru_coop_flag_ints": (c_int64, [c_int, c_int, c_int]),

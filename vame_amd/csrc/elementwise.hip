@@ -605,139 +605,6 @@ extern "C" int vame_linear_group_f32(int count, int M, int K, const float* A, in
     return VAME_OK;
 }
 
-// Narrow-OUTPUT Linear layers and sums of them in one launch: for each of up to 4 outputs, C_j (M, N) (+)= sum over its terms A_t (M, K_t) W_t + bias_j,
-// N <= 32.  Two places of a train step are chains of such contractions whose matrix-core tiles are 3/4 empty and whose split-K partial sums need a
-// reduction launch each:  Lambda's two heads, mean / logvar = hn W^T + b (rnn_model.py:56-57, 63-66: two outputs, one term each, W (N, K) as stored),
-// and d loss / d z = sum of the decoders' dgi W_ih and dhid W_l2h, plus z Minv from the nuclear norm (loss.backward(), rnn_vae.py:141-143: one
-// output, seven terms, W (K, N) as stored).  Workgroup = 8 rows of one output; 16 k-splits x (2 row quads x 8 column quads) threads; a 256-k chunk
-// of A (transposed) and W in LDS, the next chunk's global loads in flight in registers; k-ordered fmaf chains per split, the 16 splits added in a
-// fixed order through LDS.  Three workgroups per CU hide each other's chunk latency.
-constexpr int LN_ROWS = 8, LN_CH = 256, LN_MAX_TERMS = 8, LN_MAX_OUT = 4;
-struct LinNarrowParams {
-    int M, N, n_out;
-    int first[LN_MAX_OUT + 1];
-    float* C[LN_MAX_OUT]; int64_t ldc[LN_MAX_OUT]; const float* bias[LN_MAX_OUT]; int accumulate[LN_MAX_OUT];
-    const float* A[LN_MAX_TERMS]; int64_t lda[LN_MAX_TERMS]; const float* W[LN_MAX_TERMS]; int64_t ldw[LN_MAX_TERMS]; int K[LN_MAX_TERMS]; int kmajor[LN_MAX_TERMS];
-};
-
-__global__ __launch_bounds__(256) void linear_narrow_kernel(LinNarrowParams P) {
-    __shared__ __attribute__((aligned(16))) float As[LN_CH][LN_ROWS];             // [k][row]
-    __shared__ __attribute__((aligned(16))) float Ws[LN_CH][32 + 4];              // [k][n]
-    __shared__ float red[16][LN_ROWS][32];
-    const int tid = threadIdx.x, o = blockIdx.y, m0 = blockIdx.x * LN_ROWS, N = P.N;
-    const int ks = tid >> 4, rg = (tid >> 3) & 1, nq = tid & 7;                     // k-split, row quad, column quad
-    float acc[4][4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r)
-#pragma unroll
-        for (int c = 0; c < 4; ++c) acc[r][c] = 0.f;
-    // loader roles.  A: thread -> (row tid / 32, k quads (tid % 32) and +32) of the chunk.  W k-major: thread -> (k = tid, all n).  W n-major:
-    // thread -> (n = tid / 8, 32 consecutive k starting at 32 (tid % 8))
-    const int arow = tid >> 5, akq = tid & 31;
-    for (int t = P.first[o]; t < P.first[o + 1]; ++t) {
-        const int K = P.K[t];
-        const float* Ag = P.A[t] + (int64_t)(m0 + arow < P.M ? m0 + arow : P.M - 1) * P.lda[t];
-        const float* Wg = P.W[t];
-        const int64_t ldw = P.ldw[t];
-        const bool km = P.kmajor[t] != 0, avec = (P.lda[t] & 3) == 0 && (reinterpret_cast<uintptr_t>(P.A[t]) & 15) == 0;
-        float pa[8], pw[32];
-        auto fetch = [&](int k0) {
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const int k = k0 + 4 * (akq + 32 * h);
-                if (avec && k + 4 <= K) {
-                    const float4 v = *reinterpret_cast<const float4*>(Ag + k);
-                    pa[4 * h] = v.x; pa[4 * h + 1] = v.y; pa[4 * h + 2] = v.z; pa[4 * h + 3] = v.w;
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) pa[4 * h + e] = k + e < K ? Ag[k + e] : 0.f;
-                }
-            }
-            if (km) {
-                const int k = k0 + tid;
-                const float* wr = Wg + (int64_t)(k < K ? k : K - 1) * ldw;
-#pragma unroll
-                for (int n = 0; n < 32; ++n) pw[n] = (k < K && n < N) ? wr[n] : 0.f;
-            } else {
-                const int n = tid >> 3, kb = k0 + 32 * (tid & 7);
-                const float* wr = Wg + (int64_t)(n < N ? n : N - 1) * ldw;
-#pragma unroll
-                for (int e = 0; e < 32; ++e) pw[e] = (n < N && kb + e < K) ? wr[kb + e] : 0.f;
-            }
-        };
-        fetch(0);
-        for (int k0 = 0; k0 < K; k0 += LN_CH) {
-            __syncthreads();                                        // the previous chunk (or term) has been consumed
-#pragma unroll
-            for (int h = 0; h < 2; ++h)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) As[4 * (akq + 32 * h) + e][arow] = pa[4 * h + e];
-            if (km) {
-#pragma unroll
-                for (int n4 = 0; n4 < 8; ++n4) *reinterpret_cast<float4*>(&Ws[tid][4 * n4]) = make_float4(pw[4 * n4], pw[4 * n4 + 1], pw[4 * n4 + 2], pw[4 * n4 + 3]);
-            } else {
-#pragma unroll
-                for (int e = 0; e < 32; ++e) Ws[32 * (tid & 7) + e][tid >> 3] = pw[e];
-            }
-            __syncthreads();
-            if (k0 + LN_CH < K) fetch(k0 + LN_CH);                  // in flight during the chunk's FMAs
-            const int kend = K - k0 < LN_CH ? K - k0 : LN_CH;
-#pragma unroll 4
-            for (int i = 0; i < 16; ++i) {
-                const int kk = 16 * ks + i;
-                if (kk >= kend) break;                              // (a split's k range is contiguous: uniform per 16 lanes)
-                const float4 a = *reinterpret_cast<const float4*>(&As[kk][4 * rg]), w = *reinterpret_cast<const float4*>(&Ws[kk][4 * nq]);
-                const float av[4] = {a.x, a.y, a.z, a.w}, wv[4] = {w.x, w.y, w.z, w.w};
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) acc[r][c] = fmaf(av[r], wv[c], acc[r][c]);
-            }
-        }
-    }
-#pragma unroll
-    for (int r = 0; r < 4; ++r)
-#pragma unroll
-        for (int c = 0; c < 4; ++c) red[ks][4 * rg + r][4 * nq + c] = acc[r][c];
-    __syncthreads();
-    const int row = tid >> 5, n = tid & 31, m = m0 + row;
-    if (m < P.M && n < N) {
-        float sum = 0.f;
-#pragma unroll
-        for (int sp = 0; sp < 16; ++sp) sum += red[sp][row][n];
-        if (P.bias[o]) sum += P.bias[o][n];
-        float* c = P.C[o] + (int64_t)m * P.ldc[o] + n;
-        *c = P.accumulate[o] ? *c + sum : sum;
-    }
-}
-
-extern "C" int vame_linear_narrow_f32(int M, int N, int n_out, const int* first_term, float* const* C, const int64_t* ldc, const float* const* bias,
-                                      const int* accumulate, const float* const* A, const int64_t* lda, const float* const* W, const int64_t* ldw,
-                                      const int* K, const int* w_kmajor, void* stream) {
-    VAME_CHECK_ARG(M >= 1 && N >= 1 && N <= 32 && n_out >= 1 && n_out <= LN_MAX_OUT && first_term && C && ldc && bias && accumulate && A && lda && W && ldw &&
-                       K && w_kmajor, VAME_E_SHAPE, "linear_narrow: M=%d N=%d (1..32) outputs=%d (1..4)", M, N, n_out);
-    VAME_CHECK_ARG(first_term[0] == 0 && first_term[n_out] >= n_out && first_term[n_out] <= LN_MAX_TERMS, VAME_E_SHAPE, "linear_narrow: %d terms (1..8 in all)",
-                   first_term[n_out]);
-    LinNarrowParams P;
-    P.M = M; P.N = N; P.n_out = n_out;
-    for (int o = 0; o <= LN_MAX_OUT; ++o) P.first[o] = first_term[o < n_out ? o : n_out];
-    for (int o = 0; o < LN_MAX_OUT; ++o) {
-        const bool on = o < n_out;
-        VAME_CHECK_ARG(!on || (C[o] && ldc[o] >= N && first_term[o + 1] > first_term[o]), VAME_E_BADARG, "linear_narrow: output %d: null, ldc < N or no term", o);
-        P.C[o] = on ? C[o] : nullptr; P.ldc[o] = on ? ldc[o] : 0; P.bias[o] = on ? bias[o] : nullptr; P.accumulate[o] = on ? accumulate[o] : 0;
-    }
-    for (int t = 0; t < LN_MAX_TERMS; ++t) {
-        const bool on = t < first_term[n_out];
-        VAME_CHECK_ARG(!on || (A[t] && W[t] && K[t] >= 1 && lda[t] >= K[t] && ldw[t] >= (w_kmajor[t] ? N : K[t])), VAME_E_BADARG,
-                       "linear_narrow: term %d: null operand or a row stride below the row length", t);
-        P.A[t] = on ? A[t] : nullptr; P.lda[t] = on ? lda[t] : 0; P.W[t] = on ? W[t] : nullptr; P.ldw[t] = on ? ldw[t] : 0; P.K[t] = on ? K[t] : 0;
-        P.kmajor[t] = on ? w_kmajor[t] : 0;
-    }
-    hipLaunchKernelGGL(linear_narrow_kernel, dim3((unsigned)cdiv64(M, LN_ROWS), (unsigned)n_out), dim3(256), 0, (hipStream_t)stream, P);
-    VAME_LAUNCH_CHECK("linear_narrow");
-    return VAME_OK;
-}
-
 __global__ __launch_bounds__(256) void axpy_kernel(const float* __restrict__ x, float a, float* __restrict__ y, int64_t n) {
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
         y[i] += a * x[i];

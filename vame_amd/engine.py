@@ -112,7 +112,6 @@ class Workspace:
 # the measured best; the A/B tools set them by name (tools/step_ab.py B name=option:value,...; tools/shape_table.py SHAPE_ENGINE=option:value).
 ENGINE_DEFAULTS = dict(
     group_wgrads=True,     # same-shape weight-gradient contractions leave as grouped launches (_group_wgrads)
-    narrow_fused=True,     # zdims <= 32: Lambda's two heads and the d loss / d z chain as one narrow-output launch each (vame_linear_narrow_f32)
     fuse_heads=True,       # output Linear + MSE + dY + the Linear's weight gradient per decoder in ONE pass over the decoder states
                            # (vame_head_stream_f32, round 6) instead of four contractions + the MSE kernel; shapes it does not cover keep those
     small_streams=3,       # HIP streams for the independent small GEMMs before the decoders' launch
@@ -170,7 +169,6 @@ class VAEEngine:
         self.ws = Workspace()
         self._wgrad_queue = None
         self.group_wgrads = bool(opt["group_wgrads"])
-        self.narrow_fused = bool(opt["narrow_fused"])
         self.fuse_heads = bool(opt["fuse_heads"])          # (the parity tests run the step both ways)
         self._heads_deferred = False
         self._B_bwd = None
@@ -780,15 +778,10 @@ class VAEEngine:
         mu, lvr = self.buf("mu", B, Z), self.buf("lv_raw", B, Z)
         logvar, z = self.buf("logvar", B, Z), self.buf("z", B, Z)
         hn_op = Operand(hn, 4 * H)
-        if Z <= 32 and self.narrow_fused:
-            # Lambda's two heads in ONE launch (vame_linear_narrow_f32: narrow outputs, no split-K partial sums)
-            ops.linear_narrow(B, Z, [(mu, Z, self._pv("lmbda.hidden_to_mean.bias"), False, [(hn_op, self.P("lmbda.hidden_to_mean.weight", 4 * H), 4 * H, False)]),
-                                     (lvr, Z, self._pv("lmbda.hidden_to_logvar.bias"), False, [(hn_op, self.P("lmbda.hidden_to_logvar.weight", 4 * H), 4 * H, False)])])
-        else:
-            ops.gemm(B, Z, 4 * H, hn_op, 0, self.P("lmbda.hidden_to_mean.weight", 4 * H), 0, mu, Z,
-                     bias=self._pv("lmbda.hidden_to_mean.bias"), splitk=0)
-            ops.gemm(B, Z, 4 * H, hn_op, 0, self.P("lmbda.hidden_to_logvar.weight", 4 * H), 0, lvr, Z,
-                     bias=self._pv("lmbda.hidden_to_logvar.bias"), splitk=0)
+        ops.gemm(B, Z, 4 * H, hn_op, 0, self.P("lmbda.hidden_to_mean.weight", 4 * H), 0, mu, Z,
+                 bias=self._pv("lmbda.hidden_to_mean.bias"), splitk=0)
+        ops.gemm(B, Z, 4 * H, hn_op, 0, self.P("lmbda.hidden_to_logvar.weight", 4 * H), 0, lvr, Z,
+                 bias=self._pv("lmbda.hidden_to_logvar.bias"), splitk=0)
         rng = None
         if training and eps is None:
             if self._rng is None:
@@ -1089,22 +1082,11 @@ class VAEEngine:
             # time-constant dW_ih job has the same (M, N, K) -- and reads `dgsum`, which timesum wrote AFTER ev_dec was recorded
             self._early_wgrads(ev_dec, lambda j: j[0] == 3 * Hf_ and j[1] == Hf_ and j[2] == Kf and j[7] == 2 * Hf_ and j[8] == Hf_
                                and j[5].startswith("decoder_future.") and ".weight_hh" in j[5])
+        self._sum_into(dz, B, Z, dz_jobs)
         H = He
-        with_minv = use_minv and kl_weight != 0
-        if Z <= 32 and self.narrow_fused and 1 <= len(dz_jobs) + int(with_minv) <= 8:
-            # d loss / d z in ONE launch: the decoders' (B x K)(K x Z) products and z Minv (vame_linear_narrow_f32; was two grouped split-K launches,
-            # their reductions and a K = zdims GEMM).  Minv comes from the nuclear-norm solve on its side stream: joined first.
-            terms = [(A, Wop, K, True) for K, A, Wop in dz_jobs]
-            if with_minv:
-                self.join_cluster()
-                terms.append((Operand(z, Z), Operand(self.buf("Minv", Z, Z), Z), Z, True))
-            ops.linear_narrow(B, Z, [(dz, Z, None, False, terms)])
-            self.join_cluster()
-        else:
-            self._sum_into(dz, B, Z, dz_jobs)
-            self.join_cluster()
-            if with_minv:
-                ops.gemm(B, Z, Z, Operand(z, Z), 0, Operand(self.buf("Minv", Z, Z), Z), 1, dz, Z, accumulate=True)
+        self.join_cluster()
+        if use_minv and kl_weight != 0:
+            ops.gemm(B, Z, Z, Operand(z, Z), 0, Operand(self.buf("Minv", Z, Z), Z), 1, dz, Z, accumulate=True)
         if dz_ext is not None:
             ops.axpy(dz_ext, 1.0, dz, B * Z)
         # ---- reparameterisation + KL

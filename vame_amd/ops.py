@@ -128,25 +128,6 @@ def linear_group(A, M, K, problems):
     _lib.check(rc, "vame_linear_group_f32")
 
 
-def linear_narrow(M, N, outputs):
-    """Narrow-output (N <= 32) Linear layers / sums of them in one launch (vame_linear_narrow_f32).  outputs = [(C tensor, ldc, bias tensor or None,
-    accumulate, [(A Operand (M, K), W Operand, K, w_kmajor)])]: C (+)= sum_t A_t W_t + bias; W_t Operand (K, N) if w_kmajor else (N, K)."""
-    terms = [t for o in outputs for t in o[4]]
-    no, nt = len(outputs), len(terms)
-    assert 1 <= no <= 4 and nt <= 8 and all(not A.seg and not W.seg for A, W, *_ in terms)
-    first = [0]
-    for o in outputs:
-        first.append(first[-1] + len(o[4]))
-    vo, vt = ctypes.c_void_p * no, ctypes.c_void_p * nt
-    rc = _lib.lib().vame_linear_narrow_f32(
-        M, N, no, (ctypes.c_int * (no + 1))(*first), vo(*[_ptr(o[0]) for o in outputs]), (ctypes.c_int64 * no)(*[o[1] for o in outputs]),
-        vo(*[_ptr(o[2]) for o in outputs]), (ctypes.c_int * no)(*[int(bool(o[3])) for o in outputs]),
-        vt(*[_ptr(A.t, A.off) for A, *_ in terms]), (ctypes.c_int64 * nt)(*[A.ld for A, *_ in terms]), vt(*[_ptr(W.t, W.off) for _, W, *_ in terms]),
-        (ctypes.c_int64 * nt)(*[W.ld for _, W, *_ in terms]), (ctypes.c_int * nt)(*[t[2] for t in terms]), (ctypes.c_int * nt)(*[int(bool(t[3])) for t in terms]),
-        _stream())
-    _lib.check(rc, "vame_linear_narrow_f32")
-
-
 def gemm_split_ok(M, N, K, As, Bs, splitk, a_gap_at=0, a_gap=0):
     """Whether vame_gemm_group_bf16x6_f32 takes this group (its alignment rules; shapes it is worth using for are the caller's choice)."""
     a0, b0 = As[0], Bs[0]
