@@ -112,6 +112,7 @@ class Workspace:
 # the measured best; the A/B tools set them by name (tools/step_ab.py B name=option:value,...; tools/shape_table.py SHAPE_ENGINE=option:value).
 ENGINE_DEFAULTS = dict(
     group_wgrads=True,     # same-shape weight-gradient contractions leave as grouped launches (_group_wgrads)
+    group_zproj=True,      # zdims <= 32: the decoders' <= 6 Linear layers of z (latent_to_hidden, W_ih on the time-constant input) as one launch
     fuse_heads=True,       # output Linear + MSE + dY + the Linear's weight gradient per decoder in ONE pass over the decoder states
                            # (vame_head_stream_f32, round 6) instead of four contractions + the MSE kernel; shapes it does not cover keep those
     small_streams=3,       # HIP streams for the independent small GEMMs before the decoders' launch
@@ -169,6 +170,7 @@ class VAEEngine:
         self.ws = Workspace()
         self._wgrad_queue = None
         self.group_wgrads = bool(opt["group_wgrads"])
+        self.group_zproj = bool(opt["group_zproj"])
         self.fuse_heads = bool(opt["fuse_heads"])          # (the parity tests run the step both ways)
         self._heads_deferred = False
         self._B_bwd = None
@@ -794,7 +796,7 @@ class VAEEngine:
     def _decode_one(self, tag, name, dirs, steps, z, B, training, rows, jobs, inputs=None):
         H, Z = dirs[0].H, self.spec.Z
         hid = None
-        narrow = inputs is None and Z <= 32         # the projections of the time-constant z leave as ONE launch (decode(): ops.linear_group)
+        narrow = inputs is None and Z <= 32 and self.group_zproj     # the projections of the time-constant z leave as ONE launch (decode(): ops.linear_group)
         if self.h0_from_z:
             hid = self.buf(f"hid_{tag}", B, 2 * H)
             if narrow:
