@@ -691,11 +691,15 @@ def main():
                            roofline=c4["roofline"])
             b256 = train_leg(dev, 256, 30, 256, 30, 10, 0, 1, graph=True)
             b256e = train_leg(dev, 256, 30, 256, 30, 10, 0, 1, profile=False)
-            b256_line = dict(metric="temporal windows/sec (train) T=30,F=24,h=256", value=round(256 * 30 / b256["dts"][0], 1), unit="windows/s",
-                             steps=30, warmup=10, ms_per_step=round(b256["dts"][0] / 30 * 1e3, 3),
-                             execution="one hipGraph replay per step (rnn_vae.GraphedTrainStep: what train() does up to batch 1024)",
-                             eager=dict(value=round(256 * 30 / b256e["dts"][0], 1), ms_per_step=round(b256e["dts"][0] / 30 * 1e3, 3),
-                                        execution="the same step enqueued launch by launch"),
+            # train() with `vame_amd_hip_graph: auto` times both forms in its first epoch and keeps the faster (GraphedTrainStep._measure): so does this leg
+            g_ms, e_ms = b256["dts"][0] / 30 * 1e3, b256e["dts"][0] / 30 * 1e3
+            pick = "graph" if g_ms <= e_ms else "eager"
+            b256_line = dict(metric="temporal windows/sec (train) T=30,F=24,h=256", value=round(256 / min(g_ms, e_ms) * 1e3, 1), unit="windows/s",
+                             steps=30, warmup=10, ms_per_step=round(min(g_ms, e_ms), 3),
+                             execution=f"the faster of the two forms on this box, as train()'s hip_graph 'auto' picks it: {pick}",
+                             graph=dict(value=round(256 / g_ms * 1e3, 1), ms_per_step=round(g_ms, 3),
+                                        execution="one hipGraph replay per step (rnn_vae.GraphedTrainStep)"),
+                             eager=dict(value=round(256 / e_ms * 1e3, 1), ms_per_step=round(e_ms, 3), execution="the same step enqueued launch by launch"),
                              config=dict(workload=workload_name(256, 30, 256, 1)), roofline=b256["roofline"])
             emb_line = embed_leg(dev, 2_000_000, 0, 1)
             if not args.no_cpu_baseline:              # the reference's batch-1 loop as written and a batch-256 variant, beside the embedding number

@@ -1,4 +1,4 @@
-"""Every contraction of one train step that has a dimension <= 32 (bench.py's "narrow" HBM rows), listed by shape: launches per step, time, algorithmic
+"""Every contraction of one train step that has a dimension <= 32 (incl., since round 6, the streaming output heads and the grouped projections of z) (bench.py's "narrow" HBM rows), listed by shape: launches per step, time, algorithmic
 bytes (A, B read once + C written once) and the rate against the 8 TB/s HBM roofline.  HIP-event times: launches shorter than the host's enqueue time
 (~20 us with the event pair) read long here -- profiles/r05_kernel_stats.csv has their kernel-trace durations (the sum is ~0.78 ms per headline step
 against ~1.03 ms by events); at ~4.5 TB/s for the six >= 130 MB launches the step would gain ~0.15 ms (1 %).
@@ -49,7 +49,13 @@ def main():
             return ("wide", 0.0)
         return (f"{kind(akm, bkm)} M={M} N={N} K={K} x{len(As)} grouped", 4.0 * (M * K + K * N + M * N) * len(As))
 
-    saved = {n: kt.wrap(ops, n, f) for n, f in (("gemm", one), ("gemm_group", group))}
+    def head(Yop, M, F_, K, *a, **k):                               # round 6: the streaming output head (prediction + MSE + dY + dW in one pass over the states)
+        return (f"head_stream M={M} F={F_} K={K} (+ its dW reduction)", 4.0 * (2.0 * M * K + 3.0 * M * F_))
+
+    def lin(A, M, K, problems):                                     # round 6: the decoders' projections of z in one launch
+        return (f"linear_group M={M} K={K} N={'+'.join(str(p[4]) for p in problems)}", 4.0 * (M * K + sum(p[4] * (K + M) for p in problems)))
+
+    saved = {n: kt.wrap(ops, n, f) for n, f in (("gemm", one), ("gemm_group", group), ("head_stream", head), ("linear_group", lin))}
     prev = model._engine.set_overlap(False)
     steps = 5
     for _ in range(steps):

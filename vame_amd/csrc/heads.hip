@@ -97,16 +97,23 @@ __global__ __launch_bounds__(256, 2) void head_stream_kernel(HeadParams P) {
     const float bA = c0 < F ? P.bias[c0] : 0.f, bB = c0 + 16 < F ? P.bias[c0 + 16] : 0.f;
     float lsum = 0.f;
     f32x4 nxt[NT];
+    // (b, t) of this thread's row in the tile being fetched, advanced by one grid stride per tile without divisions: every VALU instruction
+    // here waits behind the f32 MFMAs of the CU's other workgroup
+    const int step_rows = (int)gridDim.x * HS_ROWS, step_b = step_rows / seg, step_t = step_rows - step_b * seg;
+    int fb = (blockIdx.x * HS_ROWS + lrow) / seg, ft = (blockIdx.x * HS_ROWS + lrow) - fb * seg, cb = 0, ct = 0;
     auto fetch = [&](int tile) {
         const int m = tile * HS_ROWS + lrow;
         const bool ok = tile < P.ntiles && m < P.M;
-        const int b = ok ? m / seg : 0;
-        const float* yrow = P.Y + (int64_t)b * P.y_seg_stride + (int64_t)(ok ? m - b * seg : 0) * P.y_ld + 4 * c0;
+        const float* yrow = P.Y + (int64_t)(ok ? fb : 0) * P.y_seg_stride + (int64_t)(ok ? ft : 0) * P.y_ld + 4 * c0;
 #pragma unroll
         for (int j = 0; j < NT; ++j) nxt[j] = ok ? *reinterpret_cast<const f32x4*>(yrow + 64 * j) : f32x4{0.f, 0.f, 0.f, 0.f};
+        cb = fb; ct = ft;                                             // what the tile just requested will be when it is the current one
+        fb += step_b; ft += step_t;
+        if (ft >= seg) { ft -= seg; ++fb; }
     };
     int tile = blockIdx.x;
     fetch(tile);
+    int tb = cb, tt = ct;                                              // (b, t) of the CURRENT tile's row
     HS_PHASE_DECL();
     for (; tile < P.ntiles; tile += gridDim.x) {
 #pragma unroll
@@ -124,8 +131,7 @@ __global__ __launch_bounds__(256, 2) void head_stream_kernel(HeadParams P) {
         const bool ok_t = m_t < P.M;
         float tgA = 0.f, tgB = 0.f;
         {
-            const int b = ok_t ? m_t / seg : 0, t = ok_t ? m_t - b * seg : 0;
-            const float* tg = P.tgt + (int64_t)b * P.tgt_row + P.tgt_off + (int64_t)t * F;
+            const float* tg = P.tgt + (int64_t)(ok_t ? tb : 0) * P.tgt_row + P.tgt_off + (int64_t)(ok_t ? tt : 0) * F;
             if (ok_t && c0 < F) tgA = tg[c0];
             if (ok_t && c0 + 16 < F) tgB = tg[c0 + 16];
         }
@@ -153,6 +159,7 @@ __global__ __launch_bounds__(256, 2) void head_stream_kernel(HeadParams P) {
         // the next tile's states: the YOUNGEST loads of the iteration (vmcnt retires in order: the wait for the targets leaves these in flight),
         // covered by the dpred phase, P3, P2 and the copy-out; not in front of P1: its fragments + these would spill
         fetch(tile + gridDim.x);
+        const int nb_ = cb, nt_ = ct;                                  // (the next iteration's current row position)
         // ---- prediction, error, loss, dpred
         {
 #pragma unroll
@@ -212,6 +219,7 @@ __global__ __launch_bounds__(256, 2) void head_stream_kernel(HeadParams P) {
             }
         }
         HS_PHASE(5);                                                   // copy-out
+        tb = nb_; tt = nt_;
     }
     HS_PHASE_END();
     // ---- this workgroup's dW sums -> workspace in ACCUMULATOR order: [mt][wave][nt][lane] float4 units (one coalesced 1 KB store per
