@@ -195,7 +195,7 @@ int vame_mse_fwd_bwd_f32(const float* pred, const float* target, int64_t tgt_row
  *   dY[m*dy_ld + n] = sum_f dpred[m,f] W[f,n], n < K;   dW[f,n] = sum_m dpred[m,f] y_m[n]  (overwritten; deterministic order).
  * pred may be null.  Replaces vame_gemm_f32 (N = F) + vame_mse_fwd_bwd_f32 + vame_gemm_f32 (K = F) + the split-K weight-gradient
  * vame_gemm_f32 (M = F, K = B*T) and its reduction on the training path; the stand-alone decoder calls keep the GEMM.
- * Shapes: 1 <= F <= 32, K a multiple of 64 up to 512; state rows, W and dY rows 16-byte aligned.  ws: vame_head_stream_ws_floats(M, F, K)
+ * Shapes: 1 <= F <= 32, K a multiple of 64 up to 512 or a multiple of 128 up to 1024; state rows, W and dY rows 16-byte aligned.  ws: vame_head_stream_ws_floats(M, F, K)
  * floats of scratch (per-workgroup dW sums); that function returns -1 for a shape the kernel does not cover. */
 int64_t vame_head_stream_ws_floats(int M, int F, int K);
 int vame_head_stream_f32(const float* Y, int64_t y_ld, int64_t y_seg, int64_t y_seg_stride, int M, int F, int K, const float* W,

@@ -876,7 +876,7 @@ def check_head_fused(dev, B=7, T=9, F=24, K=64, pad=2):
     loss = torch.full((3,), 0.5, device=dev)
     bucket = torch.full((F * K + 24,), 3.0, device=dev)
     n_ws = ops.head_stream_ws_floats(B * T, F, K)
-    assert n_ws > 0 and ops.head_stream_ws_floats(B * T, 33, K) == -1 and ops.head_stream_ws_floats(B * T, F, K + 32) == -1
+    assert n_ws > 0 and ops.head_stream_ws_floats(B * T, 33, K) == -1 and ops.head_stream_ws_floats(B * T, F, K + 32) == -1 and ops.head_stream_ws_floats(B * T, F, 1152) == -1
     ws = torch.full((n_ws,), float("nan"), device=dev)              # (every word the reduction reads must have been written by the kernel)
     o1 = 1 if pad else 0
     for _ in range(2):                                              # (a second call on the same buffers: dW is overwritten, the loss slot adds)

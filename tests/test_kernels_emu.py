@@ -146,6 +146,6 @@ def test_linear_group_of_a_narrow_input(emu):
     check_linear_group(DEV)
 
 
-@pytest.mark.parametrize("B,T,F,K,pad", [(7, 9, 24, 64, 2), (3, 50, 10, 128, 0), (5, 31, 32, 192, 2), (290, 30, 24, 64, 2)])
+@pytest.mark.parametrize("B,T,F,K,pad", [(7, 9, 24, 64, 2), (3, 50, 10, 128, 0), (5, 31, 32, 192, 2), (290, 30, 24, 64, 2), (3, 20, 24, 640, 2), (5, 7, 32, 1024, 0)])
 def test_fused_output_head(emu, B, T, F, K, pad):
     check_head_fused(DEV, B, T, F, K, pad)

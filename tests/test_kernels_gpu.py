@@ -138,6 +138,6 @@ def test_linear_group_of_a_narrow_input(hip):
     check_linear_group(DEV)
 
 
-@pytest.mark.parametrize("B,T,F,K,pad", [(7, 9, 24, 64, 2), (3, 50, 10, 128, 0), (5, 31, 32, 192, 2), (4096, 30, 24, 512, 2), (301, 15, 24, 512, 2), (290, 30, 24, 64, 2), (64, 60, 12, 384, 2)])
+@pytest.mark.parametrize("B,T,F,K,pad", [(7, 9, 24, 64, 2), (3, 50, 10, 128, 0), (5, 31, 32, 192, 2), (4096, 30, 24, 512, 2), (301, 15, 24, 512, 2), (290, 30, 24, 64, 2), (64, 60, 12, 384, 2), (512, 30, 32, 512, 2), (300, 60, 24, 1024, 2), (64, 60, 12, 768, 2), (40, 31, 32, 640, 0)])
 def test_fused_output_head(hip, B, T, F, K, pad):
     check_head_fused(DEV, B, T, F, K, pad)

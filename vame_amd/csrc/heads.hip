@@ -38,7 +38,6 @@ extern "C" int vame_probe_set_head(long long* p) { return (int)hipMemcpyToSymbol
 
 namespace {
 constexpr int HS_ROWS = 16;
-constexpr int HS_MAX_WGS = 512;            // two per CU (registers: 242 of 256 at K = 512)
 constexpr int HS_DLD = 48;                 // dpred tile row stride: rows 4s + q land 16 q banks apart (conflict-free A^T reads in P3)
 
 struct HeadParams {
@@ -48,24 +47,25 @@ struct HeadParams {
     float* pred; float* dpred;                              // (M, F) each; pred may be null
     float* dY; int64_t dy_ld;                               // (M, dy_ld), columns [0, K) written
     float* loss;                                            // loss[0] += sum of squared errors
-    float* ws;                                              // (gridDim.x, 2, 4, NT, 64) float4: per-workgroup dW sums in accumulator order
+    float* ws;                                              // (gridDim.x, 2, NW, NT, 64) float4: per-workgroup dW sums in accumulator order
     int M, F, K, ntiles;
     float gscale;
 };
 
-// NT = K / 64: 16-column MFMA tiles per wave (a wave owns K/4 state columns in P2 / P3 and K/4 of the contraction in P1); NFS = ceil(F / 4)
-// k-steps of P2 (6 covers F <= 24, 8 covers F <= 32)
-template <int NT, int NFS>
-__global__ __launch_bounds__(256, 2) void head_stream_kernel(HeadParams P) {
+// NW waves per workgroup (4: K <= 512, two workgroups per CU; 8: K <= 1024 -- hidden sizes up to 512 --, one workgroup per CU); NT = K / (16 NW):
+// 16-column MFMA tiles per wave (a wave owns K / NW state columns in P2 / P3 and K / NW of the contraction in P1); NFS = ceil(F / 4) k-steps of P2
+// (6 covers F <= 24, 8 covers F <= 32)
+template <int NT, int NFS, int NW>
+__global__ __launch_bounds__(64 * NW, 2) void head_stream_kernel(HeadParams P) {
     VAME_DYN_SMEM(smem_raw);
-    constexpr int K = 64 * NT, LD = K + 16;                    // LD = 16 (mod 32): rows 4s + q of a column sit 16 q banks apart
+    constexpr int K = 16 * NT * NW, LD = K + 16, LPR = 4 * NW; // LD = 16 (mod 32): rows 4s + q of a column sit 16 q banks apart; LPR loader lanes per row
     float* yt = reinterpret_cast<float*>(smem_raw);            // [16][LD]   state tile, later the dY tile
-    float* part = yt + HS_ROWS * LD;                           // [4][16][32] P1 partial sums per wave
-    float* db = part + 4 * HS_ROWS * 32;                       // [16][HS_DLD] dpred tile (0 for f >= F and rows >= M)
+    float* part = yt + HS_ROWS * LD;                           // [NW][16][32] P1 partial sums per wave
+    float* db = part + NW * HS_ROWS * 32;                      // [16][HS_DLD] dpred tile (0 for f >= F and rows >= M)
     const int tid = threadIdx.x, lane = tid & 63, l16 = lane & 15, q = lane >> 4;
     const int w = UNIFORM(tid >> 6);
     const int F = P.F, seg = (int)P.y_seg;
-    const int kw = w * (K / 4);                                // P1: this wave's k range; P2 / P3: this wave's state columns
+    const int kw = w * (K / NW);                               // P1: this wave's k range; P2 / P3: this wave's state columns
     // ---- W fragments.  P1 (B operand of tile x W^T: column n = 16 nt + l16, k = kw + 16 c + 4 q + e) is 8 NT registers per lane: re-read from
     // L2 for every tile (requested at the top of the iteration, consumed by P1) -- all of {P1 fragments, P2 fragments, dW accumulators, next tile
     // in flight} resident at once spills, and a spilled register costs a scratch round trip in the middle of a phase.  Rows n >= F of the padded
@@ -92,9 +92,12 @@ __global__ __launch_bounds__(256, 2) void head_stream_kernel(HeadParams P) {
     for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) acc3[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-    // loader / copy-out / dpred role of a thread: row tid / 16, 16-byte column units c0 + 16 j
-    const int lrow = tid >> 4, c0 = tid & 15;
-    const float bA = c0 < F ? P.bias[c0] : 0.f, bB = c0 + 16 < F ? P.bias[c0 + 16] : 0.f;
+    // loader / copy-out / dpred role of a thread: row tid / LPR, 16-byte column units c0 + LPR j; features c0 (and c0 + 16 when a row has 16 lanes)
+    const int lrow = tid / LPR, c0 = tid % LPR;
+    constexpr int NFT = 32 / LPR;                              // prediction features per thread (2 or 1)
+    float bF[NFT];
+#pragma unroll
+    for (int h = 0; h < NFT; ++h) bF[h] = c0 + LPR * h < F ? P.bias[c0 + LPR * h] : 0.f;
     float lsum = 0.f;
     f32x4 nxt[NT];
     // (b, t) of this thread's row in the tile being fetched, advanced by one grid stride per tile without divisions: every VALU instruction
@@ -106,7 +109,7 @@ __global__ __launch_bounds__(256, 2) void head_stream_kernel(HeadParams P) {
         const bool ok = tile < P.ntiles && m < P.M;
         const float* yrow = P.Y + (int64_t)(ok ? fb : 0) * P.y_seg_stride + (int64_t)(ok ? ft : 0) * P.y_ld + 4 * c0;
 #pragma unroll
-        for (int j = 0; j < NT; ++j) nxt[j] = ok ? *reinterpret_cast<const f32x4*>(yrow + 64 * j) : f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < NT; ++j) nxt[j] = ok ? *reinterpret_cast<const f32x4*>(yrow + 4 * LPR * j) : f32x4{0.f, 0.f, 0.f, 0.f};
         cb = fb; ct = ft;                                             // what the tile just requested will be when it is the current one
         fb += step_b; ft += step_t;
         if (ft >= seg) { ft -= seg; ++fb; }
@@ -117,7 +120,7 @@ __global__ __launch_bounds__(256, 2) void head_stream_kernel(HeadParams P) {
     HS_PHASE_DECL();
     for (; tile < P.ntiles; tile += gridDim.x) {
 #pragma unroll
-        for (int j = 0; j < NT; ++j) *reinterpret_cast<f32x4*>(&yt[lrow * LD + 4 * c0 + 64 * j]) = nxt[j];
+        for (int j = 0; j < NT; ++j) *reinterpret_cast<f32x4*>(&yt[lrow * LD + 4 * c0 + 4 * LPR * j]) = nxt[j];
 #ifndef VAME_EMU
         asm volatile("" ::: "memory");      // (the tile's registers are free before P1's fragments are requested: both live at once would spill)
 #endif
@@ -129,11 +132,11 @@ __global__ __launch_bounds__(256, 2) void head_stream_kernel(HeadParams P) {
         // this tile's targets: requested before P1, used behind it (thread = (row lrow, features c0 and c0 + 16))
         const int m_t = tile * HS_ROWS + lrow;
         const bool ok_t = m_t < P.M;
-        float tgA = 0.f, tgB = 0.f;
+        float tgv[NFT];
         {
             const float* tg = P.tgt + (int64_t)(ok_t ? tb : 0) * P.tgt_row + P.tgt_off + (int64_t)(ok_t ? tt : 0) * F;
-            if (ok_t && c0 < F) tgA = tg[c0];
-            if (ok_t && c0 + 16 < F) tgB = tg[c0 + 16];
+#pragma unroll
+            for (int h = 0; h < NFT; ++h) tgv[h] = (ok_t && c0 + LPR * h < F) ? tg[c0 + LPR * h] : 0.f;
         }
         __syncthreads();
         HS_PHASE(0);                                                   // tile -> LDS (waits for the prefetch), requests, barrier
@@ -163,13 +166,15 @@ __global__ __launch_bounds__(256, 2) void head_stream_kernel(HeadParams P) {
         // ---- prediction, error, loss, dpred
         {
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const int f = c0 + 16 * h;
+            for (int h = 0; h < NFT; ++h) {
+                const int f = c0 + LPR * h;
                 const float* pp = part + lrow * 32 + f;
-                const float p = (h ? bB : bA) + ((pp[0] + pp[HS_ROWS * 32]) + (pp[2 * HS_ROWS * 32] + pp[3 * HS_ROWS * 32]));
+                float p = (pp[0] + pp[HS_ROWS * 32]) + (pp[2 * HS_ROWS * 32] + pp[3 * HS_ROWS * 32]);
+                if (NW == 8) p += (pp[4 * HS_ROWS * 32] + pp[5 * HS_ROWS * 32]) + (pp[6 * HS_ROWS * 32] + pp[7 * HS_ROWS * 32]);
+                p += bF[h];
                 float g = 0.f;
                 if (ok_t && f < F) {
-                    const float e = p - (h ? tgB : tgA);
+                    const float e = p - tgv[h];
                     lsum += e * e;
                     g = P.gscale * e;
                     if (P.pred) P.pred[(int64_t)m_t * F + f] = p;
@@ -215,7 +220,7 @@ __global__ __launch_bounds__(256, 2) void head_stream_kernel(HeadParams P) {
             if (m < P.M) {
                 float* drow = P.dY + (int64_t)m * P.dy_ld + 4 * c0;
 #pragma unroll
-                for (int j = 0; j < NT; ++j) *reinterpret_cast<f32x4*>(drow + 64 * j) = *reinterpret_cast<const f32x4*>(&yt[lrow * LD + 4 * c0 + 64 * j]);
+                for (int j = 0; j < NT; ++j) *reinterpret_cast<f32x4*>(drow + 4 * LPR * j) = *reinterpret_cast<const f32x4*>(&yt[lrow * LD + 4 * c0 + 4 * LPR * j]);
             }
         }
         HS_PHASE(5);                                                   // copy-out
@@ -224,28 +229,28 @@ __global__ __launch_bounds__(256, 2) void head_stream_kernel(HeadParams P) {
     HS_PHASE_END();
     // ---- this workgroup's dW sums -> workspace in ACCUMULATOR order: [mt][wave][nt][lane] float4 units (one coalesced 1 KB store per
     // accumulator tile); head_dw_reduce_kernel maps unit (mt, wave, nt, lane = 16 q + l16), element r to dW[16 mt + 4 q + r][wave K/4 + 16 nt + l16]
-    f32x4* wsb = reinterpret_cast<f32x4*>(P.ws) + (int64_t)blockIdx.x * (2 * 4 * NT * 64);
+    f32x4* wsb = reinterpret_cast<f32x4*>(P.ws) + (int64_t)blockIdx.x * (2 * NW * NT * 64);
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) wsb[((mt * 4 + w) * NT + nt) * 64 + lane] = acc3[mt][nt];
+        for (int nt = 0; nt < NT; ++nt) wsb[((mt * NW + w) * NT + nt) * 64 + lane] = acc3[mt][nt];
     // one float atomic per workgroup (atomics on one address serialise)
-    __shared__ float red[4];
+    __shared__ float red[8];
     lsum = wave_sum(lsum);
     if (lane == 0) red[w] = lsum;
     __syncthreads();
-    if (tid == 0) atomicAdd(P.loss, (red[0] + red[1]) + (red[2] + red[3]));
+    if (tid == 0) atomicAdd(P.loss, NW == 8 ? ((red[0] + red[1]) + (red[2] + red[3])) + ((red[4] + red[5]) + (red[6] + red[7])) : (red[0] + red[1]) + (red[2] + red[3]));
 }
 
 // dW = sum over the workgroups' partial sums, read in the accumulator order they were stored in.  A block = 64 consecutive float4 units x 16
 // segments of the workgroup range (1024 threads; a unit's 16 segment sums meet in LDS and are added as a fixed tree), so 0.4 M loads are in
 // flight and the order of the additions depends on nothing but nwg.
-__global__ __launch_bounds__(1024) void head_dw_reduce_kernel(const f32x4* ws, int nwg, int NT, int F, int K, float* dW) {
+__global__ __launch_bounds__(1024) void head_dw_reduce_kernel(const f32x4* ws, int nwg, int NT, int NW, int F, int K, float* dW) {
     __shared__ f32x4 seg[16][64];
-    const int u = blockIdx.x * 64 + (threadIdx.x & 63), sg = threadIdx.x >> 6, units = 2 * 4 * NT * 64;
+    const int u = blockIdx.x * 64 + (threadIdx.x & 63), sg = threadIdx.x >> 6, units = 2 * NW * NT * 64;
     f32x4 a = {0.f, 0.f, 0.f, 0.f}, b = {0.f, 0.f, 0.f, 0.f};
     // unit -> (mt, wave, nt, lane); rows 16 mt + 4 q + r >= F are padding: never read
-    const int lane = u & 63, nt = (u >> 6) % NT, wv = (u >> 6) / NT % 4, mt = (u >> 6) / NT / 4, q = lane >> 4, l16 = lane & 15;
+    const int lane = u & 63, nt = (u >> 6) % NT, wv = (u >> 6) / NT % NW, mt = (u >> 6) / NT / NW, q = lane >> 4, l16 = lane & 15;
     const int f0 = 16 * mt + 4 * q;
     const bool live = u < units && f0 < F;
     if (live) {
@@ -264,47 +269,58 @@ __global__ __launch_bounds__(1024) void head_dw_reduce_kernel(const f32x4* ws, i
         for (int st = 1; st < 16; st *= 2)
 #pragma unroll
             for (int i = 0; i < 16; i += 2 * st) t[i] += t[i + st];
-        const int col = wv * (K / 4) + 16 * nt + l16;
+        const int col = wv * (K / NW) + 16 * nt + l16;
 #pragma unroll
         for (int r = 0; r < 4; ++r)
             if (f0 + r < F) dW[(int64_t)(f0 + r) * K + col] = t[0][r];
     }
 }
 
-int head_nwg(int M) {
-    const int tiles = (int)cdiv64(M, HS_ROWS);
-    return tiles < HS_MAX_WGS ? tiles : HS_MAX_WGS;
+// 4 waves per workgroup for K a multiple of 64 up to 512, 8 waves for multiples of 128 up to 1024
+int head_nw(int K) { return (K <= 512 && K % 64 == 0) ? 4 : 8; }
+bool head_covers(int M, int F, int K) { return M >= 1 && F >= 1 && F <= 32 && K >= 64 && ((K <= 512 && K % 64 == 0) || (K <= 1024 && K % 128 == 0)); }
+int head_nwg(int M, int K) {
+    const int tiles = (int)cdiv64(M, HS_ROWS), cap = head_nw(K) == 4 ? 512 : 256;     // two (one) workgroups per CU
+    return tiles < cap ? tiles : cap;
 }
 
-template <int NT, int NFS>
+template <int NT, int NFS, int NW>
 int head_launch(const HeadParams& P, int nwg, hipStream_t st) {
-    const size_t lds = ((size_t)HS_ROWS * (64 * NT + 16) + 4 * HS_ROWS * 32 + HS_ROWS * HS_DLD) * sizeof(float);
+    const size_t lds = ((size_t)HS_ROWS * (16 * NT * NW + 16) + NW * HS_ROWS * 32 + HS_ROWS * HS_DLD) * sizeof(float);
 #ifndef VAME_EMU
-    VAME_CHECK_ARG(hipFuncSetAttribute(reinterpret_cast<const void*>(&head_stream_kernel<NT, NFS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess,
+    VAME_CHECK_ARG(hipFuncSetAttribute(reinterpret_cast<const void*>(&head_stream_kernel<NT, NFS, NW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess,
                    VAME_E_HIP, "head_stream: cannot reserve %d bytes of LDS", (int)lds);
 #endif
-    hipLaunchKernelGGL((head_stream_kernel<NT, NFS>), dim3((unsigned)nwg), dim3(256), lds, st, P);
+    hipLaunchKernelGGL((head_stream_kernel<NT, NFS, NW>), dim3((unsigned)nwg), dim3(64 * NW), lds, st, P);
     return VAME_OK;
 }
 
 template <int NFS>
 int head_dispatch(const HeadParams& P, int nwg, hipStream_t st) {
-    switch (P.K / 64) {
-        case 1: return head_launch<1, NFS>(P, nwg, st);
-        case 2: return head_launch<2, NFS>(P, nwg, st);
-        case 3: return head_launch<3, NFS>(P, nwg, st);
-        case 4: return head_launch<4, NFS>(P, nwg, st);
-        case 5: return head_launch<5, NFS>(P, nwg, st);
-        case 6: return head_launch<6, NFS>(P, nwg, st);
-        case 7: return head_launch<7, NFS>(P, nwg, st);
-        default: return head_launch<8, NFS>(P, nwg, st);
+    if (head_nw(P.K) == 4) {
+        switch (P.K / 64) {
+            case 1: return head_launch<1, NFS, 4>(P, nwg, st);
+            case 2: return head_launch<2, NFS, 4>(P, nwg, st);
+            case 3: return head_launch<3, NFS, 4>(P, nwg, st);
+            case 4: return head_launch<4, NFS, 4>(P, nwg, st);
+            case 5: return head_launch<5, NFS, 4>(P, nwg, st);
+            case 6: return head_launch<6, NFS, 4>(P, nwg, st);
+            case 7: return head_launch<7, NFS, 4>(P, nwg, st);
+            default: return head_launch<8, NFS, 4>(P, nwg, st);
+        }
+    }
+    switch (P.K / 128) {
+        case 5: return head_launch<5, NFS, 8>(P, nwg, st);
+        case 6: return head_launch<6, NFS, 8>(P, nwg, st);
+        case 7: return head_launch<7, NFS, 8>(P, nwg, st);
+        default: return head_launch<8, NFS, 8>(P, nwg, st);
     }
 }
 }  // namespace
 
 extern "C" int64_t vame_head_stream_ws_floats(int M, int F, int K) {
-    if (M < 1 || F < 1 || F > 32 || K < 64 || K > 512 || K % 64) return -1;      // -1: shape not covered (callers keep the separate launches)
-    return (int64_t)head_nwg(M) * (2 * 4 * (K / 64) * 64 * 4);               // accumulator-order units incl. the padding rows f >= F
+    if (!head_covers(M, F, K)) return -1;                                           // -1: shape not covered (callers keep the separate launches)
+    return (int64_t)head_nwg(M, K) * (2 * (K / 16) * 64 * 4);                     // accumulator-order units (2 x NW x NT x 64 float4) incl. the padding rows f >= F
 }
 
 extern "C" int vame_head_stream_f32(const float* Y, int64_t y_ld, int64_t y_seg, int64_t y_seg_stride, int M, int F, int K, const float* W,
@@ -312,7 +328,7 @@ extern "C" int vame_head_stream_f32(const float* Y, int64_t y_ld, int64_t y_seg,
                                     float* dpred, float* dY, int64_t dy_ld, float* loss, float* dW, float* ws, void* stream) {
     VAME_CHECK_ARG(Y && W && bias && tgt && dpred && dY && loss && dW && ws, VAME_E_BADARG, "head_stream: null pointer");
     VAME_CHECK_ARG(vame_head_stream_ws_floats(M, F, K) > 0 && y_seg >= 1, VAME_E_SHAPE,
-                   "head_stream: M=%d F=%d (1..32) K=%d (a multiple of 64 up to 512)", M, F, K);
+                   "head_stream: M=%d F=%d (1..32) K=%d (a multiple of 64 up to 512 or of 128 up to 1024)", M, F, K);
     VAME_CHECK_ARG(y_ld % 4 == 0 && y_seg_stride % 4 == 0 && (uintptr_t)Y % 16 == 0 && (uintptr_t)W % 16 == 0 && dy_ld >= K && dy_ld % 4 == 0 &&
                        (uintptr_t)dY % 16 == 0, VAME_E_SHAPE,
                    "head_stream: state rows, W and dY rows must be 16-byte aligned (y_ld=%lld, y_seg_stride=%lld, dy_ld=%lld)", (long long)y_ld,
@@ -321,11 +337,11 @@ extern "C" int vame_head_stream_f32(const float* Y, int64_t y_ld, int64_t y_seg,
     P.Y = Y; P.y_ld = y_ld; P.y_seg = y_seg; P.y_seg_stride = y_seg_stride; P.W = W; P.bias = bias; P.tgt = tgt; P.tgt_row = tgt_row;
     P.tgt_off = tgt_off; P.pred = pred; P.dpred = dpred; P.dY = dY; P.dy_ld = dy_ld; P.loss = loss; P.ws = ws; P.M = M; P.F = F; P.K = K;
     P.ntiles = (int)cdiv64(M, HS_ROWS); P.gscale = gscale;
-    const int nwg = head_nwg(M);
+    const int nwg = head_nwg(M, K), NWv = head_nw(K);
     const int rc = F <= 24 ? head_dispatch<6>(P, nwg, (hipStream_t)stream) : head_dispatch<8>(P, nwg, (hipStream_t)stream);
     if (rc != VAME_OK) return rc;
     VAME_LAUNCH_CHECK("head_stream");
-    hipLaunchKernelGGL(head_dw_reduce_kernel, dim3((unsigned)(2 * 4 * (K / 64))), dim3(1024), 0, (hipStream_t)stream, reinterpret_cast<const f32x4*>(ws), nwg, K / 64, F, K, dW);
+    hipLaunchKernelGGL(head_dw_reduce_kernel, dim3((unsigned)(2 * (K / 16))), dim3(1024), 0, (hipStream_t)stream, reinterpret_cast<const f32x4*>(ws), nwg, K / 16 / NWv, NWv, F, K, dW);
     VAME_LAUNCH_CHECK("head_dw_reduce");
     return VAME_OK;
 }
