@@ -289,6 +289,19 @@ def test_unaligned_feature_and_latent_dims(hip):
     check_odd_dims_vs_oracle("cuda", F=12, Z=30, H=64, T=6, FS=3, B=33)
 
 
+def test_more_than_32_features_keeps_the_separate_head_launches(hip):
+    """num_features > 32: outside the streaming output head's (and the fused layer-0 input projection's) range -- the step falls back to the
+    separate contractions; whole train step against the numpy oracle."""
+    from vame_amd import ops
+    calls, orig = [], ops.head_stream
+    ops.head_stream = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]
+    try:
+        check_odd_dims_vs_oracle("cuda", F=36, Z=7, H=32, T=5, FS=2, B=9)
+    finally:
+        ops.head_stream = orig
+    assert not calls
+
+
 def test_latent_width_above_64(hip):
     """zdims > 64 leaves the LDS-resident nuclear-norm kernel for the state-buffer one; everything else is width-agnostic."""
     check_odd_dims_vs_oracle("cuda", F=12, Z=72, H=32, T=5, FS=2, B=90)
