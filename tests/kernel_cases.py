@@ -932,6 +932,15 @@ def check_colsum(dev):
         o = torch.zeros(C, device=dev)
         ops.colsum(T_(b, dev), 0, R, C, C, o, 0)
         np.testing.assert_allclose(N_(o), b.astype(np.float64).sum(0), atol=2e-3)
+    # wide aligned matrices with >= 1024 rows: the 16-byte form (all of a thread's loads in flight); a column offset inside wider rows, ragged last
+    # slab, a column count that is not a multiple of 256, accumulate
+    for (R, C, ld, off) in ((4096, 512, 512, 0), (1030, 260, 520, 8), (9001, 768, 1024, 256)):
+        b = rng.standard_normal((R, ld)).astype(np.float32)
+        o = torch.full((C + 4,), 2.0, device=dev)
+        ops.colsum(T_(b, dev), off, R, C, ld, o, 0, accumulate=True)
+        got = N_(o)
+        np.testing.assert_allclose(got[:C], 2.0 + b[:, off:off + C].astype(np.float64).sum(0), atol=3e-3)
+        assert (got[C:] == 2.0).all()
 
 
 def check_colsum_batch(dev):
